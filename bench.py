@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the query x database Smith-Waterman scan (BASELINE.json metric) on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one full pass of the hot path over the workload held in HBM: every query of the rank's shard
+scored against the whole resident database (s4g_scan), the per-query top-400 selection, and for N > 1 the
+RCCL all-gather of the per-query top-hit lists.  Workload = BASELINE.json configs[1]
+(1k synthetic queries len U[300,400] x 100k-sequence synthetic DB, BLOSUM62, gap 10/1) per GPU:
+queries are sharded across ranks and the DB is replicated (SURVEY.md 8e query-shard mode), so per-GPU work is
+fixed as N grows ("weak").  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E column model, 2 int32 loads + 2 stores per cell
+TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
+
+
+def cpu_baseline(cfg, n_threads, target_seconds=15.0):
+    """The scalar oracle (kind "port": a restatement, NOT swsharp's SSE code) timed on this host's cores on a
+    bounded sample of the same workload."""
+    import oracle
+    M = oracle.blosum62()
+    q_off, t_off = cfg["q_off"], cfg["t_off"]
+
+    def run(nq, nt):
+        t0 = time.perf_counter()
+        oracle.scan_flat(cfg["q_codes"], q_off[:nq + 1].copy(), cfg["t_codes"], t_off[:nt + 1].copy(), M, 10, 1, n_threads)
+        dt = time.perf_counter() - t0
+        cells = float(q_off[nq]) * float(t_off[nt])
+        return cells, dt
+
+    cells, dt = run(min(8, len(q_off) - 1), min(512, len(t_off) - 1))      # pilot
+    rate = cells / max(dt, 1e-6)
+    nq = min(16, len(q_off) - 1)
+    per_target = float(q_off[nq]) * (float(t_off[-1]) / (len(t_off) - 1))
+    nt = int(min(len(t_off) - 1, max(512, rate * target_seconds / per_target)))
+    cells, dt = run(nq, nt)
+    return dict(value=round(cells / dt / 1e9, 3), unit="GCUPS", cores=n_threads, kind="port",
+                sample=f"first {nq} queries x first {nt} targets of the same workload, {cells:.3e} cells in {dt:.1f} s, "
+                       f"scalar C oracle (oracle/sw_oracle.c), {n_threads} pthreads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=1000, help="queries per GPU")
+    ap.add_argument("--targets", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sift4g_amd as s4g
+    from sift4g_amd import synth
+    from sift4g_amd.device import scan_cells, scan_plan
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: identical generator on every rank; DB replicated, queries sharded ----
+    cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"], device=local_rank)
+    allq = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"], device=local_rank)
+    q_begin, q_count = rank * args.queries, args.queries
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    cells_rank = scan_cells(db, allq, q_begin, q_count)
+    plan = scan_plan(db, allq, scorer)
+    scores = torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count)
+        if i is not None:
+            ev[i][1].record()
+        ids, sc, cnt = s4g.topk(db, scores, TOPK, 1)
+        if world > 1:
+            mine = torch.from_numpy(np.stack([ids.astype(np.int64), sc.astype(np.int64)], axis=0)).to(dev)
+            allhits = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+            dist.all_gather_into_tensor(allhits, mine)
+            return allhits
+        return ids, sc, cnt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+
+    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
+    c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    dt, kern_ms = float(t[0]), float(t[1])
+    cells_total = float(c[0])
+
+    if rank == 0:
+        gcups = cells_total * args.steps / dt / 1e9
+        kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        achieved = kern_gcups * BYTES_PER_CELL            # GB/s of ALGORITHMIC bytes moved by the scan kernel
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes, if collected
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                if pj.get("kernel") == plan["kernel"] and pj.get("workload_cells") == cells_rank:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GCUPS (SW cell updates/s) on query x DB scan",
+            "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.queries} synthetic queries/GPU len U[300,400] x "
+                                   f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
+                                   f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",
+                       "cells_per_step": cells_total, "parallelism": f"query-shard x{world}, DB replicated",
+                       "kernel": plan["kernel"], "grid_blocks": plan["grid_blocks"], "strip_rows": plan["strip_rows"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
+                         "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                         "note": "register-tiled kernel moves ~17/R B per cell, so frac may exceed 1; the binding limit is VALU issue"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

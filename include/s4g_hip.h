@@ -1,0 +1,134 @@
+/*
+ * s4g_hip.h -- C ABI of libs4g_hip.so, the MI355X (gfx950) Smith-Waterman
+ * database scorer that replaces the scoring step of swsharp's alignDatabase
+ * for sift4g.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point
+ * returns S4G_OK (0) or a negative error code; s4g_last_error() gives the
+ * text.  The library has NO CPU fallback: without a usable HIP device every
+ * device entry point returns S4G_ERR_NO_DEVICE.
+ *
+ * Residue codes are letter - 'A' (0..25), the alphabet sift4g relies on
+ * (/root/reference/sift4g/src/hash.cpp:16-19).  Sequences are passed as one
+ * concatenated code array plus n+1 offsets (CSR style).
+ *
+ * Reference interface each entry point replaces (the swsharp source itself is
+ * an absent submodule; signatures are taken from sift4g's call sites):
+ *
+ *   s4g_device_count / s4g_device_check
+ *       cudaGetCards(int**, int*) / cudaCheckCards(int*, int)
+ *       /root/reference/sift4g/src/main.cpp:183-186
+ *   s4g_scorer_create / s4g_scorer_destroy
+ *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
+ *       /root/reference/sift4g/src/main.cpp:208,223
+ *   s4g_db_create / s4g_db_destroy
+ *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
+ *       chainDatabaseDelete
+ *       /root/reference/sift4g/src/database_alignment.cpp:80,92
+ *   s4g_queries_create / s4g_queries_destroy
+ *       the `Chain* query` argument of alignDatabase
+ *       /root/reference/sift4g/src/database_alignment.cpp:83-86
+ *   s4g_scan / s4g_scan_host / s4g_score_lists_host
+ *       step 1 of swsharp alignDatabase(...): the optimal local affine-gap
+ *       score of the query against every target of the ChainDatabase
+ *       /root/reference/sift4g/src/database_alignment.cpp:83-86
+ *       (s4g_score_lists_host = the per-query candidate lists built by
+ *       createFilteredDatabase, database_alignment.cpp:136-162)
+ *   s4g_topk_host
+ *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
+ *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
+ *       and the merge semantics of dbAlignmentsMerge (:101-102)
+ */
+#ifndef S4G_HIP_H
+#define S4G_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S4G_OK               0
+#define S4G_ERR_NO_DEVICE   -1   /* no HIP device / HIP runtime error at init */
+#define S4G_ERR_INVALID     -2   /* bad argument */
+#define S4G_ERR_HIP         -3   /* HIP runtime call failed */
+#define S4G_ERR_NOMEM       -4
+
+#define S4G_ALPHABET        26   /* letter - 'A' */
+
+typedef struct s4g_scorer  s4g_scorer;   /* substitution table + gap penalties (host object) */
+typedef struct s4g_db      s4g_db;       /* length-sorted, lane-transposed database resident in HBM */
+typedef struct s4g_queries s4g_queries;  /* query set resident in HBM */
+
+/* text of the last error on the calling thread ("" if none) */
+const char* s4g_last_error(void);
+
+/* library/ABI version, bumped on any signature change */
+int s4g_abi_version(void);
+
+/* number of usable HIP devices; S4G_ERR_NO_DEVICE if the runtime cannot start */
+int s4g_device_count(int* count);
+/* 1 if every card id in cards[0..n) names a usable device (n == 0 passes), else 0 */
+int s4g_device_check(const int* cards, int n);
+
+/* Built-in substitution tables by the names scorerCreateMatrix accepts
+ * (/root/reference/sift4g/src/main.cpp:73,208,304-314).  Round 1 ships BLOSUM_62
+ * (the reference default); other names return S4G_ERR_INVALID.
+ * table26x26 receives 676 int32, letter-indexed (code = letter - 'A'). */
+int s4g_matrix_by_name(const char* name, int32_t* table26x26);
+
+/* table: 26x26 row-major int32, table[a*26+b] = score(a, b); |entry| <= 127.
+ * gap_open = cost of the first gap residue, gap_extend = cost of each further
+ * one (a gap of k residues costs gap_open + (k-1)*gap_extend); 0 <= extend <= open. */
+int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_open, int gap_extend);
+int s4g_scorer_destroy(s4g_scorer* s);
+
+/* Upload a database to `device`.  codes[offsets[i] .. offsets[i+1]) are the
+ * residue codes of target i.  Host buffers may be freed on return. */
+int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs);
+int s4g_db_destroy(s4g_db* db);
+/* any out pointer may be NULL */
+int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, uint64_t* padded_residues, uint64_t* hbm_bytes);
+
+int s4g_queries_create(s4g_queries** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_queries);
+int s4g_queries_destroy(s4g_queries* q);
+
+/* DP cells of scanning queries [q_begin, q_begin+q_count) against the whole
+ * database: sum over pairs of Lq*Lt (the GCUPS numerator). */
+int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint64_t* cells);
+
+/* Score queries [q_begin, q_begin+q_count) against every target.
+ * d_scores: DEVICE pointer to q_count * n_seqs int32, row = query (relative to
+ * q_begin), column = target in the ORIGINAL order given to s4g_db_create.
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+             const s4g_scorer* scorer, int32_t* d_scores, void* stream);
+
+/* Same, synchronous, scores copied to host memory h_scores[q_count * n_seqs]. */
+int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                  const s4g_scorer* scorer, int32_t* h_scores);
+
+/* Candidate-list mode (what sift4g's wrapper does per query): query i is
+ * scored against targets cand_ids[cand_offsets[i] .. cand_offsets[i+1]) only.
+ * h_scores[cand_offsets[n_queries]] receives the scores in list order. */
+int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t* cand_offsets,
+                         const uint32_t* cand_ids, const s4g_scorer* scorer, int32_t* h_scores);
+
+/* Per-query top-k of a device score matrix [q_count][n_seqs] (as written by
+ * s4g_scan): the k highest scores with score >= min_score, ordered by score
+ * descending then target id ascending.  h_ids / h_scores: q_count * k entries
+ * (unused tail filled with id 0xFFFFFFFF / score 0); h_counts[q] = entries used. */
+int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+                  uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream);
+
+/* Introspection for measurement (bench.py): name and launch geometry of the
+ * kernel s4g_scan dispatches for this (db, queries, scorer) combination. */
+int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer,
+                  char* kernel_name, size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
+                  uint32_t* strip_rows, uint64_t* workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S4G_HIP_H */

@@ -1,0 +1,522 @@
+// s4g_hip.hip -- C ABI (include/s4g_hip.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: database packing (length sort, 64-lane
+// groups, lane-transposed residues), residency in HBM, persistent-grid launch.
+// Mirrors what swsharp's chainDatabaseCreate + alignDatabase(step 1) do for
+// sift4g (/root/reference/sift4g/src/database_alignment.cpp:80-86).
+#include "../../include/s4g_hip.h"
+#include "sw_kernels.hip.h"
+#include "matrices.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace s4g;
+
+#define S4G_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(S4G_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+int device_count_raw() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return n;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct s4g_scorer {
+    int32_t table[26 * 26];
+    int8_t mat32[32 * 32];
+    int open, ext;
+    int max_score;
+};
+
+struct s4g_db {
+    int device = 0;
+    uint32_t n_seqs = 0, n_groups = 0, max_len4 = 0;
+    uint64_t residues = 0, padded_residues = 0, hbm_bytes = 0;
+    uint32_t* d_res = nullptr;
+    uint64_t* d_grp_off = nullptr;
+    uint32_t* d_grp_len4 = nullptr;
+    uint32_t* d_grp_perm = nullptr;
+    std::vector<uint32_t> order;   // sorted position -> original index
+    std::vector<uint32_t> rank;    // original index -> sorted position
+    std::vector<uint32_t> len;     // original index -> length
+    // per-device scratch, created lazily and reused (scan calls on one db are serialized)
+    mutable std::mutex mu;
+    mutable int32_t* d_ws = nullptr;
+    mutable uint64_t ws_bytes = 0;
+    mutable unsigned* d_counter = nullptr;
+    mutable int8_t* d_mat = nullptr;
+    mutable uint32_t grid_blocks = 0;
+};
+
+struct s4g_queries {
+    int device = 0;
+    uint32_t n = 0;
+    uint8_t* d_codes = nullptr;
+    uint64_t* d_off = nullptr;
+    uint32_t* d_len = nullptr;
+    std::vector<uint32_t> len;
+    uint32_t max_len = 0;
+};
+
+// ---------------------------------------------------------------------------
+S4G_API const char* s4g_last_error(void) { return g_err.c_str(); }
+S4G_API int s4g_abi_version(void) { return 1; }
+
+S4G_API int s4g_device_count(int* count) {
+    if (!count) return fail(S4G_ERR_INVALID, "count is NULL");
+    int n = device_count_raw();
+    if (n < 0) { *count = 0; return fail(S4G_ERR_NO_DEVICE, "HIP runtime reports no usable device"); }
+    *count = n;
+    return S4G_OK;
+}
+
+S4G_API int s4g_device_check(const int* cards, int n) {
+    if (n == 0) return 1;
+    if (n < 0 || !cards) return 0;
+    int have = device_count_raw();
+    if (have <= 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (cards[i] < 0 || cards[i] >= have) return 0;
+    return 1;
+}
+
+S4G_API int s4g_matrix_by_name(const char* name, int32_t* table26x26) {
+    if (!name || !table26x26) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (!matrix_by_name(name, table26x26)) return fail(S4G_ERR_INVALID, "unknown substitution matrix '%s' (available: BLOSUM_62)", name);
+    return S4G_OK;
+}
+
+S4G_API int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_open, int gap_extend) {
+    if (!out || !table) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (gap_extend < 0 || gap_open < gap_extend)
+        return fail(S4G_ERR_INVALID, "need 0 <= gap_extend <= gap_open (got open=%d extend=%d)", gap_open, gap_extend);
+    s4g_scorer* s = new s4g_scorer();
+    s->open = gap_open;
+    s->ext = gap_extend;
+    s->max_score = 0;
+    for (int i = 0; i < 32 * 32; ++i) s->mat32[i] = (int8_t)kPadScore;
+    for (int a = 0; a < 26; ++a)
+        for (int b = 0; b < 26; ++b) {
+            int v = table[a * 26 + b];
+            if (v < -127 || v > 127) { delete s; return fail(S4G_ERR_INVALID, "table entry %d out of int8 range", v); }
+            s->table[a * 26 + b] = v;
+            s->mat32[a * 32 + b] = (int8_t)v;
+            s->max_score = std::max(s->max_score, v);
+        }
+    *out = s;
+    return S4G_OK;
+}
+
+S4G_API int s4g_scorer_destroy(s4g_scorer* s) { delete s; return S4G_OK; }
+
+// ---------------------------------------------------------------------------
+S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs) {
+    if (!out || !offsets || (!codes && n_seqs && offsets[n_seqs])) return fail(S4G_ERR_INVALID, "NULL argument");
+    int have = device_count_raw();
+    if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
+    if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    DeviceGuard guard(device);
+
+    s4g_db* db = new s4g_db();
+    db->device = device;
+    db->n_seqs = n_seqs;
+    db->len.resize(n_seqs);
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        uint64_t l = offsets[i + 1] - offsets[i];
+        if (offsets[i + 1] < offsets[i] || l > 0x7FFFFFF0ull) { delete db; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
+        db->len[i] = (uint32_t)l;
+        db->residues += l;
+    }
+    // length sort, longest first (ties by original index): items are issued in
+    // this order so the longest work runs first and the tail is short work.
+    db->order.resize(n_seqs);
+    std::iota(db->order.begin(), db->order.end(), 0u);
+    std::stable_sort(db->order.begin(), db->order.end(),
+                     [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
+    db->rank.resize(n_seqs);
+    for (uint32_t p = 0; p < n_seqs; ++p) db->rank[db->order[p]] = p;
+
+    const uint32_t G = (n_seqs + 63) / 64;
+    db->n_groups = G;
+    std::vector<uint64_t> grp_off(G);
+    std::vector<uint32_t> grp_len4(G);
+    std::vector<uint32_t> perm((size_t)G * 64, 0xFFFFFFFFu);
+    uint64_t dwords = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        uint32_t lg = db->len[db->order[(size_t)g * 64]];
+        grp_len4[g] = (lg + 3) / 4;
+        grp_off[g] = dwords;
+        dwords += (uint64_t)grp_len4[g] * 64;
+        db->max_len4 = std::max(db->max_len4, grp_len4[g]);
+    }
+    db->padded_residues = dwords * 4;
+    std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
+    for (uint32_t p = 0; p < n_seqs; ++p) {
+        const uint32_t g = p >> 6, lane = p & 63, id = db->order[p];
+        perm[p] = id;
+        const uint8_t* src = codes + offsets[id];
+        const uint32_t l = db->len[id];
+        uint8_t* base = reinterpret_cast<uint8_t*>(res.data() + grp_off[g]);
+        for (uint32_t j = 0; j < l; ++j) {
+            uint8_t c = src[j];
+            if (c >= 26) { delete db; return fail(S4G_ERR_INVALID, "residue code %u out of range in target %u", c, id); }
+            base[((size_t)(j >> 2) * 64 + lane) * 4 + (j & 3)] = c;
+        }
+    }
+    auto cleanup = [&]() { s4g_db_destroy(db); };
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e != hipSuccess) return e;
+        db->hbm_bytes += bytes;
+        return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    hipError_t e;
+    if ((e = up((void**)&db->d_res, res.data(), dwords * 4)) != hipSuccess ||
+        (e = up((void**)&db->d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess ||
+        (e = up((void**)&db->d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess ||
+        (e = up((void**)&db->d_grp_perm, perm.data(), (size_t)G * 64 * 4)) != hipSuccess) {
+        cleanup();
+        return fail(S4G_ERR_HIP, "database upload failed: %s", hipGetErrorString(e));
+    }
+    *out = db;
+    return S4G_OK;
+}
+
+S4G_API int s4g_db_destroy(s4g_db* db) {
+    if (!db) return S4G_OK;
+    DeviceGuard guard(db->device);
+    (void)hipFree(db->d_res); (void)hipFree(db->d_grp_off); (void)hipFree(db->d_grp_len4); (void)hipFree(db->d_grp_perm);
+    (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat);
+    delete db;
+    return S4G_OK;
+}
+
+S4G_API int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, uint64_t* padded_residues, uint64_t* hbm_bytes) {
+    if (!db) return fail(S4G_ERR_INVALID, "db is NULL");
+    if (n_seqs) *n_seqs = db->n_seqs;
+    if (residues) *residues = db->residues;
+    if (padded_residues) *padded_residues = db->padded_residues;
+    if (hbm_bytes) *hbm_bytes = db->hbm_bytes + db->ws_bytes;
+    return S4G_OK;
+}
+
+// ---------------------------------------------------------------------------
+S4G_API int s4g_queries_create(s4g_queries** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n) {
+    if (!out || !offsets || (!codes && n && offsets[n])) return fail(S4G_ERR_INVALID, "NULL argument");
+    int have = device_count_raw();
+    if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
+    if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    DeviceGuard guard(device);
+    s4g_queries* q = new s4g_queries();
+    q->device = device;
+    q->n = n;
+    q->len.resize(n);
+    std::vector<uint64_t> off(n ? n : 1);
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t l = offsets[i + 1] - offsets[i];
+        if (offsets[i + 1] < offsets[i] || l > 0x7FFFFFF0ull) { delete q; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
+        q->len[i] = (uint32_t)l;
+        q->max_len = std::max(q->max_len, (uint32_t)l);
+        off[i] = bytes;
+        bytes += (l + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;
+    }
+    std::vector<uint8_t> padded(bytes ? bytes : 1, (uint8_t)kPadCode);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < q->len[i]; ++j) {
+            uint8_t c = codes[offsets[i] + j];
+            if (c >= 26) { delete q; return fail(S4G_ERR_INVALID, "residue code %u out of range in query %u", c, i); }
+            padded[off[i] + j] = c;
+        }
+    hipError_t e;
+    if ((e = hipMalloc((void**)&q->d_codes, padded.size())) != hipSuccess ||
+        (e = hipMalloc((void**)&q->d_off, off.size() * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&q->d_len, (n ? n : 1) * 4)) != hipSuccess ||
+        (e = hipMemcpy(q->d_codes, padded.data(), padded.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(q->d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (n && (e = hipMemcpy(q->d_len, q->len.data(), (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess)) {
+        s4g_queries_destroy(q);
+        return fail(S4G_ERR_HIP, "query upload failed: %s", hipGetErrorString(e));
+    }
+    *out = q;
+    return S4G_OK;
+}
+
+S4G_API int s4g_queries_destroy(s4g_queries* q) {
+    if (!q) return S4G_OK;
+    DeviceGuard guard(q->device);
+    (void)hipFree(q->d_codes); (void)hipFree(q->d_off); (void)hipFree(q->d_len);
+    delete q;
+    return S4G_OK;
+}
+
+S4G_API int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint64_t* cells) {
+    if (!db || !q || !cells) return fail(S4G_ERR_INVALID, "NULL argument");
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    uint64_t lq = 0;
+    for (uint32_t i = 0; i < q_count; ++i) lq += q->len[q_begin + i];
+    *cells = lq * db->residues;
+    return S4G_OK;
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kStripRows = 32;
+
+struct Plan {
+    const char* name;
+    uint32_t grid, block, strip;
+    uint64_t ws_slot;   // int32 per wave slot
+    uint64_t ws_bytes;
+};
+
+int make_plan(const s4g_db* db, Plan* p) {
+    if (db->grid_blocks == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, db->device));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_scan_i32<kStripRows>, kBlock, 0));
+        if (per_cu < 1) per_cu = 1;
+        db->grid_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }
+    p->name = "sw_scan_i32<32>";
+    p->grid = db->grid_blocks;
+    p->block = kBlock;
+    p->strip = kStripRows;
+    p->ws_slot = 2ull * (db->max_len4 ? db->max_len4 : 1) * 64 * 4;
+    p->ws_bytes = p->ws_slot * 4 * p->grid * kWavesPerBlock;
+    return S4G_OK;
+}
+
+int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStream_t stream) {
+    if (db->ws_bytes < p.ws_bytes) {
+        if (db->d_ws) HIP_TRY(hipFree(db->d_ws));
+        db->d_ws = nullptr; db->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&db->d_ws, p.ws_bytes));
+        db->ws_bytes = p.ws_bytes;
+    }
+    if (!db->d_counter) HIP_TRY(hipMalloc((void**)&db->d_counter, 256));
+    if (!db->d_mat) HIP_TRY(hipMalloc((void**)&db->d_mat, 1024));
+    HIP_TRY(hipMemcpyAsync(db->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
+    return S4G_OK;
+}
+
+}  // namespace
+
+S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, char* kernel_name,
+                          size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
+                          uint32_t* strip_rows, uint64_t* workspace_bytes) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(db->device);
+    std::lock_guard<std::mutex> lk(db->mu);
+    Plan p;
+    int rc = make_plan(db, &p);
+    if (rc) return rc;
+    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", p.name);
+    if (grid_blocks) *grid_blocks = p.grid;
+    if (block_threads) *block_threads = p.block;
+    if (strip_rows) *strip_rows = p.strip;
+    if (workspace_bytes) *workspace_bytes = p.ws_bytes;
+    return S4G_OK;
+}
+
+S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                     const s4g_scorer* scorer, int32_t* d_scores, void* stream_) {
+    if (!db || !q || !scorer || (!d_scores && q_count && db->n_seqs)) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
+    if ((uint64_t)db->n_groups * q_count >= 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "too many work items; split the query range");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    std::lock_guard<std::mutex> lk(db->mu);
+    Plan p;
+    int rc = make_plan(db, &p);
+    if (rc) return rc;
+    rc = ensure_scratch(db, scorer, p, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 4, stream));
+    ScanArgs a;
+    a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.mat = db->d_mat;
+    a.scores = d_scores; a.score_stride = db->n_seqs;
+    a.ws = db->d_ws; a.ws_slot = p.ws_slot;
+    a.counter = db->d_counter;
+    a.n_groups = db->n_groups; a.q_begin = q_begin; a.q_count = q_count;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(p.grid), dim3(p.block), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+S4G_API int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                          const s4g_scorer* scorer, int32_t* h_scores) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
+    if (!h_scores) return fail(S4G_ERR_INVALID, "h_scores is NULL");
+    DeviceGuard guard(db->device);
+    int32_t* d = nullptr;
+    size_t bytes = (size_t)q_count * db->n_seqs * 4;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    int rc = s4g_scan(db, q, q_begin, q_count, scorer, d, nullptr);
+    if (rc == S4G_OK) {
+        hipError_t e = hipMemcpy(h_scores, d, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(S4G_ERR_HIP, "score download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+S4G_API int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t* cand_offsets,
+                                 const uint32_t* cand_ids, const s4g_scorer* scorer, int32_t* h_scores) {
+    // Round 1: the scan is cheap enough on MI355X that candidate lists are served by
+    // scanning the resident database in query batches and picking the listed columns.
+    if (!db || !q || !scorer || !cand_offsets) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q->n == 0 || cand_offsets[q->n] == 0) return S4G_OK;
+    if (!cand_ids || !h_scores) return fail(S4G_ERR_INVALID, "NULL argument");
+    for (uint64_t i = 0; i < cand_offsets[q->n]; ++i)
+        if (cand_ids[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "candidate id %u out of range", cand_ids[i]);
+    const uint32_t batch = std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>(q->n, (1ull << 28) / std::max<uint32_t>(1, db->n_seqs)));
+    std::vector<int32_t> row((size_t)batch * db->n_seqs);
+    for (uint32_t b = 0; b < q->n; b += batch) {
+        uint32_t cnt = std::min(batch, q->n - b);
+        int rc = s4g_scan_host(db, q, b, cnt, scorer, row.data());
+        if (rc) return rc;
+        for (uint32_t i = 0; i < cnt; ++i)
+            for (uint64_t k = cand_offsets[b + i]; k < cand_offsets[b + i + 1]; ++k)
+                h_scores[k] = row[(size_t)i * db->n_seqs + cand_ids[k]];
+    }
+    return S4G_OK;
+}
+
+// ---------------------------------------------------------------------------
+// top-k: one block per query, iterative threshold selection in a single pass
+// over the score row (histogram of scores -> cut score -> compaction).
+namespace {
+
+constexpr int kTopkBlock = 256;
+constexpr int kHistBins = 4096;
+
+__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k,
+                                                        int32_t min_score, uint32_t* __restrict__ out_ids,
+                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                        uint32_t cap) {
+    // Pass 1: histogram of clamp(score, 0, kHistBins-1); pass 2: emit everything with
+    // score > cut, plus the score == cut entries (smallest ids first is restored on host by the sort).
+    __shared__ unsigned hist[kHistBins];
+    __shared__ int cut_s;
+    __shared__ unsigned n_out;
+    const int32_t* row = scores + (uint64_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < kHistBins; i += kTopkBlock) hist[i] = 0;
+    if (threadIdx.x == 0) n_out = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kTopkBlock) {
+        int v = row[i];
+        if (v >= min_score) atomicAdd(&hist[v < 0 ? 0 : (v >= kHistBins ? kHistBins - 1 : v)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned acc = 0; int c = kHistBins - 1;
+        for (; c > 0; --c) { acc += hist[c]; if (acc >= k) break; }
+        cut_s = c;  // every score > cut is kept; scores == cut may overflow k (host trims)
+    }
+    __syncthreads();
+    const int cut = cut_s;
+    for (uint32_t i = threadIdx.x; i < n; i += kTopkBlock) {
+        int v = row[i];
+        if (v >= min_score && v >= cut) {
+            unsigned pos = atomicAdd(&n_out, 1u);
+            if (pos < cap) { out_ids[(uint64_t)blockIdx.x * cap + pos] = i; out_scores[(uint64_t)blockIdx.x * cap + pos] = v; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[blockIdx.x] = n_out;
+}
+
+}  // namespace
+
+S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+                          uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream_) {
+    if (!db || !d_scores || !h_ids || !h_scores || !h_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q_count == 0) return S4G_OK;
+    if (k == 0) { memset(h_counts, 0, (size_t)q_count * 4); return S4G_OK; }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    const uint32_t n = db->n_seqs;
+    // candidates above the cut: at most k-1 strictly above plus all ties at the cut; give ties room.
+    uint32_t cap = std::min<uint64_t>(n, (uint64_t)k * 4 + 1024);
+    for (;;) {
+        uint32_t *d_ids = nullptr, *d_counts = nullptr; int32_t* d_sc = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_ids, (size_t)q_count * cap * 4));
+        HIP_TRY(hipMalloc((void**)&d_sc, (size_t)q_count * cap * 4));
+        HIP_TRY(hipMalloc((void**)&d_counts, (size_t)q_count * 4));
+        hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, stream, d_scores, n, k, min_score, d_ids, d_sc, d_counts, cap);
+        std::vector<uint32_t> ids((size_t)q_count * cap), counts(q_count);
+        std::vector<int32_t> sc((size_t)q_count * cap);
+        hipError_t e = hipMemcpyAsync(counts.data(), d_counts, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ids.data(), d_ids, ids.size() * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sc.data(), d_sc, sc.size() * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_ids); (void)hipFree(d_sc); (void)hipFree(d_counts);
+        if (e != hipSuccess) return fail(S4G_ERR_HIP, "top-k failed: %s", hipGetErrorString(e));
+        uint32_t worst = 0;
+        for (uint32_t q = 0; q < q_count; ++q) worst = std::max(worst, counts[q]);
+        if (worst > cap && cap < n) { cap = std::min<uint64_t>(n, (uint64_t)worst); continue; }  // rare: huge tie at the cut
+        std::vector<std::pair<int32_t, uint32_t>> v;
+        for (uint32_t q = 0; q < q_count; ++q) {
+            uint32_t m = std::min(counts[q], cap);
+            v.resize(m);
+            for (uint32_t i = 0; i < m; ++i) v[i] = {sc[(size_t)q * cap + i], ids[(size_t)q * cap + i]};
+            std::sort(v.begin(), v.end(), [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& b) {
+                return a.first != b.first ? a.first > b.first : a.second < b.second;
+            });
+            uint32_t keep = std::min<uint32_t>(m, k);
+            for (uint32_t i = 0; i < k; ++i) {
+                h_ids[(size_t)q * k + i] = i < keep ? v[i].second : 0xFFFFFFFFu;
+                h_scores[(size_t)q * k + i] = i < keep ? v[i].first : 0;
+            }
+            h_counts[q] = keep;
+        }
+        return S4G_OK;
+    }
+}

@@ -1,0 +1,201 @@
+// sw_kernels.hip.h -- gfx950 Smith-Waterman database-scan kernels.
+//
+// Replaces the scoring step of swsharp's alignDatabase as sift4g calls it
+// (/root/reference/sift4g/src/database_alignment.cpp:83-86; swsharp itself is
+// an absent submodule, so the kernels are designed from the recurrence, not
+// from any reference kernel):
+//
+//   E[i][j] = max(E[i][j-1] - ext, H[i][j-1] - open)
+//   F[i][j] = max(F[i-1][j] - ext, H[i-1][j] - open)
+//   H[i][j] = max(0, H[i-1][j-1] + M[q_i][t_j], E[i][j], F[i][j]),  score = max H
+//
+// Mapping to CDNA4 (inter-sequence): one database sequence per lane, 64
+// length-sorted sequences per wave ("group"), targets stored lane-transposed
+// (4 residues per dword, dword c*64+lane) so every wave load is one contiguous
+// 256-B line.  The query is cut into strips of R rows whose H and E values
+// live in VGPRs; for a strip the wave builds a private LDS "strip profile"
+//   prof[k][t][16] = M[q_{16k+b}][t]   (int8, b = 0..15)
+// so one ds_read_b128 per lane and column delivers 16 substitution scores.
+// The only HBM traffic that scales with the DP is the strip boundary: H and F
+// of the strip's last row, one 16-B load and store per lane and 4 columns
+// (lane-contiguous, 1 KiB per wave instruction).
+//
+// Arithmetic: E and F are kept clamped at 0 (max(x,0) commutes with the
+// recurrence because H >= 0), which turns "x - c" into one saturating
+// unsigned subtract and removes the explicit max(.,0) from H.  Per cell:
+// add, max3, max(best), 3 saturating subs, 2 max  (8 VALU ops, int32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s4g {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kPadCode = 31;        // target / query padding residue
+constexpr int kPadScore = -64;      // substitution score of any pair involving kPadCode
+constexpr int kQueryAlign = 64;     // queries are padded to a multiple of this (>= max strip height)
+
+struct ScanArgs {
+    const uint32_t* __restrict__ db_res;    // lane-transposed residues, 4 per dword
+    const uint64_t* __restrict__ grp_off;   // [G] dword offset of group g in db_res
+    const uint32_t* __restrict__ grp_len4;  // [G] number of 4-column chunks of group g
+    const uint32_t* __restrict__ grp_perm;  // [G*64] original target index of (g, lane); ~0u = empty lane
+    const uint8_t* __restrict__ q_codes;    // queries padded with kPadCode to kQueryAlign
+    const uint64_t* __restrict__ q_off;     // [Q] byte offset of query q in q_codes
+    const uint32_t* __restrict__ q_len;     // [Q] true length
+    const int8_t* __restrict__ mat;         // [32][32] int8, row = query code, col = target code
+    int32_t* __restrict__ scores;           // [q_count][score_stride]
+    uint64_t score_stride;
+    int32_t* __restrict__ ws;               // strip-boundary workspace
+    uint64_t ws_slot;                       // int32 elements per wave slot
+    unsigned* counter;                      // work-queue head, zeroed before launch
+    uint32_t n_groups;
+    uint32_t q_begin, q_count;
+    uint32_t open, ext;
+};
+
+__device__ __forceinline__ unsigned usub_sat(unsigned a, unsigned b) {
+    return __builtin_elementwise_sub_sat(a, b);
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umax_s(unsigned a, unsigned b) {  // both < 2^31
+    return (unsigned)imax((int)a, (int)b);
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// One DP column of an R-row strip.  H[r] holds H(row r, previous column) on
+// entry and H(row r, this column) on exit; E[r] holds E(row r, this column)
+// on entry and E(row r, next column) on exit.  sc = the column's R int8 scores.
+template <int R>
+__device__ __forceinline__ void sw_column(int (&H)[R], unsigned (&E)[R], const v4i (&sc)[R / 16],
+                                          int diag, unsigned F, int& best, unsigned open, unsigned ext,
+                                          int& h_last, unsigned& f_last) {
+    int hprev = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int w = sc[r / 16][(r % 16) / 4];
+        const int s = (int)(signed char)(w >> (8 * (r % 4)));
+        const int h = imax(imax(diag + s, (int)E[r]), (int)F);
+        if (r & 1) best = imax(imax(best, hprev), h); else hprev = h;
+        const unsigned hm = usub_sat((unsigned)h, open);
+        E[r] = umax_s(usub_sat(E[r], ext), hm);
+        F = umax_s(usub_sat(F, ext), hm);
+        diag = H[r];
+        H[r] = h;
+    }
+    h_last = H[R - 1];
+    f_last = F;
+}
+
+template <int R>
+__device__ __forceinline__ void load_scores(v4i (&sc)[R / 16], const char* prof, unsigned res4, int cc) {
+    const unsigned taddr = (cc == 0 ? (res4 << 4) : (res4 >> (8 * cc - 4))) & 0x1F0u;
+#pragma unroll
+    for (int k = 0; k < R / 16; ++k) sc[k] = *reinterpret_cast<const v4i*>(prof + k * 512 + taddr);
+}
+
+// Persistent kernel: waves pull (group, query) items from a global counter.
+template <int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
+    static_assert(R % 16 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 32);
+
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const unsigned n_items = a.n_groups * a.q_count;
+    const unsigned open = a.open, ext = a.ext;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const unsigned g = item / a.q_count;
+        const unsigned qi = item - g * a.q_count;
+        const unsigned q = a.q_begin + qi;
+        const unsigned len4 = a.grp_len4[g];
+        const uint32_t* res = a.db_res + a.grp_off[g] + lane;
+        const uint8_t* qc = a.q_codes + a.q_off[q];
+        const unsigned lq = a.q_len[q];
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        int best = 0;
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            // ---- strip profile: prof[k][t][b] = M[q_{sR+16k+b}][t] ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 2 * R; e0 += 64) {
+                const int e = e0 + lane;
+                const int k = e >> 5, t = e & 31;
+                const v4i q16 = *reinterpret_cast<const v4i*>(qc + s * R + 16 * k);
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const unsigned code = ((unsigned)q16[d] >> (8 * b)) & 31u;
+                        w |= (unsigned)(unsigned char)lmat[code * 32 + t] << (8 * b);
+                    }
+                    out[d] = (int)w;
+                }
+                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            int H[R];
+            unsigned E[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
+            int hdiag = 0;  // H(strip top - 1, previous column)
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+
+            uint32_t res_n = res[0];
+            v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+            if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+            v4i sc_n[R / 16];
+            load_scores<R>(sc_n, prof, res_n, 0);
+            for (unsigned c = 0; c < len4; ++c) {
+                const uint32_t r4 = res_n;
+                const v4i hb = hb_n, fb = fb_n;
+                const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+                res_n = res[(uint64_t)cn * 64];
+                if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+                v4i ho, fo;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    v4i sc[R / 16];
+#pragma unroll
+                    for (int k = 0; k < R / 16; ++k) sc[k] = sc_n[k];
+                    // software pipeline: the next column's scores are in flight while this one computes
+                    if (cc < 3) load_scores<R>(sc_n, prof, r4, cc + 1); else load_scores<R>(sc_n, prof, res_n, 0);
+                    int hl; unsigned fl;
+                    sw_column<R>(H, E, sc, hdiag, (unsigned)fb[cc], best, open, ext, hl, fl);
+                    hdiag = hb[cc];
+                    ho[cc] = hl; fo[cc] = (int)fl;
+                    // pin the running maximum here: LLVM otherwise sinks the whole max3 chain to the
+                    // end of the 4-column body and keeps every H value of the body live (250 VGPRs)
+                    asm volatile("" : "+v"(best));
+                    __builtin_amdgcn_sched_barrier(0);  // one scheduling region per column
+                }
+                if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+            }
+        }
+        const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
+        if (p != 0xFFFFFFFFu) a.scores[(uint64_t)qi * a.score_stride + p] = best;
+    }
+}
+
+}  // namespace s4g

@@ -1,0 +1,153 @@
+"""Python face of the C ABI (include/s4g_hip.h): Scorer / Database / QuerySet handles and scan calls.
+
+Names follow the swsharp objects sift4g uses (Scorer, ChainDatabase, Chain query;
+/root/reference/sift4g/src/main.cpp:208, database_alignment.cpp:80-86).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, c_u8p, c_u32p, c_u64p, c_i32p
+from .seqio import flatten
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib.s4g_device_count(ctypes.byref(n)), "s4g_device_count")
+    return n.value
+
+
+def matrix_by_name(name):
+    m = np.zeros(26 * 26, dtype=np.int32)
+    check(lib.s4g_matrix_by_name(name.encode(), _ptr(m, c_i32p)), "s4g_matrix_by_name")
+    return m.reshape(26, 26)
+
+
+class Scorer:
+    """scorerCreateMatrix(&scorer, name, gap_open, gap_extend)  (main.cpp:208)"""
+
+    def __init__(self, matrix="BLOSUM_62", gap_open=10, gap_extend=1):
+        table = matrix_by_name(matrix) if isinstance(matrix, str) else np.ascontiguousarray(matrix, dtype=np.int32)
+        if table.shape != (26, 26):
+            raise ValueError("substitution table must be 26x26")
+        self.table = np.ascontiguousarray(table, dtype=np.int32)
+        self.gap_open, self.gap_extend = int(gap_open), int(gap_extend)
+        self._h = ctypes.c_void_p()
+        check(lib.s4g_scorer_create(ctypes.byref(self._h), _ptr(self.table, c_i32p), self.gap_open, self.gap_extend),
+              "s4g_scorer_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.s4g_scorer_destroy(self._h)
+            self._h = None
+
+
+class _SeqSet:
+    _create = None
+    _destroy = None
+
+    def __init__(self, seqs=None, device=0, codes=None, offsets=None):
+        if codes is None:
+            codes, offsets = flatten(seqs)
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = len(self.offsets) - 1
+        self.device = device
+        self.lengths = np.diff(self.offsets.astype(np.int64))
+        self._h = ctypes.c_void_p()
+        check(type(self)._create(ctypes.byref(self._h), device, _ptr(self.codes, c_u8p), _ptr(self.offsets, c_u64p), self.n),
+              type(self)._create.__name__)
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            type(self)._destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Database(_SeqSet):
+    """chainDatabaseCreate(database, 0, n, cards, cardsLen)  (database_alignment.cpp:80): resident in HBM."""
+    _create = lib.s4g_db_create
+    _destroy = lib.s4g_db_destroy
+
+    def info(self):
+        n = ctypes.c_uint32(); r = ctypes.c_uint64(); p = ctypes.c_uint64(); b = ctypes.c_uint64()
+        check(lib.s4g_db_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(p), ctypes.byref(b)), "s4g_db_info")
+        return dict(n_seqs=n.value, residues=r.value, padded_residues=p.value, hbm_bytes=b.value)
+
+
+class QuerySet(_SeqSet):
+    _create = lib.s4g_queries_create
+    _destroy = lib.s4g_queries_destroy
+
+
+def scan_cells(db, queries, q_begin=0, q_count=None):
+    q_count = queries.n - q_begin if q_count is None else q_count
+    c = ctypes.c_uint64()
+    check(lib.s4g_scan_cells(db._h, queries._h, q_begin, q_count, ctypes.byref(c)), "s4g_scan_cells")
+    return c.value
+
+
+def scan_plan(db, queries, scorer):
+    name = ctypes.create_string_buffer(128)
+    g = ctypes.c_uint32(); b = ctypes.c_uint32(); s = ctypes.c_uint32(); w = ctypes.c_uint64()
+    check(lib.s4g_scan_plan(db._h, queries._h, scorer._h, name, 128, ctypes.byref(g), ctypes.byref(b), ctypes.byref(s),
+                            ctypes.byref(w)), "s4g_scan_plan")
+    return dict(kernel=name.value.decode(), grid_blocks=g.value, block_threads=b.value, strip_rows=s.value,
+                workspace_bytes=w.value)
+
+
+def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None):
+    """Asynchronous scan into a device tensor `out` (torch int32 [q_count, n_seqs], on db.device).
+
+    stream: a torch.cuda.Stream (default: torch's current stream on that device)."""
+    import torch
+    q_count = queries.n - q_begin if q_count is None else q_count
+    if out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < q_count * db.n or not out.is_cuda:
+        raise ValueError("out must be a contiguous CUDA int32 tensor of at least q_count*n_seqs elements")
+    if stream is None:
+        stream = torch.cuda.current_stream(out.device)
+    check(lib.s4g_scan(db._h, queries._h, q_begin, q_count, scorer._h, ctypes.c_void_p(out.data_ptr()),
+                       ctypes.c_void_p(stream.cuda_stream)), "s4g_scan")
+    return out
+
+
+def scan_host(db, queries, scorer, q_begin=0, q_count=None):
+    """Synchronous scan -> numpy int32 [q_count, n_seqs]."""
+    q_count = queries.n - q_begin if q_count is None else q_count
+    out = np.zeros((q_count, db.n), dtype=np.int32)
+    check(lib.s4g_scan_host(db._h, queries._h, q_begin, q_count, scorer._h, _ptr(out, c_i32p)), "s4g_scan_host")
+    return out
+
+
+def score_lists(db, queries, scorer, cand_offsets, cand_ids):
+    cand_offsets = np.ascontiguousarray(cand_offsets, dtype=np.uint64)
+    cand_ids = np.ascontiguousarray(cand_ids, dtype=np.uint32)
+    out = np.zeros(max(int(cand_offsets[-1]), 1), dtype=np.int32)
+    check(lib.s4g_score_lists_host(db._h, queries._h, _ptr(cand_offsets, c_u64p), _ptr(cand_ids, c_u32p), scorer._h,
+                                   _ptr(out, c_i32p)), "s4g_score_lists_host")
+    return out[: int(cand_offsets[-1])]
+
+
+def topk(db, scores, k, min_score=1, stream=None):
+    """Per-query top-k of a device score tensor [q, n_seqs] -> (ids uint32 [q,k], scores int32 [q,k], counts uint32 [q])."""
+    import torch
+    q = scores.shape[0]
+    ids = np.zeros((q, k), dtype=np.uint32)
+    sc = np.zeros((q, k), dtype=np.int32)
+    cnt = np.zeros(q, dtype=np.uint32)
+    if stream is None:
+        stream = torch.cuda.current_stream(scores.device)
+    check(lib.s4g_topk_host(db._h, ctypes.c_void_p(scores.data_ptr()), q, k, int(min_score), _ptr(ids, c_u32p),
+                            _ptr(sc, c_i32p), _ptr(cnt, c_u32p), ctypes.c_void_p(stream.cuda_stream)), "s4g_topk_host")
+    return ids, sc, cnt

@@ -1,0 +1,57 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.lib()  # builds oracle/libsw_oracle.so on first use
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def blosum62(oracle_mod):
+    return oracle_mod.blosum62()
+
+
+@pytest.fixture(scope="session")
+def micro():
+    with open(os.path.join(GOLDEN, "micro.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def cfg1():
+    """BASELINE.json configs[0]: the reference's own test_files (inputs) + oracle-generated scores."""
+    from sift4g_amd.seqio import read_fasta
+    with open(os.path.join(GOLDEN, "cfg1_scores.json")) as fh:
+        gold = json.load(fh)
+    queries = read_fasta(os.path.join(GOLDEN, "test_files", "query.fasta"))
+    targets = read_fasta(os.path.join(GOLDEN, "test_files", "sample_protein_database.fa"))
+    return dict(queries=queries, targets=targets, scores=np.array(gold["scores"], dtype=np.int32), gold=gold)
+
+
+def rand_seqs(rng, n, lo, hi, alphabet=20):
+    """n random code arrays with lengths in [lo, hi]; alphabet=20 -> standard residues, 26 -> every letter code."""
+    std = np.array([0, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18, 19, 21, 22, 24], dtype=np.uint8)
+    out = []
+    for _ in range(n):
+        l = int(rng.integers(lo, hi + 1))
+        if alphabet == 26:
+            out.append(rng.integers(0, 26, size=l).astype(np.uint8))
+        else:
+            out.append(std[rng.integers(0, 20, size=l)])
+    return out

@@ -1,0 +1,81 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header declares,
+and fails loudly (no fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "s4g_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(s4g_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sift4g_amd import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 17
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/s4g_hip.h but not exported by libs4g_hip.so"
+    assert sorted(_lib.SIGNATURES) == declared, "sift4g_amd/_lib.py SIGNATURES out of sync with include/s4g_hip.h"
+    assert _lib.lib.s4g_abi_version() == 1
+
+
+def test_header_cites_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "s4g_hip.h")).read()
+    for cite in ("database_alignment.cpp:83-86", "database_alignment.cpp:80", "main.cpp:208", "main.cpp:183-186"):
+        assert cite in text
+
+
+def test_builtin_matrix_equals_oracle_table(blosum62):
+    from sift4g_amd.device import matrix_by_name
+    assert np.array_equal(matrix_by_name("BLOSUM_62"), blosum62)
+    from sift4g_amd._lib import S4GError
+    with pytest.raises(S4GError):
+        matrix_by_name("BLOSUM_13")
+
+
+def test_scorer_validation():
+    from sift4g_amd import Scorer
+    from sift4g_amd._lib import S4GError
+    Scorer("BLOSUM_62", 10, 1)
+    with pytest.raises(S4GError):
+        Scorer("BLOSUM_62", 1, 2)        # extend > open (main.cpp:297-303)
+    bad = np.zeros((26, 26), dtype=np.int32); bad[0, 0] = 1000
+    with pytest.raises(S4GError):
+        Scorer(bad, 10, 1)
+
+
+def test_device_check_accepts_zero_cards():
+    # cudaCheckCards must pass for 0 cards (main.cpp:78-79,186)
+    from sift4g_amd._lib import lib
+    assert lib.s4g_device_check(None, 0) == 1
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_fails_loudly():
+    import sift4g_amd as s
+    from sift4g_amd._lib import S4GError, S4G_ERR_NO_DEVICE
+    with pytest.raises(S4GError) as e:
+        s.Database([np.zeros(4, dtype=np.uint8)])
+    assert e.value.code == S4G_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    with pytest.raises(S4GError):
+        s.QuerySet([np.zeros(4, dtype=np.uint8)])
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under sift4g_amd/ (or the C++ sources) may reference it."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "sift4g_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".c")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\bimport oracle\b|\bfrom oracle\b|sw_oracle|libsw_oracle|s4g_oracle_", txt):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

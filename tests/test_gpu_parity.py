@@ -1,0 +1,208 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact int32 scores."""
+import numpy as np
+import pytest
+
+from conftest import rand_seqs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s4g():
+    import sift4g_amd
+    assert sift4g_amd.device_count() >= 1
+    return sift4g_amd
+
+
+@pytest.fixture(scope="module")
+def scorer(s4g):
+    return s4g.Scorer("BLOSUM_62", 10, 1)
+
+
+def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8):
+    db = s4g.Database(targets)
+    qs = s4g.QuerySet(queries)
+    got = s4g.scan_host(db, qs, scorer)
+    exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, f"{len(bad)} mismatches, first {bad[:5].tolist()} got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}"
+    return got
+
+
+def test_micro_known_answers(s4g, oracle_mod, micro, scorer):
+    qs = [oracle_mod.encode(c["q"]) for c in micro["cases"]]
+    ts = [oracle_mod.encode(c["t"]) for c in micro["cases"]]
+    got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), scorer)
+    for i, c in enumerate(micro["cases"]):
+        assert got[i, i] == c["score"], (c["name"], int(got[i, i]), c["score"])
+
+
+def test_cfg1_reference_fixture(s4g, cfg1, scorer):
+    """BASELINE.json configs[0]: test_files/query.fasta x sample_protein_database.fa vs the golden 2 x 9 matrix."""
+    got = s4g.scan_host(s4g.Database([c for _, c in cfg1["targets"]]), s4g.QuerySet([c for _, c in cfg1["queries"]]), scorer)
+    assert np.array_equal(got, cfg1["scores"])
+
+
+def test_random_standard_alphabet(s4g, oracle_mod, blosum62, scorer):
+    rng = np.random.default_rng(11)
+    _check(s4g, oracle_mod, blosum62, rand_seqs(rng, 24, 1, 450), rand_seqs(rng, 700, 1, 600), scorer)
+
+
+def test_all_26_codes_and_ragged_groups(s4g, oracle_mod, blosum62, scorer):
+    """every letter code (B, J, O, U, X, Z included); target count not a multiple of 64."""
+    rng = np.random.default_rng(12)
+    _check(s4g, oracle_mod, blosum62, rand_seqs(rng, 9, 1, 200, 26), rand_seqs(rng, 131, 1, 300, 26), scorer)
+
+
+def test_strip_and_chunk_boundaries(s4g, oracle_mod, blosum62, scorer):
+    """query lengths around the strip height (32) and target lengths around the 4-column chunk."""
+    rng = np.random.default_rng(13)
+    qlens = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 95, 96, 97, 128, 129]
+    tlens = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 127, 128, 129, 255, 256, 257]
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
+    ts = [rand_seqs(rng, 1, l, l)[0] for l in tlens]
+    _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+
+
+def test_empty_and_degenerate_inputs(s4g, oracle_mod, blosum62, scorer):
+    rng = np.random.default_rng(14)
+    e = np.zeros(0, dtype=np.uint8)
+    qs = [e, rand_seqs(rng, 1, 40, 40)[0], e, rand_seqs(rng, 1, 1, 1)[0]]
+    ts = [rand_seqs(rng, 1, 50, 50)[0], e, e, rand_seqs(rng, 1, 1, 1)[0], rand_seqs(rng, 1, 70, 70)[0]]
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert (got[0] == 0).all() and (got[:, 1] == 0).all()
+    # zero queries / zero targets: calls succeed and return empty results
+    assert s4g.scan_host(s4g.Database(ts), s4g.QuerySet([]), scorer).shape == (0, 5)
+    assert s4g.scan_host(s4g.Database([]), s4g.QuerySet(qs), scorer).shape == (4, 0)
+
+
+def test_homologs_identical_and_gapped(s4g, oracle_mod, blosum62, scorer):
+    """high-scoring pairs: identical copies, planted indels of 1..40 residues, long runs of W (max score/column)."""
+    rng = np.random.default_rng(15)
+    qs = rand_seqs(rng, 6, 200, 420)
+    ts = []
+    for q in qs:
+        ts.append(q.copy())
+        for gap in (1, 2, 3, 10, 40):
+            cut = int(rng.integers(20, len(q) - 20))
+            ts.append(np.concatenate([q[:cut], rand_seqs(rng, 1, gap, gap)[0], q[cut:]]))   # insertion in target
+            ts.append(np.concatenate([q[:cut], q[cut + gap:]]))                             # deletion in target
+    w = np.full(500, ord("W") - 65, dtype=np.uint8)
+    qs.append(w[:400]); ts.append(w)
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert got[-1, -1] == 400 * 11
+
+
+def test_long_sequences(s4g, oracle_mod, blosum62, scorer):
+    """BASELINE config 5 shape at oracle-friendly size: queries 2000-5000, targets up to 3000 (+ one 12k)."""
+    rng = np.random.default_rng(16)
+    qs = rand_seqs(rng, 3, 2000, 5000)
+    ts = rand_seqs(rng, 70, 30, 3000) + [rand_seqs(rng, 1, 12000, 12000)[0], np.concatenate([qs[0][100:1900], qs[1][:50]])]
+    _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+
+
+def test_more_items_than_resident_waves(s4g, oracle_mod, blosum62, scorer):
+    """enough (group, query) items that the persistent grid loops, with very unequal work."""
+    rng = np.random.default_rng(17)
+    qs = rand_seqs(rng, 40, 5, 120)
+    ts = rand_seqs(rng, 64 * 40 + 5, 1, 90)
+    _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+
+
+@pytest.mark.parametrize("go,ge", [(11, 1), (10, 2), (5, 5), (12, 0), (1, 1)])
+def test_other_gap_penalties(s4g, oracle_mod, blosum62, go, ge):
+    rng = np.random.default_rng(18 + go)
+    sc = s4g.Scorer("BLOSUM_62", go, ge)
+    qs = rand_seqs(rng, 6, 30, 200)
+    ts = rand_seqs(rng, 100, 10, 250) + [np.concatenate([qs[0][:60], qs[0][70:]])]
+    _check(s4g, oracle_mod, blosum62, qs, ts, sc, go, ge)
+
+
+def test_custom_matrix(s4g, oracle_mod):
+    """scorer tables other than BLOSUM62: random symmetric table with large entries."""
+    rng = np.random.default_rng(19)
+    M = rng.integers(-20, 21, size=(26, 26)).astype(np.int32)
+    M = np.triu(M) + np.triu(M, 1).T
+    sc = s4g.Scorer(M, 7, 2)
+    _check(s4g, oracle_mod, M, rand_seqs(rng, 5, 20, 150, 26), rand_seqs(rng, 90, 5, 200, 26), sc, 7, 2)
+
+
+def test_query_ranges_and_device_tensor(s4g, oracle_mod, blosum62, scorer):
+    """s4g_scan into a torch device buffer on torch's current stream, by query sub-range."""
+    import torch
+    rng = np.random.default_rng(20)
+    qs, ts = rand_seqs(rng, 10, 20, 150), rand_seqs(rng, 200, 5, 180)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    out = torch.full((4, len(ts)), -7, dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, out, q_begin=3, q_count=4)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), exp[3:7])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out2 = torch.empty((10, len(ts)), dtype=torch.int32, device="cuda:0")
+        s4g.scan(db, q, scorer, out2)
+    side.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), exp)
+
+
+def test_candidate_lists(s4g, oracle_mod, blosum62, scorer):
+    """the per-query candidate lists sift4g's wrapper builds (database_alignment.cpp:136-162)."""
+    rng = np.random.default_rng(21)
+    qs, ts = rand_seqs(rng, 7, 20, 150), rand_seqs(rng, 300, 5, 180)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    lists = [np.sort(rng.choice(300, size=int(rng.integers(0, 60)), replace=False)).astype(np.uint32) for _ in qs]
+    off = np.zeros(len(qs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists) if off[-1] else np.zeros(0, np.uint32)
+    got = s4g.score_lists(s4g.Database(ts), s4g.QuerySet(qs), scorer, off, ids)
+    want = np.concatenate([exp[i, l] for i, l in enumerate(lists)])
+    assert np.array_equal(got, want)
+
+
+def test_topk_matches_sorted_oracle(s4g, oracle_mod, blosum62, scorer):
+    import torch
+    rng = np.random.default_rng(22)
+    qs, ts = rand_seqs(rng, 6, 50, 120), rand_seqs(rng, 1500, 20, 150)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    out = torch.empty((len(qs), len(ts)), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, out)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    for k, min_score in ((10, 1), (400, 30), (2000, 1)):
+        ids, sc, cnt = s4g.topk(db, out, k, min_score)
+        for i in range(len(qs)):
+            order = sorted((j for j in range(len(ts)) if exp[i, j] >= min_score), key=lambda j: (-exp[i, j], j))[:k]
+            assert cnt[i] == len(order)
+            assert ids[i, :cnt[i]].tolist() == order
+            assert sc[i, :cnt[i]].tolist() == [int(exp[i, j]) for j in order]
+
+
+def test_full_size_properties(s4g, oracle_mod, blosum62, scorer):
+    """BASELINE configs[1] shape (subsampled queries x the full 100k DB): size-independent properties
+    plus an oracle spot-check."""
+    import torch
+    from sift4g_amd import synth
+    cfg = synth.make_config(2, n_queries=1000, n_targets=100000)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    nq = 24
+    out = torch.empty((nq, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, out, q_begin=0, q_count=nq)
+    got = out.cpu().numpy()
+    assert (got >= 0).all()
+    # local score bounds: <= 11 * min(Lq, Lt)
+    ql = q.lengths[:nq, None]; tl = db.lengths[None, :]
+    assert (got <= 11 * np.minimum(ql, tl)).all()
+    # planted homologs stand out from the background
+    planted = [(a, b) for a, b in cfg["planted"] if a < nq]
+    bg = np.percentile(got, 99.9)
+    assert np.mean([got[a, b] > bg for a, b in planted]) > 0.95
+    # idempotence: a second scan gives identical bytes
+    out2 = torch.empty_like(out)
+    s4g.scan(db, q, scorer, out2, q_begin=0, q_count=nq)
+    assert torch.equal(out, out2)
+    # oracle spot-check on a random sample of pairs + every planted pair of the first queries
+    rng = np.random.default_rng(23)
+    pq = np.concatenate([rng.integers(0, nq, 3000), [a for a, _ in planted[:200]]]).astype(np.uint32)
+    pt = np.concatenate([rng.integers(0, db.n, 3000), [b for _, b in planted[:200]]]).astype(np.uint32)
+    exp = oracle_mod.pairs_flat(cfg["q_codes"], cfg["q_off"], cfg["t_codes"], cfg["t_off"], pq, pt, blosum62, 10, 1, threads=8)
+    assert np.array_equal(got[pq, pt], exp)

@@ -1,0 +1,137 @@
+"""CPU tests that pin the oracle (oracle/sw_oracle.c).
+
+The reference holds no golden vectors for this path: the oracle is "parity unpinned"
+against swsharp and is pinned instead by hand-computed known answers, the published
+Karlin-Altschul statistics of BLOSUM62, and identities on the reference's own input fixtures.
+"""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from conftest import rand_seqs
+
+
+def test_micro_known_answers(oracle_mod, blosum62, micro):
+    for c in micro["cases"]:
+        got = oracle_mod.sw_score(oracle_mod.encode(c["q"]), oracle_mod.encode(c["t"]), blosum62,
+                                  micro["gap_open"], micro["gap_extend"])
+        assert got == c["score"], (c["name"], got, c["score"])
+
+
+def test_blosum62_shape_and_symmetry(blosum62):
+    assert blosum62.shape == (26, 26)
+    assert (blosum62 == blosum62.T).all()
+    idx = {c: ord(c) - 65 for c in "ABCDEFGHIJKLMNOPQRSTUVWXYZ"}
+    assert blosum62[idx["W"], idx["W"]] == 11 and blosum62[idx["C"], idx["C"]] == 9
+    assert blosum62[idx["A"], idx["R"]] == -1 and blosum62[idx["L"], idx["S"]] == -2
+    # J, O, U have no NCBI row: documented assumption = X row
+    for c in "JOU":
+        assert (blosum62[idx[c]] == blosum62[idx["X"]]).all()
+
+
+def test_blosum62_published_statistics(blosum62):
+    """Ungapped Karlin-Altschul lambda and relative entropy of BLOSUM62 under the Robinson & Robinson
+    background: published values lambda = 0.3176, H = 0.4012 (NCBI BLAST)."""
+    from scipy.optimize import brentq
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    p = np.array([0.07805, 0.05129, 0.04487, 0.05364, 0.01925, 0.04264, 0.06295, 0.07377, 0.02199, 0.05142,
+                  0.09019, 0.05744, 0.02243, 0.03856, 0.05203, 0.07120, 0.05841, 0.01330, 0.03216, 0.06441])
+    p = p / p.sum()
+    ix = [ord(c) - 65 for c in aa]
+    S = blosum62[np.ix_(ix, ix)].astype(float)
+    pp = np.outer(p, p)
+    lam = brentq(lambda l: (pp * np.exp(l * S)).sum() - 1.0, 0.05, 1.0)
+    H = lam * (pp * np.exp(lam * S) * S).sum()
+    assert abs(lam - 0.3176) < 5e-4
+    assert abs(H - 0.4012) < 1e-3
+
+
+def test_cfg1_fixture_identities(oracle_mod, blosum62, cfg1):
+    """DB entry QUERY == query LACI_ECOLI; DB LACI_ECOLI differs at 286 (L->S);
+    DB PURR_SALTY == query PURR_SALTY."""
+    q = {n.split()[0]: c for n, c in cfg1["queries"]}
+    t = {n.split()[0]: c for n, c in cfg1["targets"]}
+    M = blosum62
+    self_laci = int(sum(M[a, a] for a in q["LACI_ECOLI"]))
+    self_purr = int(sum(M[a, a] for a in q["PURR_SALTY"]))
+    assert np.array_equal(t["QUERY"], q["LACI_ECOLI"])
+    assert np.array_equal(t["PURR_SALTY"], q["PURR_SALTY"])
+    diff = np.nonzero(t["LACI_ECOLI"] != q["LACI_ECOLI"])[0]
+    assert diff.tolist() == [285]
+    L, S = ord("L") - 65, ord("S") - 65
+    assert q["LACI_ECOLI"][285] == L and t["LACI_ECOLI"][285] == S
+    assert oracle_mod.sw_score(q["LACI_ECOLI"], t["QUERY"], M) == self_laci
+    assert oracle_mod.sw_score(q["PURR_SALTY"], t["PURR_SALTY"], M) == self_purr
+    assert oracle_mod.sw_score(q["LACI_ECOLI"], t["LACI_ECOLI"], M) == self_laci - M[L, L] + M[L, S]
+
+
+def test_cfg1_golden_scores(oracle_mod, blosum62, cfg1):
+    got = oracle_mod.scan([c for _, c in cfg1["queries"]], [c for _, c in cfg1["targets"]], blosum62, 10, 1, threads=2)
+    assert np.array_equal(got, cfg1["scores"])
+    assert cfg1["gold"]["query_lengths"] == [360, 341]
+    assert sum(cfg1["gold"]["target_lengths"]) == 3091
+
+
+def _rescore(path, q, t, qs, ts, M, go, ge):
+    """Score an alignment path independently of the DP."""
+    i, j, s, prev = qs, ts, 0, 0
+    for mv in path:
+        if mv == 0:
+            s += int(M[q[i], t[j]]); i += 1; j += 1
+        elif mv == 1:
+            s -= ge if prev == 1 else go; j += 1
+        else:
+            s -= ge if prev == 2 else go; i += 1
+        prev = mv
+    return s, i - 1, j - 1
+
+
+def test_traceback_rescoring(oracle_mod, blosum62):
+    rng = np.random.default_rng(7)
+    for _ in range(60):
+        q = rand_seqs(rng, 1, 1, 80)[0]
+        t = q.copy() if rng.random() < 0.3 else rand_seqs(rng, 1, 1, 90)[0]
+        if rng.random() < 0.5 and len(q) > 10:   # plant an indel so gaps are exercised
+            cut = int(rng.integers(3, len(q) - 3))
+            t = np.concatenate([q[:cut], rand_seqs(rng, 1, 1, 4)[0], q[cut:]])
+        a = oracle_mod.sw_align(q, t, blosum62, 10, 1)
+        assert a["score"] == oracle_mod.sw_score(q, t, blosum62, 10, 1)
+        if a["score"] == 0:
+            assert len(a["path"]) == 0
+            continue
+        s, qe, te = _rescore(a["path"], q, t, a["q_start"], a["t_start"], blosum62, 10, 1)
+        assert (s, qe, te) == (a["score"], a["q_end"], a["t_end"])
+        assert a["path"][0] == 0 and a["path"][-1] == 0     # local alignments start and end on a match column
+
+
+codes = st.lists(st.integers(0, 25), min_size=0, max_size=40).map(lambda l: np.array(l, dtype=np.uint8))
+
+
+@settings(max_examples=150, deadline=None)
+@given(q=codes, t=codes, go=st.integers(1, 14), ge=st.integers(0, 3))
+def test_properties(oracle_mod, blosum62, q, t, go, ge):
+    ge = min(ge, go)
+    s = oracle_mod.sw_score(q, t, blosum62, go, ge)
+    assert s >= 0
+    assert s == oracle_mod.sw_score(t, q, blosum62, go, ge)          # symmetric matrix -> symmetric score
+    assert s == oracle_mod.sw_score(q[::-1], t[::-1], blosum62, go, ge)  # reversal invariance
+    if len(q):
+        assert oracle_mod.sw_score(q, q, blosum62, go, ge) >= max(0, int(sum(blosum62[a, a] for a in q)))
+    # a cheaper gap model can only raise the score
+    assert oracle_mod.sw_score(q, t, blosum62, max(go - 1, ge), ge) >= s
+    # appending residues never lowers a local score
+    assert oracle_mod.sw_score(np.concatenate([q, t[:3]]), t, blosum62, go, ge) >= s
+
+
+def test_pairs_and_scan_agree(oracle_mod, blosum62):
+    rng = np.random.default_rng(3)
+    qs, ts = rand_seqs(rng, 5, 0, 70, 26), rand_seqs(rng, 9, 0, 90, 26)
+    full = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=3)
+    for i, q in enumerate(qs):
+        for j, t in enumerate(ts):
+            assert full[i, j] == oracle_mod.sw_score(q, t, blosum62, 10, 1)
+    from oracle import _flat
+    qc, qo = _flat(qs); tc, to = _flat(ts)
+    pq = np.array([4, 0, 2], dtype=np.uint32); pt = np.array([8, 3, 3], dtype=np.uint32)
+    got = oracle_mod.pairs_flat(qc, qo, tc, to, pq, pt, blosum62, 10, 1, threads=2)
+    assert got.tolist() == [full[4, 8], full[0, 3], full[2, 3]]
