@@ -27,26 +27,28 @@ BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E colu
 TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
 
 
-def cpu_baseline(cfg, n_threads, target_seconds=15.0):
+def cpu_baseline(cfg, n_threads, target_seconds=12.0):
     """The scalar oracle (kind "port": a restatement, NOT swsharp's SSE code) timed on this host's cores on a
     bounded sample of the same workload."""
     import oracle
     M = oracle.blosum62()
     q_off, t_off = cfg["q_off"], cfg["t_off"]
 
-    def run(nq, nt):
-        t0 = time.perf_counter()
-        oracle.scan_flat(cfg["q_codes"], q_off[:nq + 1].copy(), cfg["t_codes"], t_off[:nt + 1].copy(), M, 10, 1, n_threads)
-        dt = time.perf_counter() - t0
-        cells = float(q_off[nq]) * float(t_off[nt])
-        return cells, dt
-
-    cells, dt = run(min(8, len(q_off) - 1), min(512, len(t_off) - 1))      # pilot
-    rate = cells / max(dt, 1e-6)
     nq = min(16, len(q_off) - 1)
-    per_target = float(q_off[nq]) * (float(t_off[-1]) / (len(t_off) - 1))
-    nt = int(min(len(t_off) - 1, max(512, rate * target_seconds / per_target)))
-    cells, dt = run(nq, nt)
+    qo = q_off[:nq + 1].copy()
+    n_t = len(t_off) - 1
+    chunk = max(64, min(n_t, 16 * n_threads))
+    cells, dt, nt = 0.0, 0.0, 0
+    while nt < n_t and dt < target_seconds:           # time-boxed: whole chunks of targets until ~target_seconds
+        hi = min(n_t, nt + chunk)
+        to = (t_off[nt:hi + 1] - t_off[nt]).copy()
+        tc = cfg["t_codes"][int(t_off[nt]):int(t_off[hi])]
+        t0 = time.perf_counter()
+        oracle.scan_flat(cfg["q_codes"], qo, np.ascontiguousarray(tc), to, M, 10, 1, n_threads)
+        dt += time.perf_counter() - t0
+        cells += float(qo[nq]) * float(to[-1])
+        nt = hi
+        chunk = min(chunk * 2, 65536)
     return dict(value=round(cells / dt / 1e9, 3), unit="GCUPS", cores=n_threads, kind="port",
                 sample=f"first {nq} queries x first {nt} targets of the same workload, {cells:.3e} cells in {dt:.1f} s, "
                        f"scalar C oracle (oracle/sw_oracle.c), {n_threads} pthreads")

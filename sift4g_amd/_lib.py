@@ -49,6 +49,15 @@ SIGNATURES = {
                                      c_u32p, c_u32p, c_u32p, c_u64p]),
 }
 
+# torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  If our
+# library pulled in /opt/rocm's copy first, a later `import torch` in the same process ends up with two HSA
+# runtimes and reports "No HIP GPUs are available".  Loading torch first makes both use one runtime.  torch is
+# plumbing here (device buffers, streams, torch.distributed); C++ hosts link /opt/rocm directly and never see it.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pure-ctypes use without torch is fine
+    pass
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the HIP library first (`make` or `python -c 'import __graft_entry__ as g; g.build()'`). "
