@@ -11,11 +11,25 @@ CSRC    := sift4g_amd/csrc
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -Wall -Wno-unused-function
 CXXFLAGS := -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Iinclude
 
-all: $(LIBDIR)/libs4g_hip.so oracle
+SWSRC   := $(CSRC)/swsharp/core.cpp $(CSRC)/swsharp/evalue.cpp $(CSRC)/swsharp/align.cpp $(CSRC)/swsharp/output.cpp
+REF     ?= /root/reference
+
+all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so oracle
 
 $(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h $(CSRC)/matrices.h include/s4g_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/s4g_hip.hip
+
+$(LIBDIR)/libswsharp.so: $(SWSRC) $(CSRC)/swsharp/impl.hpp $(CSRC)/matrices.h include/swsharp/swsharp.h include/swsharp/evalue.h $(LIBDIR)/libs4g_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(SWSRC) -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN'
+
+# Drop-in link test: the reference's own, unmodified sift4g sources compiled where they lie, against OUR
+# swsharp-compatible headers and libraries.  Not an oracle (it runs our scorer); needs a GPU to run.
+dropin: $(LIBDIR)/libswsharp.so
+	@test -d $(REF)/sift4g/src || { echo "no reference tree at $(REF): skipping drop-in build"; exit 0; }
+	@mkdir -p build/dropin
+	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -o build/dropin/sift4g $(REF)/sift4g/src/*.cpp \
+	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
 oracle:
 	$(MAKE) -s -C oracle
@@ -28,4 +42,4 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean
+.PHONY: all oracle isa clean dropin

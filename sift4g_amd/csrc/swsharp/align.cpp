@@ -1,0 +1,368 @@
+// align.cpp -- ChainDatabase, alignDatabase / shotgunDatabase, host traceback, DbAlignment / Alignment objects.
+//
+// alignDatabase as sift4g calls it (/root/reference/sift4g/src/database_alignment.cpp:83-86):
+//   1. score the query against every target       -> libs4g_hip (HIP, MI355X); NO host scoring path
+//   2. valueFunction(values, scores, ...)          -> caller's callback (e-values, :129-134)
+//   3. keep value <= threshold, sort, top maxAlignments
+//   4. traceback of the survivors                  -> host C++ below (<= 400 pairs per query)
+// ASSUMPTIONS (unpinned, swsharp source absent): order = value ascending, then score descending, then target index
+// ascending; traceback ties = first maximum in row-major order as end cell, then DIAG before UP before LEFT.
+#include "impl.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------------ traceback
+namespace swimpl {
+
+namespace {
+constexpr int kNegInf = -(1 << 29);
+inline int imax(int a, int b) { return a > b ? a : b; }
+enum : unsigned char { H_STOP = 0, H_DIAG = 1, H_UP = 2, H_LEFT = 3, E_OPENS = 4, F_OPENS = 8 };
+}  // namespace
+
+void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc, PairResult* out) {
+    out->score = 0; out->q_start = out->q_end = out->t_start = out->t_end = -1; out->path.clear();
+    if (lq <= 0 || lt <= 0) return;
+    const int open = sc->gap_open, ext = sc->gap_extend;
+    const int32_t* M = sc->table;
+    // pass 1: score and end cell (first maximum in row-major order), O(lt) memory
+    std::vector<int> Hrow(lt + 1, 0), Frow(lt + 1, kNegInf);
+    int best = 0, bi = 0, bj = 0;
+    for (int i = 1; i <= lq; ++i) {
+        const int32_t* Mq = M + 26 * q[i - 1];
+        int diag = 0, hleft = 0, e = kNegInf;
+        for (int j = 1; j <= lt; ++j) {
+            e = imax(e - ext, hleft - open);
+            const int f = imax(Frow[j] - ext, Hrow[j] - open);
+            int h = imax(imax(diag + Mq[(int)t[j - 1]], 0), imax(e, f));
+            diag = Hrow[j]; Hrow[j] = h; Frow[j] = f; hleft = h;
+            if (h > best) { best = h; bi = i; bj = j; }
+        }
+    }
+    out->score = best;
+    if (best == 0) return;
+    // pass 2: direction bytes on the prefix box [1..bi] x [1..bj] (cell values there equal the full DP's)
+    const size_t W = (size_t)bj + 1;
+    std::vector<unsigned char> dir(((size_t)bi + 1) * W, 0);
+    std::fill(Hrow.begin(), Hrow.end(), 0);
+    std::fill(Frow.begin(), Frow.end(), kNegInf);
+    for (int i = 1; i <= bi; ++i) {
+        const int32_t* Mq = M + 26 * q[i - 1];
+        int diag = 0, hleft = 0, e = kNegInf;
+        unsigned char* drow = dir.data() + (size_t)i * W;
+        for (int j = 1; j <= bj; ++j) {
+            const int e_open = hleft - open, f_open = Hrow[j] - open;
+            e = imax(e - ext, e_open);
+            const int f = imax(Frow[j] - ext, f_open);
+            const int d = diag + Mq[(int)t[j - 1]];
+            const int h = imax(imax(d, 0), imax(e, f));
+            unsigned char b = h == 0 ? H_STOP : (h == d ? H_DIAG : (h == f ? H_UP : H_LEFT));
+            if (e == e_open) b |= E_OPENS;
+            if (f == f_open) b |= F_OPENS;
+            drow[j] = b;
+            diag = Hrow[j]; Hrow[j] = h; Frow[j] = f; hleft = h;
+        }
+    }
+    int i = bi, j = bj, state = 0;   // 0 = H, 1 = E (LEFT run), 2 = F (UP run)
+    std::vector<char>& p = out->path;
+    while (i > 0 && j > 0) {
+        const unsigned char b = dir[(size_t)i * W + j];
+        if (state == 0) {
+            const int s = b & 3;
+            if (s == H_STOP) break;
+            if (s == H_DIAG) { p.push_back(MOVE_DIAG); --i; --j; }
+            else state = (s == H_UP) ? 2 : 1;
+        } else if (state == 1) {
+            p.push_back(MOVE_LEFT);
+            if (b & E_OPENS) state = 0;
+            --j;
+        } else {
+            p.push_back(MOVE_UP);
+            if (b & F_OPENS) state = 0;
+            --i;
+        }
+    }
+    std::reverse(p.begin(), p.end());
+    out->q_start = i; out->t_start = j; out->q_end = bi - 1; out->t_end = bj - 1;
+}
+
+}  // namespace swimpl
+
+// ------------------------------------------------------------------------------------------------ ChainDatabase
+static int pick_device(int* cards, int cardsLen) { return (cards && cardsLen > 0) ? cards[0] : 0; }
+
+static void flatten(Chain** chains, int n, std::vector<uint8_t>& codes, std::vector<uint64_t>& off) {
+    off.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        SW_ASSERT(chains[i] != NULL, "NULL chain at index %d", i);
+        off[i + 1] = off[i] + (uint64_t)chainGetLength(chains[i]);
+    }
+    codes.resize(off[n] ? off[n] : 1);
+    for (int i = 0; i < n; ++i) memcpy(codes.data() + off[i], chainGetCodes(chains[i]), (size_t)chainGetLength(chains[i]));
+}
+
+SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, int databaseLen, int* cards, int cardsLen) {
+    SW_ASSERT(database != NULL && databaseStart >= 0 && databaseLen >= 0, "chainDatabaseCreate: invalid arguments");
+    ChainDatabase* db = new ChainDatabase();
+    db->chains = database + databaseStart;
+    db->length = databaseLen;
+    db->device = pick_device(cards, cardsLen);
+    db->dev = NULL;
+    std::vector<uint8_t> codes; std::vector<uint64_t> off;
+    flatten(db->chains, databaseLen, codes, off);
+    db->residues = (long long)off[databaseLen];
+    int rc = s4g_db_create(&db->dev, db->device, codes.data(), off.data(), (uint32_t)databaseLen);
+    if (rc != S4G_OK)
+        SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->device, s4g_last_error());
+    return db;
+}
+
+SW_API void chainDatabaseDelete(ChainDatabase* db) {
+    if (!db) return;
+    s4g_db_destroy(db->dev);
+    delete db;
+}
+
+// ------------------------------------------------------------------------------------------------ DbAlignment / Alignment
+static DbAlignment* make_db_alignment(Chain* query, int query_idx, Chain* target, int target_idx, double value,
+                                      Scorer* scorer, const swimpl::PairResult& r) {
+    DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
+    a->query = query; a->query_idx = query_idx; a->query_start = r.q_start; a->query_end = r.q_end;
+    a->target = target; a->target_idx = target_idx; a->target_start = r.t_start; a->target_end = r.t_end;
+    a->score = r.score; a->value = value; a->scorer = scorer;
+    a->path_len = (int)r.path.size();
+    a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+    if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
+    return a;
+}
+
+SW_API Chain* dbAlignmentGetQuery(DbAlignment* a) { return a->query; }
+SW_API int dbAlignmentGetQueryIdx(DbAlignment* a) { return a->query_idx; }
+SW_API int dbAlignmentGetQueryStart(DbAlignment* a) { return a->query_start; }
+SW_API int dbAlignmentGetQueryEnd(DbAlignment* a) { return a->query_end; }
+SW_API Chain* dbAlignmentGetTarget(DbAlignment* a) { return a->target; }
+SW_API int dbAlignmentGetTargetIdx(DbAlignment* a) { return a->target_idx; }
+SW_API int dbAlignmentGetTargetStart(DbAlignment* a) { return a->target_start; }
+SW_API int dbAlignmentGetTargetEnd(DbAlignment* a) { return a->target_end; }
+SW_API int dbAlignmentGetScore(DbAlignment* a) { return a->score; }
+SW_API double dbAlignmentGetValue(DbAlignment* a) { return a->value; }
+SW_API Scorer* dbAlignmentGetScorer(DbAlignment* a) { return a->scorer; }
+SW_API int dbAlignmentGetPathLen(DbAlignment* a) { return a->path_len; }
+SW_API char dbAlignmentGetMove(DbAlignment* a, int index) { return a->path[index]; }
+SW_API void dbAlignmentCopyPath(DbAlignment* a, char* dest) { memcpy(dest, a->path, a->path_len); }
+SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { free(a->path); free(a); } }
+
+SW_API Alignment* dbAlignmentToAlignment(DbAlignment* d) {
+    Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
+    a->query = d->query; a->query_start = d->query_start; a->query_end = d->query_end;
+    a->target = d->target; a->target_start = d->target_start; a->target_end = d->target_end;
+    a->score = d->score; a->scorer = d->scorer; a->path_len = d->path_len;
+    a->path = (char*)malloc(d->path_len ? d->path_len : 1);
+    if (d->path_len) memcpy(a->path, d->path, d->path_len);
+    return a;
+}
+
+SW_API Chain* alignmentGetQuery(Alignment* a) { return a->query; }
+SW_API int alignmentGetQueryStart(Alignment* a) { return a->query_start; }
+SW_API int alignmentGetQueryEnd(Alignment* a) { return a->query_end; }
+SW_API Chain* alignmentGetTarget(Alignment* a) { return a->target; }
+SW_API int alignmentGetTargetStart(Alignment* a) { return a->target_start; }
+SW_API int alignmentGetTargetEnd(Alignment* a) { return a->target_end; }
+SW_API int alignmentGetScore(Alignment* a) { return a->score; }
+SW_API Scorer* alignmentGetScorer(Alignment* a) { return a->scorer; }
+SW_API int alignmentGetPathLen(Alignment* a) { return a->path_len; }
+SW_API char alignmentGetMove(Alignment* a, int index) { return a->path[index]; }
+SW_API void alignmentCopyPath(Alignment* a, char* dest) { memcpy(dest, a->path, a->path_len); }
+SW_API void alignmentDelete(Alignment* a) { if (a) { free(a->path); free(a); } }
+
+SW_API void alignPair(Alignment** alignment, int type, Chain* query, Chain* target, Scorer* scorer,
+                      int* cards, int cardsLen, Thread* thread) {
+    (void)cards; (void)cardsLen; (void)thread;
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    swimpl::PairResult r;
+    swimpl::sw_traceback(chainGetCodes(query), chainGetLength(query), chainGetCodes(target), chainGetLength(target), scorer, &r);
+    Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
+    a->query = query; a->query_start = r.q_start; a->query_end = r.q_end;
+    a->target = target; a->target_start = r.t_start; a->target_end = r.t_end;
+    a->score = r.score; a->scorer = scorer; a->path_len = (int)r.path.size();
+    a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+    if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
+    *alignment = a;
+}
+
+// ------------------------------------------------------------------------------------------------ steps 2-4
+namespace {
+
+struct Survivor { int idx; int score; double value; };
+
+struct TraceJob {
+    Chain* query; Chain* target; int target_idx; double value; Scorer* scorer; int expect_score;
+    DbAlignment* result;
+};
+
+void* trace_task(void* p) {
+    TraceJob* jb = (TraceJob*)p;
+    swimpl::PairResult r;
+    swimpl::sw_traceback(chainGetCodes(jb->query), chainGetLength(jb->query), chainGetCodes(jb->target),
+                         chainGetLength(jb->target), jb->scorer, &r);
+    if (r.score != jb->expect_score)
+        SW_FATAL("internal error: device score %d and host traceback score %d disagree for target '%s'", jb->expect_score,
+                 r.score, chainGetName(jb->target));
+    jb->result = make_db_alignment(jb->query, 0, jb->target, jb->target_idx, jb->value, jb->scorer, r);
+    return NULL;
+}
+
+}  // namespace
+
+SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,
+                                   Chain** database, int databaseLen, const int* scores, Scorer* scorer, int maxAlignments,
+                                   ValueFunction valueFunction, void* valueFunctionParam, double valueThreshold) {
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    *dbAlignments = NULL;
+    *dbAlignmentsLen = 0;
+    if (databaseLen <= 0) return;
+    std::vector<double> values(databaseLen);
+    if (valueFunction) {
+        std::vector<int> sc(scores, scores + databaseLen);
+        valueFunction(values.data(), sc.data(), query, database, databaseLen, NULL, 0, valueFunctionParam);
+    } else {
+        for (int i = 0; i < databaseLen; ++i) values[i] = -(double)scores[i];
+    }
+    std::vector<Survivor> keep;
+    for (int i = 0; i < databaseLen; ++i)
+        if (scores[i] > 0 && (!valueFunction || values[i] <= valueThreshold)) keep.push_back({i, scores[i], values[i]});
+    std::sort(keep.begin(), keep.end(), [](const Survivor& a, const Survivor& b) {
+        if (a.value != b.value) return a.value < b.value;
+        if (a.score != b.score) return a.score > b.score;
+        return a.idx < b.idx;
+    });
+    if (maxAlignments >= 0 && (int)keep.size() > maxAlignments) keep.resize(maxAlignments);
+    const int n = (int)keep.size();
+    if (n == 0) return;
+    std::vector<TraceJob> jobs(n);
+    std::vector<ThreadPoolTask*> tasks(n);
+    for (int k = 0; k < n; ++k) {
+        jobs[k] = {query, database[keep[k].idx], keep[k].idx, keep[k].value, scorer, keep[k].score, NULL};
+        tasks[k] = threadPoolSubmit(trace_task, &jobs[k]);
+    }
+    DbAlignment** out = (DbAlignment**)malloc(sizeof(DbAlignment*) * n);   /* malloc domain: callers free() these arrays */
+    for (int k = 0; k < n; ++k) {
+        threadPoolTaskWait(tasks[k]);
+        threadPoolTaskDelete(tasks[k]);
+        out[k] = jobs[k].result;
+    }
+    *dbAlignments = out;
+    *dbAlignmentsLen = n;
+}
+
+// ------------------------------------------------------------------------------------------------ step 1 + glue
+SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                            ChainDatabase* cdb, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
+                            void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
+                            int* cards, int cardsLen, Thread* thread) {
+    (void)cards; (void)cardsLen; (void)thread;   // the ChainDatabase already lives on its device
+    SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0, "shotgunDatabase: invalid arguments");
+    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    if (queriesLen == 0 || cdb->length == 0) return;
+
+    std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
+    flatten(queries, queriesLen, qcodes, qoff);
+    s4g_queries* dq = NULL;
+    if (s4g_queries_create(&dq, cdb->device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
+        SW_FATAL("cannot place the queries on MI355X device %d: %s", cdb->device, s4g_last_error());
+
+    // targets to consider: all, or the caller's subset
+    std::vector<int> subset;
+    std::vector<Chain*> sub_chains;
+    if (indexes && indexesLen > 0) {
+        subset.assign(indexes, indexes + indexesLen);
+        for (int i : subset) { SW_ASSERT(i >= 0 && i < cdb->length, "index %d out of range", i); sub_chains.push_back(cdb->chains[i]); }
+    }
+    // batches bound the host score matrix to ~1 GiB
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)queriesLen, (1ull << 28) / (uint64_t)cdb->length));
+    std::vector<int32_t> scores((size_t)batch * cdb->length);
+    std::vector<int> picked;
+    for (uint32_t b = 0; b < (uint32_t)queriesLen; b += batch) {
+        const uint32_t cnt = std::min<uint32_t>(batch, (uint32_t)queriesLen - b);
+        if (s4g_scan_host(cdb->dev, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
+            SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int32_t* row = scores.data() + (size_t)i * cdb->length;
+            DbAlignment** out = NULL; int n = 0;
+            if (subset.empty()) {
+                dbAlignmentsFromScores(&out, &n, type, queries[b + i], cdb->chains, cdb->length, row, scorer, maxAlignments,
+                                       valueFunction, valueFunctionParam, valueThreshold);
+            } else {
+                picked.resize(subset.size());
+                for (size_t k = 0; k < subset.size(); ++k) picked[k] = row[subset[k]];
+                dbAlignmentsFromScores(&out, &n, type, queries[b + i], sub_chains.data(), (int)subset.size(), picked.data(),
+                                       scorer, maxAlignments, valueFunction, valueFunctionParam, valueThreshold);
+                for (int k = 0; k < n; ++k) out[k]->target_idx = subset[out[k]->target_idx];
+            }
+            for (int k = 0; k < n; ++k) out[k]->query_idx = (int)(b + i);
+            (*dbAlignments)[b + i] = out;
+            (*dbAlignmentsLens)[b + i] = n;
+        }
+    }
+    s4g_queries_destroy(dq);
+}
+
+SW_API void alignDatabase(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,
+                          ChainDatabase* chainDatabase, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
+                          void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
+                          int* cards, int cardsLen, Thread* thread) {
+    DbAlignment*** all = NULL; int* lens = NULL;
+    shotgunDatabase(&all, &lens, type, &query, 1, chainDatabase, scorer, maxAlignments, valueFunction, valueFunctionParam,
+                    valueThreshold, indexes, indexesLen, cards, cardsLen, thread);
+    *dbAlignments = all[0];
+    *dbAlignmentsLen = lens[0];
+    for (int k = 0; k < lens[0]; ++k) all[0][k]->query_idx = 0;
+    free(all);
+    free(lens);
+}
+
+// ------------------------------------------------------------------------------------------------ merge / delete
+static bool db_alignment_before(const DbAlignment* a, const DbAlignment* b) {
+    if (a->value != b->value) return a->value < b->value;
+    return a->score > b->score;
+}
+
+// Merges, per query, the sorted list src into the sorted list dst and keeps the best maxAlignments
+// (the cross-chunk merge of database_alignment.cpp:97-104; also the multi-GPU merge).  Entries that do not
+// survive are deleted; src lists are left empty so the caller's deleteShotgunDatabase(src) frees only containers.
+SW_API void dbAlignmentsMerge(DbAlignment*** dst, int* dstLens, DbAlignment*** src, int* srcLens, int n, int maxAlignments) {
+    for (int i = 0; i < n; ++i) {
+        const int a = dstLens[i], b = srcLens[i];
+        if (b == 0) continue;
+        const int total = a + b;
+        const int keep = (maxAlignments >= 0 && total > maxAlignments) ? maxAlignments : total;
+        DbAlignment** merged = (DbAlignment**)malloc(sizeof(DbAlignment*) * (total ? total : 1));
+        int x = 0, y = 0, k = 0;
+        while (x < a || y < b) {
+            DbAlignment* pick;
+            if (y >= b || (x < a && !db_alignment_before(src[i][y], dst[i][x]))) pick = dst[i][x++];   // stable: dst first on ties
+            else pick = src[i][y++];
+            if (k < keep) merged[k++] = pick; else dbAlignmentDelete(pick);
+        }
+        free(dst[i]);
+        dst[i] = merged;
+        dstLens[i] = keep;
+        free(src[i]);
+        src[i] = NULL;
+        srcLens[i] = 0;
+    }
+}
+
+SW_API void deleteShotgunDatabase(DbAlignment*** dbAlignments, int* dbAlignmentsLens, int dbAlignmentsLen) {
+    if (dbAlignments) {
+        for (int i = 0; i < dbAlignmentsLen; ++i) {
+            if (!dbAlignments[i]) continue;
+            for (int j = 0; j < dbAlignmentsLens[i]; ++j) dbAlignmentDelete(dbAlignments[i][j]);
+            free(dbAlignments[i]);
+        }
+        free(dbAlignments);
+    }
+    free(dbAlignmentsLens);
+}

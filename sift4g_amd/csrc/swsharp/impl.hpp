@@ -1,0 +1,86 @@
+// impl.hpp -- internal object layouts of libswsharp (the swsharp-compatible host API, include/swsharp/*.h).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../../include/s4g_hip.h"
+#include "../../../include/swsharp/evalue.h"
+#include "../../../include/swsharp/swsharp.h"
+
+#define SW_API extern "C" __attribute__((visibility("default")))
+
+// sift4g's own fatal-error style (/root/reference/sift4g/src/utils.hpp:13-19): message on stderr, exit(-1).
+#define SW_FATAL(fmt, ...)                                            \
+    do {                                                              \
+        fprintf(stderr, "[ERROR]: " fmt "\n", ##__VA_ARGS__);         \
+        exit(-1);                                                     \
+    } while (0)
+#define SW_ASSERT(expr, fmt, ...) do { if (!(expr)) SW_FATAL(fmt, ##__VA_ARGS__); } while (0)
+
+struct ChainData {           // shared storage of a chain and its views
+    char* name;
+    char* chars;
+    char* codes;
+    int length;
+    int refs;
+};
+
+struct Chain {
+    ChainData* data;
+    int start;               // view window into data, inclusive
+    int length;
+    bool reverse;
+    char* rev_chars;         // materialised only for reverse views
+    char* rev_codes;
+};
+
+struct Scorer {
+    std::string name;
+    int32_t table[26 * 26];
+    int gap_open, gap_extend, max_score;
+    s4g_scorer* dev;         // device-side twin (host object inside libs4g_hip)
+};
+
+struct ChainDatabase {
+    Chain** chains;          // borrowed: database + databaseStart
+    int length;
+    int device;
+    s4g_db* dev;
+    long long residues;
+};
+
+struct DbAlignment {
+    Chain* query; int query_idx, query_start, query_end;
+    Chain* target; int target_idx, target_start, target_end;
+    int score; double value;
+    Scorer* scorer;
+    char* path; int path_len;
+};
+
+struct Alignment {
+    Chain* query; int query_start, query_end;
+    Chain* target; int target_start, target_end;
+    int score;
+    Scorer* scorer;
+    char* path; int path_len;
+};
+
+struct EValueParams {
+    long long length;
+    double lambda, K, logK, H, a, b, alpha, beta, sigma, tau;
+    bool gapped_row_found;
+};
+
+namespace swimpl {
+
+struct PairResult {
+    int score, q_start, q_end, t_start, t_end;
+    std::vector<char> path;   // MOVE_* from start to end
+};
+// Host Smith-Waterman with traceback (the "traceback of the <= maxAlignments survivors" stage).
+void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc, PairResult* out);
+
+}  // namespace swimpl

@@ -1,0 +1,105 @@
+"""GPU tests of the swsharp-compatible API: alignDatabase / shotgunDatabase through libswsharp.so (HIP scoring)
+against the same selection run on oracle scores, and the reference's own CLI linked against our libraries."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, rand_seqs
+import swsharp_ctypes as sw
+from swsharp_ctypes import L, vp, pvp, ci
+
+pytestmark = pytest.mark.gpu
+
+
+def _hits(out, n):
+    return [(L.dbAlignmentGetTargetIdx(out[k]), L.dbAlignmentGetScore(out[k]), L.dbAlignmentGetValue(out[k]),
+             L.dbAlignmentGetQueryStart(out[k]), L.dbAlignmentGetTargetStart(out[k]),
+             tuple(sw.path_of(L.dbAlignmentGetPathLen, L.dbAlignmentGetMove, out[k]))) for k in range(n)]
+
+
+def test_align_database_equals_selection_on_oracle_scores(oracle_mod, blosum62, cfg1):
+    """the 15-argument call of database_alignment.cpp:83-86 on the reference fixture."""
+    s = sw.scorer(10, 1)
+    targets = [sw.chain(n, c) for n, c in cfg1["targets"]]
+    arr = sw.chain_array(targets)
+    cards = (ci * 1)(0)
+    cdb = L.chainDatabaseCreate(arr, 0, len(targets), cards, 1)
+    ev = L.createEValueParams(3091, s)
+    cb = sw.evalue_callback()
+    for qi, (qn, qc) in enumerate(cfg1["queries"]):
+        q = sw.chain(qn, qc)
+        out, n = pvp(), ci()
+        L.alignDatabase(ctypes.byref(out), ctypes.byref(n), 0, q, cdb, s, 400, cb, ev, 1e-4, None, 0, cards, 1, None)
+        ref, nr = pvp(), ci()
+        sc = (ci * len(targets))(*[int(x) for x in cfg1["scores"][qi]])
+        L.dbAlignmentsFromScores(ctypes.byref(ref), ctypes.byref(nr), 0, q, arr, len(targets), sc, s, 400, cb, ev, 1e-4)
+        assert n.value == nr.value >= 5
+        assert _hits(out, n.value) == _hits(ref, nr.value)
+        # subset call (indexes argument)
+        idx = (ci * 3)(4, 1, 7)
+        sub, ns = pvp(), ci()
+        L.alignDatabase(ctypes.byref(sub), ctypes.byref(ns), 0, q, cdb, s, 400, cb, ev, 1e9, idx, 3, cards, 1, None)
+        assert sorted(h[0] for h in _hits(sub, ns.value)) == [1, 4, 7]
+        assert all(cfg1["scores"][qi][h[0]] == h[1] for h in _hits(sub, ns.value))
+        L.chainDelete(q)
+    L.deleteEValueParams(ev); L.chainDatabaseDelete(cdb); L.scorerDelete(s)
+
+
+def test_shotgun_database_batch(oracle_mod, blosum62):
+    rng = np.random.default_rng(31)
+    qs = rand_seqs(rng, 12, 60, 200)
+    ts = rand_seqs(rng, 400, 30, 260)
+    for k in range(40):                                   # plant homologs
+        m = qs[k % 12].copy(); idx = rng.choice(len(m), size=len(m) // 3, replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]; ts[k * 7] = m
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    s = sw.scorer(10, 1)
+    tch = [sw.chain(f"t{i}", t) for i, t in enumerate(ts)]
+    qch = [sw.chain(f"q{i}", q) for i, q in enumerate(qs)]
+    tarr, qarr = sw.chain_array(tch), sw.chain_array(qch)
+    cdb = L.chainDatabaseCreate(tarr, 0, len(tch), None, 0)       # zero cards: device 0
+    cells = int(sum(len(t) for t in ts))
+    ev = L.createEValueParams(cells, s)
+    cb = sw.evalue_callback()
+    outs, lens = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
+    L.shotgunDatabase(ctypes.byref(outs), ctypes.byref(lens), 0, qarr, len(qch), cdb, s, 10, cb, ev, 1e-3, None, 0, None, 0, None)
+    total = 0
+    for i in range(len(qs)):
+        ref, nr = pvp(), ci()
+        sc = (ci * len(ts))(*[int(x) for x in exp[i]])
+        L.dbAlignmentsFromScores(ctypes.byref(ref), ctypes.byref(nr), 0, qch[i], tarr, len(tch), sc, s, 10, cb, ev, 1e-3)
+        assert lens[i] == nr.value
+        assert _hits(outs[i], lens[i]) == _hits(ref, nr.value)
+        total += lens[i]
+    assert total >= 40
+    L.deleteShotgunDatabase(outs, lens, len(qs))
+    L.deleteEValueParams(ev); L.chainDatabaseDelete(cdb); L.scorerDelete(s)
+
+
+DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+def test_reference_cli_runs_on_our_library(tmp_path):
+    """The reference's unmodified sift4g CLI, linked against libswsharp/libs4g_hip, on its own test_files
+    (test_files/README.md:13-19).  Output parity with swsharp is unpinned; this checks the pipeline completes and
+    the predictions are well-formed and stable against the committed run of this same path."""
+    tf = os.path.join(GOLDEN, "test_files")
+    r = subprocess.run([DROPIN, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d",
+                        os.path.join(tf, "sample_protein_database.fa"), "--out", str(tmp_path), "--cards", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name, n_subst in (("LACI_ECOLI", 3), ("PURR_SALTY", 2)):
+        path = tmp_path / f"{name}.SIFTprediction"
+        assert path.exists(), r.stderr[-2000:]
+        lines = [l for l in path.read_text().splitlines() if l and not l.startswith("WARNING")]
+        assert len(lines) == n_subst
+        for l in lines:
+            f = l.split("\t")
+            assert f[1] in ("TOLERATED", "DELETERIOUS") and 0.0 <= float(f[2]) <= 1.0
+        gold = os.path.join(GOLDEN, "dropin_predictions", f"{name}.SIFTprediction")
+        if os.path.exists(gold):
+            assert path.read_text() == open(gold).read()

@@ -1,0 +1,215 @@
+"""CPU tests of the host side of the drop-in boundary (libswsharp.so): FASTA, Chain, thread pool, e-values,
+post-scoring selection + traceback, merge.  Scores are supplied by the oracle; the HIP scoring step itself is
+covered by the -m gpu tests."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rand_seqs
+import swsharp_ctypes as sw
+from swsharp_ctypes import L, vp, pvp, ci, cd
+
+FASTA_Q = os.path.join(GOLDEN, "test_files", "query.fasta").encode()
+FASTA_DB = os.path.join(GOLDEN, "test_files", "sample_protein_database.fa").encode()
+
+
+def test_read_fasta_matches_fixture(cfg1):
+    chains, n = pvp(), ci()
+    L.readFastaChains(ctypes.byref(chains), ctypes.byref(n), FASTA_DB)
+    assert n.value == 9
+    for i, (name, codes) in enumerate(cfg1["targets"]):
+        assert L.chainGetName(chains[i]).decode() == name
+        assert sw.chain_codes(chains[i]) == codes.tolist()
+        assert L.chainGetChar(chains[i], 0) == bytes([codes[0] + 65])
+    # deleteFastaChains must skip NULL entries (database_search.cpp:127-128 NULLs them)
+    L.chainDelete(chains[3]); chains[3] = None
+    L.deleteFastaChains(chains, n)
+
+
+def test_read_fasta_in_parts(cfg1):
+    """chunked reading appends to the same array and returns 0 at EOF (database_alignment.cpp:36-47,116-118)."""
+    chains, n, fh, ser = pvp(), ci(), vp(), ci()
+    L.readFastaChainsPartInit(ctypes.byref(chains), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), FASTA_DB)
+    assert n.value == 0 and ser.value == 0
+    counts = []
+    while True:
+        status = L.readFastaChainsPart(ctypes.byref(chains), ctypes.byref(n), fh, ser, 700)   # ~2 records per part
+        counts.append(n.value)
+        if status == 0:
+            break
+    assert counts[-1] == 9 and len(counts) >= 3 and counts == sorted(counts)
+    for i, (name, codes) in enumerate(cfg1["targets"]):
+        assert L.chainGetName(chains[i]).decode() == name and sw.chain_codes(chains[i]) == codes.tolist()
+    sw.libc.fclose(fh)
+    L.deleteFastaChains(chains, n)
+
+
+def test_chain_create_filters_and_views():
+    c = L.chainCreate(b"x y", 3, b"ac-d*e 1fG\n", 11)
+    assert L.chainGetName(c) == b"x y" and L.chainGetLength(c) == 6
+    assert sw.chain_codes(c) == [0, 2, 3, 4, 5, 6]
+    v = L.chainCreateView(c, 1, 3, 0)
+    assert sw.chain_codes(v) == [2, 3, 4] and L.chainGetChar(v, 0) == b"C"
+    r = L.chainCreateView(c, 0, 5, 1)
+    assert sw.chain_codes(r) == [6, 5, 4, 3, 2, 0]
+    L.chainDelete(c)                      # views keep the storage alive
+    assert sw.chain_codes(v) == [2, 3, 4]
+    L.chainDelete(v); L.chainDelete(r)
+
+
+def test_scorer_matches_oracle_table(blosum62):
+    s = sw.scorer(10, 1)
+    assert L.scorerGetGapOpen(s) == 10 and L.scorerGetGapExtend(s) == 1 and L.scorerGetMaxScore(s) == 11
+    for a in range(26):
+        for b in range(26):
+            assert L.scorerScore(s, bytes([a]), bytes([b])) == blosum62[a, b]
+    L.scorerDelete(s)
+
+
+def test_thread_pool_runs_tasks_and_tolerates_null():
+    hits = []
+    cb = sw.Routine(lambda p: hits.append(p) or None)
+    t0 = L.threadPoolSubmit(cb, 5)        # pool not initialised: runs inline
+    L.threadPoolTaskWait(t0); L.threadPoolTaskDelete(t0)
+    assert hits == [5]
+    L.threadPoolInitialize(4)
+    tasks = [L.threadPoolSubmit(cb, i + 10) for i in range(32)]
+    for t in tasks:
+        L.threadPoolTaskWait(t); L.threadPoolTaskDelete(t)
+    assert sorted(hits[1:]) == list(range(10, 42))
+    L.threadPoolTaskWait(None); L.threadPoolTaskDelete(None)      # select_alignments.cpp:57-59,68-69
+    L.threadPoolTerminate()
+
+
+def test_align_pair_equals_oracle_traceback(oracle_mod, blosum62):
+    rng = np.random.default_rng(5)
+    s = sw.scorer(10, 1)
+    for it in range(80):
+        q = rand_seqs(rng, 1, 1, 120)[0]
+        t = rand_seqs(rng, 1, 1, 140)[0]
+        if it % 2 and len(q) > 12:
+            cut = int(rng.integers(3, len(q) - 3))
+            t = np.concatenate([q[:cut], rand_seqs(rng, 1, 1, 5)[0], q[cut + (it % 3):]])
+        cq, ct = sw.chain("q", q), sw.chain("t", t)
+        a = vp()
+        L.alignPair(ctypes.byref(a), 0, cq, ct, s, None, 0, None)
+        o = oracle_mod.sw_align(q, t, blosum62, 10, 1)
+        assert L.alignmentGetScore(a) == o["score"]
+        if o["score"] > 0:
+            assert (L.alignmentGetQueryStart(a), L.alignmentGetQueryEnd(a)) == (o["q_start"], o["q_end"])
+            assert (L.alignmentGetTargetStart(a), L.alignmentGetTargetEnd(a)) == (o["t_start"], o["t_end"])
+            assert sw.path_of(L.alignmentGetPathLen, L.alignmentGetMove, a) == [sw.ORACLE_TO_MOVE[m] for m in o["path"]]
+        L.alignmentDelete(a); L.chainDelete(cq); L.chainDelete(ct)
+    L.scorerDelete(s)
+
+
+def _lists_from_scores(query, targets, scores, s, max_align, threshold, cells):
+    ev = L.createEValueParams(cells, s)
+    cb = sw.evalue_callback()
+    out, n = pvp(), ci()
+    arr = sw.chain_array(targets)
+    sc = (ci * len(targets))(*[int(x) for x in scores])
+    L.dbAlignmentsFromScores(ctypes.byref(out), ctypes.byref(n), 0, query, arr, len(targets), sc, s, max_align, cb, ev, threshold)
+    L.deleteEValueParams(ev)
+    return out, n
+
+
+def test_selection_sorting_threshold_and_paths(oracle_mod, blosum62, cfg1):
+    """steps 2-4 of alignDatabase on the reference fixture with oracle scores (main.cpp:75-76 defaults)."""
+    s = sw.scorer(10, 1)
+    targets = [sw.chain(n, c) for n, c in cfg1["targets"]]
+    for qi, (qn, qc) in enumerate(cfg1["queries"]):
+        q = sw.chain(qn, qc)
+        out, n = _lists_from_scores(q, targets, cfg1["scores"][qi], s, 400, 1e-4, 3091)
+        got = [(L.dbAlignmentGetTargetIdx(out[k]), L.dbAlignmentGetScore(out[k]), L.dbAlignmentGetValue(out[k])) for k in range(n.value)]
+        assert [g[1] for g in got] == sorted((g[1] for g in got), reverse=True)        # e-value order == score order here
+        assert all(g[2] <= 1e-4 for g in got) and [g[2] for g in got] == sorted(g[2] for g in got)
+        assert all(cfg1["scores"][qi][g[0]] == g[1] for g in got)
+        # the homologous repressors are all significant on this tiny database
+        assert n.value >= 5
+        for k in range(n.value):
+            ti = L.dbAlignmentGetTargetIdx(out[k])
+            o = oracle_mod.sw_align(qc, cfg1["targets"][ti][1], blosum62, 10, 1)
+            assert sw.path_of(L.dbAlignmentGetPathLen, L.dbAlignmentGetMove, out[k]) == [sw.ORACLE_TO_MOVE[m] for m in o["path"]]
+            assert L.dbAlignmentGetQueryStart(out[k]) == o["q_start"] and L.dbAlignmentGetTargetEnd(out[k]) == o["t_end"]
+            al = L.dbAlignmentToAlignment(out[k])
+            assert L.alignmentGetPathLen(al) == len(o["path"]) and L.alignmentGetScore(al) == o["score"]
+            L.alignmentDelete(al)
+        # top-k cut
+        out2, n2 = _lists_from_scores(q, targets, cfg1["scores"][qi], s, 3, 1e-4, 3091)
+        assert n2.value == 3 and [L.dbAlignmentGetTargetIdx(out2[k]) for k in range(3)] == [g[0] for g in got[:3]]
+        lens = (ci * 1)(n.value); outer = (pvp * 1)(out)
+        for fmt in (0, 1, 2, 3):
+            path = f"/tmp/s4g_out_{os.getpid()}_{fmt}.txt".encode()
+            L.outputShotgunDatabase(outer, lens, 1, path, fmt)
+            assert os.path.getsize(path) > 50
+            os.remove(path)
+        for k in range(n.value):
+            L.dbAlignmentDelete(out[k])
+        for k in range(n2.value):
+            L.dbAlignmentDelete(out2[k])
+        sw.libc.free(out); sw.libc.free(out2)
+        L.chainDelete(q)
+    for t in targets:
+        L.chainDelete(t)
+    L.scorerDelete(s)
+
+
+def test_merge_of_chunks_equals_whole(oracle_mod, blosum62):
+    """dbAlignmentsMerge across database chunks (database_alignment.cpp:97-104) == one pass over the whole set."""
+    rng = np.random.default_rng(9)
+    s = sw.scorer(10, 1)
+    qc = rand_seqs(rng, 1, 150, 150)[0]
+    ts = []
+    for k in range(60):
+        m = qc.copy()
+        idx = rng.choice(150, size=int(rng.integers(5, 90)), replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]
+        ts.append(m)
+    scores = oracle_mod.scan([qc], ts, blosum62, 10, 1)[0]
+    q = sw.chain("q", qc)
+    chains = [sw.chain(f"t{k}", t) for k, t in enumerate(ts)]
+    cells = int(sum(len(t) for t in ts))
+    whole, nw = _lists_from_scores(q, chains, scores, s, 25, 10.0, cells)
+    a, na = _lists_from_scores(q, chains[:35], scores[:35], s, 25, 10.0, cells)
+    b, nb = _lists_from_scores(q, chains[35:], scores[35:], s, 25, 10.0, cells)
+    dst = (pvp * 1)(a); dl = (ci * 1)(na.value); src = (pvp * 1)(b); sl = (ci * 1)(nb.value)
+    L.dbAlignmentsMerge(dst, dl, src, sl, 1, 25)
+    assert dl[0] == nw.value == 25 and sl[0] == 0
+    merged = [(L.chainGetName(L.dbAlignmentGetTarget(dst[0][k])), L.dbAlignmentGetScore(dst[0][k])) for k in range(dl[0])]
+    want = [(L.chainGetName(L.dbAlignmentGetTarget(whole[k])), L.dbAlignmentGetScore(whole[k])) for k in range(nw.value)]
+    assert [m[1] for m in merged] == [w[1] for w in want]
+    assert sorted(merged) == sorted(want)
+    for k in range(dl[0]):
+        L.dbAlignmentDelete(dst[0][k])
+    for k in range(nw.value):
+        L.dbAlignmentDelete(whole[k])
+    sw.libc.free(dst[0]); sw.libc.free(whole)
+    for c in chains:
+        L.chainDelete(c)
+    L.chainDelete(q); L.scorerDelete(s)
+
+
+def test_evalue_behaviour():
+    s = sw.scorer(10, 1)
+    q = sw.chain("q", np.zeros(350, dtype=np.uint8))
+    t = sw.chain("t", np.zeros(340, dtype=np.uint8))
+    arr = sw.chain_array([t] * 6)
+    vals = (cd * 6)()
+    ev = L.createEValueParams(34_000_000, s)
+    L.eValues(vals, (ci * 6)(30, 50, 80, 120, 300, 1700), q, arr, 6, None, 0, ev)
+    v = list(vals)
+    assert all(v[i] > v[i + 1] for i in range(5))            # strictly decreasing in score
+    assert v[0] > 1.0 and v[3] < 1e-4 and v[5] < 1e-100       # random-level score vs clear homolog vs identity
+    ev2 = L.createEValueParams(68_000_000, s)
+    vals2 = (cd * 6)()
+    L.eValues(vals2, (ci * 6)(30, 50, 80, 120, 300, 1700), q, arr, 6, None, 0, ev2)
+    assert all(abs(vals2[i] / v[i] - 2.0) < 1e-9 for i in range(5))   # linear in database size
+    L.deleteEValueParams(ev); L.deleteEValueParams(ev2)
+    L.chainDelete(q); L.chainDelete(t); L.scorerDelete(s)
+
+
+def test_cards_api_without_gpu():
+    assert L.cudaCheckCards(None, 0) == 1          # main.cpp:78-79,186: zero cards must pass
