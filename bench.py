@@ -67,7 +67,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sift4g_amd as s4g
-    from sift4g_amd import synth
+    from sift4g_amd import synth, shard
     from sift4g_amd.device import scan_cells, scan_plan
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,13 +101,8 @@ def main():
         s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count)
         if i is not None:
             ev[i][1].record()
-        ids, sc, cnt = s4g.topk(db, scores, TOPK, 1)
-        if world > 1:
-            mine = torch.from_numpy(np.stack([ids.astype(np.int64), sc.astype(np.int64)], axis=0)).to(dev)
-            allhits = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
-            dist.all_gather_into_tensor(allhits, mine)
-            return allhits
-        return ids, sc, cnt
+        ids, sc, cnt = s4g.topk_device(db, scores, TOPK, 1)                     # steps 2-3 on the device
+        return shard.gather_query_shards(ids, sc, cnt, allq.n)                  # RCCL all-gather of the hit lists (N > 1)
 
     def fence():
         if world > 1:

@@ -34,7 +34,7 @@
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
  *       (s4g_score_lists_host = the per-query candidate lists built by
  *       createFilteredDatabase, database_alignment.cpp:136-162)
- *   s4g_topk_host
+ *   s4g_topk / s4g_topk_host
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
  *       and the merge semantics of dbAlignmentsMerge (:101-102)
@@ -117,8 +117,13 @@ int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t*
 
 /* Per-query top-k of a device score matrix [q_count][n_seqs] (as written by
  * s4g_scan): the k highest scores with score >= min_score, ordered by score
- * descending then target id ascending.  h_ids / h_scores: q_count * k entries
- * (unused tail filled with id 0xFFFFFFFF / score 0); h_counts[q] = entries used. */
+ * descending then target id ascending (exact and deterministic; 1 <= k <= 4096).
+ * ids / scores: q_count * k entries (unused tail filled with id 0xFFFFFFFF /
+ * score 0); counts[q] = entries used.
+ * s4g_topk: all pointers are DEVICE pointers, asynchronous on `stream` -- the
+ * form the multi-GPU gather consumes.  s4g_topk_host: results in host memory. */
+int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+             uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts, void* stream);
 int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
                   uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream);
 

@@ -43,6 +43,8 @@ SIGNATURES = {
     "s4g_scan_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_void_p, c_i32p]),
     "s4g_score_lists_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u32p, ctypes.c_void_p, c_i32p]),
+    "s4g_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "s4g_topk_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                      c_u32p, c_i32p, c_u32p, ctypes.c_void_p]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,

@@ -430,93 +430,159 @@ S4G_API int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const u
 }
 
 // ---------------------------------------------------------------------------
-// top-k: one block per query, iterative threshold selection in a single pass
-// over the score row (histogram of scores -> cut score -> compaction).
+// top-k (steps 2-3 of alignDatabase on the device): one 256-thread block per query row.
+//   1. two-level radix select on the int32 score (high 12 bits of a 24-bit score, then low 12 bits) finds the cut
+//      score exactly: the k-th largest score >= min_score;
+//   2. everything above the cut is kept; among the ties AT the cut the smallest target ids are kept (ordered
+//      block scan), so the result is the exact, deterministic top-k under (score desc, id asc);
+//   3. bitonic sort of the <= k survivors in LDS on the 64-bit key (~score << 32 | id).
 namespace {
 
 constexpr int kTopkBlock = 256;
-constexpr int kHistBins = 4096;
+constexpr int kBins = 4096;
+constexpr int kTopkMax = 4096;     // LDS: 4096 keys * 8 B = 32 KiB
+constexpr int kScoreCap = (1 << 24) - 1;
 
-__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k,
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// finds, scanning bins from the top, the bin where the running count reaches `want`; returns bin (or -1) and the
+// count strictly above it.  Single-threaded over 4096 LDS words: ~4k cycles per row, negligible next to the scan.
+__device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned* above) {
+    unsigned acc = 0;
+    int b = kBins - 1;
+    for (; b >= 0; --b) {
+        if (acc + hist[b] >= want) break;
+        acc += hist[b];
+    }
+    *bin = b;
+    *above = acc;
+}
+
+__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k, uint32_t kpad,
                                                         int32_t min_score, uint32_t* __restrict__ out_ids,
-                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                        uint32_t cap) {
-    // Pass 1: histogram of clamp(score, 0, kHistBins-1); pass 2: emit everything with
-    // score > cut, plus the score == cut entries (smallest ids first is restored on host by the sort).
-    __shared__ unsigned hist[kHistBins];
-    __shared__ int cut_s;
-    __shared__ unsigned n_out;
+                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
+    __shared__ unsigned hist[kBins];
+    __shared__ unsigned long long keys[kTopkMax];
+    __shared__ int s_hi, s_cut;
+    __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
+    const int tid = threadIdx.x;
     const int32_t* row = scores + (uint64_t)blockIdx.x * n;
-    for (int i = threadIdx.x; i < kHistBins; i += kTopkBlock) hist[i] = 0;
-    if (threadIdx.x == 0) n_out = 0;
+    if (min_score < 0) min_score = 0;
+
+    // ---- level 1: high 12 bits ----
+    for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kTopkBlock) {
-        int v = row[i];
-        if (v >= min_score) atomicAdd(&hist[v < 0 ? 0 : (v >= kHistBins ? kHistBins - 1 : v)], 1u);
+    for (uint32_t i = tid; i < n; i += kTopkBlock) {
+        const int v = row[i];
+        if (v >= min_score) atomicAdd(&hist[clampi(v, 0, kScoreCap) >> 12], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned acc = 0; int c = kHistBins - 1;
-        for (; c > 0; --c) { acc += hist[c]; if (acc >= k) break; }
-        cut_s = c;  // every score > cut is kept; scores == cut may overflow k (host trims)
-    }
+    if (tid == 0) { int b; unsigned a; find_bin(hist, k, &b, &a); s_hi = b; s_above = a; }
     __syncthreads();
-    const int cut = cut_s;
-    for (uint32_t i = threadIdx.x; i < n; i += kTopkBlock) {
-        int v = row[i];
-        if (v >= min_score && v >= cut) {
-            unsigned pos = atomicAdd(&n_out, 1u);
-            if (pos < cap) { out_ids[(uint64_t)blockIdx.x * cap + pos] = i; out_scores[(uint64_t)blockIdx.x * cap + pos] = v; }
+    const int hi = s_hi;
+    if (hi < 0) {
+        // fewer than k entries pass min_score: keep them all
+        if (tid == 0) { s_cut = min_score; s_quota = 0xFFFFFFFFu; }
+    } else {
+        // ---- level 2: low 12 bits inside the high bin ----
+        const unsigned above_hi = s_above;
+        __syncthreads();
+        for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kTopkBlock) {
+            const int v = row[i];
+            if (v >= min_score && (clampi(v, 0, kScoreCap) >> 12) == hi) atomicAdd(&hist[clampi(v, 0, kScoreCap) & (kBins - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int b; unsigned a;
+            find_bin(hist, k - above_hi, &b, &a);
+            s_cut = (hi << 12) | b;                       // exact cut score (scores are < 2^24)
+            s_quota = k - (above_hi + a);                 // ties at the cut to keep (smallest ids)
         }
     }
+    if (tid == 0) { s_nout = 0; s_tie_base = 0; }
     __syncthreads();
-    if (threadIdx.x == 0) out_counts[blockIdx.x] = n_out;
+    const int cut = s_cut;
+    const unsigned quota = s_quota;
+
+    // ---- compaction: > cut unordered, == cut in id order up to quota ----
+    for (uint32_t base = 0; base < n; base += kTopkBlock) {
+        const uint32_t i = base + tid;
+        const int v = i < n ? row[i] : -1;
+        const bool ok = i < n && v >= min_score;
+        const bool above = ok && (v > cut || quota == 0xFFFFFFFFu);
+        const bool tie = ok && !above && v == cut;
+        if (above) keys[atomicAdd(&s_nout, 1u)] = ((unsigned long long)(unsigned)(0x7FFFFFFF - v) << 32) | i;
+        const unsigned long long tb = __ballot(tie);
+        if ((tid & 63) == 0) s_wave_cnt[tid >> 6] = __popcll(tb);
+        __syncthreads();
+        unsigned rank = s_tie_base + __popcll(tb & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) rank += s_wave_cnt[w];
+        if (tie && rank < quota) keys[atomicAdd(&s_nout, 1u)] = ((unsigned long long)(unsigned)(0x7FFFFFFF - v) << 32) | i;
+        __syncthreads();
+        if (tid == 0) { unsigned t = 0; for (int w = 0; w < kTopkBlock / 64; ++w) t += s_wave_cnt[w]; s_tie_base += t; }
+        __syncthreads();
+    }
+    const unsigned m = s_nout;                             // <= k by construction
+    for (unsigned i = m + tid; i < kpad; i += kTopkBlock) keys[i] = ~0ull;
+    __syncthreads();
+    // ---- bitonic sort ascending on the key = score descending, id ascending ----
+    for (unsigned size = 2; size <= kpad; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < kpad / 2; t += kTopkBlock) {
+                const unsigned lo = 2 * t - (t & (stride - 1));
+                const unsigned hi2 = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a > b) == up) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (unsigned i = tid; i < k; i += kTopkBlock) {
+        const unsigned long long key = keys[i];
+        const bool valid = i < m;
+        out_ids[(uint64_t)blockIdx.x * k + i] = valid ? (uint32_t)key : 0xFFFFFFFFu;
+        out_scores[(uint64_t)blockIdx.x * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+    }
+    if (tid == 0) out_counts[blockIdx.x] = m;
 }
 
 }  // namespace
+
+S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+                     uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts, void* stream_) {
+    if (!db || !d_scores || !d_ids || !d_top_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (k == 0 || k > (uint32_t)kTopkMax) return fail(S4G_ERR_INVALID, "k must be in 1..%d (got %u)", kTopkMax, k);
+    if (q_count == 0) return S4G_OK;
+    DeviceGuard guard(db->device);
+    uint32_t kpad = 2;
+    while (kpad < k) kpad <<= 1;
+    hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, k, kpad,
+                       min_score, d_ids, d_top_scores, d_counts);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
 
 S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
                           uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream_) {
     if (!db || !d_scores || !h_ids || !h_scores || !h_counts) return fail(S4G_ERR_INVALID, "NULL argument");
     if (q_count == 0) return S4G_OK;
-    if (k == 0) { memset(h_counts, 0, (size_t)q_count * 4); return S4G_OK; }
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
-    const uint32_t n = db->n_seqs;
-    // candidates above the cut: at most k-1 strictly above plus all ties at the cut; give ties room.
-    uint32_t cap = std::min<uint64_t>(n, (uint64_t)k * 4 + 1024);
-    for (;;) {
-        uint32_t *d_ids = nullptr, *d_counts = nullptr; int32_t* d_sc = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_ids, (size_t)q_count * cap * 4));
-        HIP_TRY(hipMalloc((void**)&d_sc, (size_t)q_count * cap * 4));
-        HIP_TRY(hipMalloc((void**)&d_counts, (size_t)q_count * 4));
-        hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, stream, d_scores, n, k, min_score, d_ids, d_sc, d_counts, cap);
-        std::vector<uint32_t> ids((size_t)q_count * cap), counts(q_count);
-        std::vector<int32_t> sc((size_t)q_count * cap);
-        hipError_t e = hipMemcpyAsync(counts.data(), d_counts, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ids.data(), d_ids, ids.size() * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(sc.data(), d_sc, sc.size() * 4, hipMemcpyDeviceToHost, stream);
+    uint32_t *d_ids = nullptr, *d_counts = nullptr; int32_t* d_sc = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_ids, (size_t)q_count * k * 4));
+    HIP_TRY(hipMalloc((void**)&d_sc, (size_t)q_count * k * 4));
+    HIP_TRY(hipMalloc((void**)&d_counts, (size_t)q_count * 4));
+    int rc = s4g_topk(db, d_scores, q_count, k, min_score, d_ids, d_sc, d_counts, stream_);
+    if (rc == S4G_OK) {
+        hipError_t e = hipMemcpyAsync(h_counts, d_counts, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_ids, d_ids, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_scores, d_sc, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_ids); (void)hipFree(d_sc); (void)hipFree(d_counts);
-        if (e != hipSuccess) return fail(S4G_ERR_HIP, "top-k failed: %s", hipGetErrorString(e));
-        uint32_t worst = 0;
-        for (uint32_t q = 0; q < q_count; ++q) worst = std::max(worst, counts[q]);
-        if (worst > cap && cap < n) { cap = std::min<uint64_t>(n, (uint64_t)worst); continue; }  // rare: huge tie at the cut
-        std::vector<std::pair<int32_t, uint32_t>> v;
-        for (uint32_t q = 0; q < q_count; ++q) {
-            uint32_t m = std::min(counts[q], cap);
-            v.resize(m);
-            for (uint32_t i = 0; i < m; ++i) v[i] = {sc[(size_t)q * cap + i], ids[(size_t)q * cap + i]};
-            std::sort(v.begin(), v.end(), [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& b) {
-                return a.first != b.first ? a.first > b.first : a.second < b.second;
-            });
-            uint32_t keep = std::min<uint32_t>(m, k);
-            for (uint32_t i = 0; i < k; ++i) {
-                h_ids[(size_t)q * k + i] = i < keep ? v[i].second : 0xFFFFFFFFu;
-                h_scores[(size_t)q * k + i] = i < keep ? v[i].first : 0;
-            }
-            h_counts[q] = keep;
-        }
-        return S4G_OK;
+        if (e != hipSuccess) rc = fail(S4G_ERR_HIP, "top-k download failed: %s", hipGetErrorString(e));
     }
+    (void)hipFree(d_ids); (void)hipFree(d_sc); (void)hipFree(d_counts);
+    return rc;
 }

@@ -139,6 +139,22 @@ def score_lists(db, queries, scorer, cand_offsets, cand_ids):
     return out[: int(cand_offsets[-1])]
 
 
+def topk_device(db, scores, k, min_score=1, stream=None):
+    """Per-query top-k kept on the device: -> (ids int32 [q,k] (-1 = unused), scores int32 [q,k], counts int32 [q]) torch tensors.
+    This is the form the RCCL gather consumes (sift4g_amd/shard.py)."""
+    import torch
+    q = scores.shape[0]
+    ids = torch.empty((q, k), dtype=torch.int32, device=scores.device)
+    sc = torch.empty((q, k), dtype=torch.int32, device=scores.device)
+    cnt = torch.empty((q,), dtype=torch.int32, device=scores.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(scores.device)
+    check(lib.s4g_topk(db._h, ctypes.c_void_p(scores.data_ptr()), q, k, int(min_score), ctypes.c_void_p(ids.data_ptr()),
+                       ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(stream.cuda_stream)),
+          "s4g_topk")
+    return ids, sc, cnt
+
+
 def topk(db, scores, k, min_score=1, stream=None):
     """Per-query top-k of a device score tensor [q, n_seqs] -> (ids uint32 [q,k], scores int32 [q,k], counts uint32 [q])."""
     import torch

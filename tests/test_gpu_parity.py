@@ -174,6 +174,34 @@ def test_topk_matches_sorted_oracle(s4g, oracle_mod, blosum62, scorer):
             assert cnt[i] == len(order)
             assert ids[i, :cnt[i]].tolist() == order
             assert sc[i, :cnt[i]].tolist() == [int(exp[i, j]) for j in order]
+        dids, dsc, dcnt = s4g.topk_device(db, out, k, min_score)                # device-resident form (feeds the RCCL gather)
+        torch.cuda.synchronize()
+        assert np.array_equal(dcnt.cpu().numpy().astype(np.uint32), cnt)
+        assert np.array_equal(dsc.cpu().numpy(), sc)
+        assert np.array_equal(dids.cpu().numpy().astype(np.uint32), ids)
+
+
+def test_topk_heavy_ties_and_large_scores(s4g, scorer):
+    """exactness of the radix select: thousands of ties at the cut, scores beyond 12 bits, fewer than k candidates."""
+    import torch
+    rng = np.random.default_rng(24)
+    n = 5000
+    db = s4g.Database([np.zeros(3, dtype=np.uint8)] * n)
+    rows = np.stack([
+        np.full(n, 37),                                                    # all tied
+        rng.integers(30, 34, size=n),                                      # 4 distinct values
+        np.where(rng.random(n) < 0.01, rng.integers(4000, 300000, size=n), rng.integers(0, 60, size=n)),   # > 12-bit scores
+        np.where(np.arange(n) % 1000 == 7, 55, 0),                         # only 5 candidates
+        np.zeros(n),                                                       # none
+    ]).astype(np.int32)
+    t = torch.from_numpy(rows).cuda()
+    for k in (1, 7, 400, 4096):
+        ids, sc, cnt = s4g.topk(db, t, k, 1)
+        for i in range(rows.shape[0]):
+            order = sorted((j for j in range(n) if rows[i, j] >= 1), key=lambda j: (-rows[i, j], j))[:k]
+            assert cnt[i] == len(order) and ids[i, :cnt[i]].tolist() == order
+            assert sc[i, :cnt[i]].tolist() == [int(rows[i, j]) for j in order]
+            assert (ids[i, cnt[i]:] == 0xFFFFFFFF).all() and (sc[i, cnt[i]:] == 0).all()
 
 
 def test_full_size_properties(s4g, oracle_mod, blosum62, scorer):

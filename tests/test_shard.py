@@ -1,0 +1,108 @@
+"""Multi-process CPU tests (gloo, world size 2) of the sharding + gather logic used on N GPUs: the per-rank
+"device" results are emulated with oracle scores, the collectives are the real torch.distributed code path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _topk_ref(scores, k, min_score=1):
+    """numpy reference of s4g_topk: (score desc, id asc)"""
+    q, n = scores.shape
+    ids = np.full((q, k), -1, dtype=np.int32); sc = np.zeros((q, k), dtype=np.int32); cnt = np.zeros(q, dtype=np.int32)
+    for i in range(q):
+        order = sorted((j for j in range(n) if scores[i, j] >= min_score), key=lambda j: (-scores[i, j], j))[:k]
+        ids[i, :len(order)] = order; sc[i, :len(order)] = scores[i, order]; cnt[i] = len(order)
+    return ids, sc, cnt
+
+
+def _worker(rank, world, port, scores, k, mode, lengths, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sift4g_amd import shard
+    try:
+        nq, nt = scores.shape
+        if mode == "query":
+            b = shard.shard_bounds(nq, world)
+            ids, sc, cnt = _topk_ref(scores[b[rank]:b[rank + 1]], k)
+            out = shard.gather_query_shards(torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt), nq)
+        else:
+            mine = shard.balanced_db_shards(lengths, world)[rank]
+            ids, sc, cnt = _topk_ref(scores[:, mine.numpy()], k)
+            out = shard.gather_db_shards(torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt), mine, k)
+        q.put((rank, [t.numpy() for t in out]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, scores, k, mode, lengths=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scores, k, mode, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.fixture(scope="module")
+def case(oracle_mod, blosum62):
+    from conftest import rand_seqs
+    rng = np.random.default_rng(41)
+    qs = rand_seqs(rng, 7, 30, 90)          # 7 queries: uneven split over 2 ranks
+    ts = rand_seqs(rng, 150, 10, 120)
+    for j in range(0, 150, 9):
+        ts[j] = qs[j % 7][: 20 + j % 40].copy()
+    scores = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=4)
+    return scores, np.array([len(t) for t in ts])
+
+
+@pytest.mark.parametrize("k", [5, 40])
+def test_query_shard_gather_world2(case, k):
+    scores, _ = case
+    want = _topk_ref(scores, k)
+    res = _run(2, scores, k, "query")
+    for r in (0, 1):                        # every rank ends with the full, identical result
+        for got, exp in zip(res[r], want):
+            assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("k", [5, 40])
+def test_db_shard_merge_world2(case, k):
+    scores, lengths = case
+    want = _topk_ref(scores, k)
+    res = _run(2, scores, k, "db", lengths)
+    for r in (0, 1):
+        for got, exp in zip(res[r], want):
+            assert np.array_equal(got, exp)
+
+
+def test_single_process_paths_and_helpers(case):
+    from sift4g_amd import shard
+    scores, lengths = case
+    assert shard.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    parts = shard.balanced_db_shards(lengths, 3)
+    allids = torch.sort(torch.cat(parts)).values
+    assert allids.tolist() == list(range(len(lengths)))
+    tot = [int(lengths[p.numpy()].sum()) for p in parts]
+    assert max(tot) - min(tot) <= lengths.max()
+    ids, sc, cnt = _topk_ref(scores, 12)
+    out = shard.gather_query_shards(torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt), scores.shape[0])
+    assert np.array_equal(out[0].numpy(), ids)
+    m = shard.merge_topk(torch.from_numpy(np.concatenate([ids, ids], axis=1)), torch.from_numpy(np.concatenate([sc, sc], axis=1)), 24)
+    assert (m[2].numpy() == np.minimum(2 * cnt, 24)).all()
