@@ -144,7 +144,7 @@ def main():
             "metric": "GCUPS (SW cell updates/s) on query x DB scan",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if "i16" in plan["kernel"] else "int32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.queries} synthetic queries/GPU len U[300,400] x "
                                    f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
                                    f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",

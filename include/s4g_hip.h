@@ -28,7 +28,7 @@
  *   s4g_queries_create / s4g_queries_destroy
  *       the `Chain* query` argument of alignDatabase
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
- *   s4g_scan / s4g_scan_host / s4g_score_lists_host
+ *   s4g_scan / s4g_scan_flags / s4g_scan_host / s4g_scan_host_flags / s4g_score_lists_host
  *       step 1 of swsharp alignDatabase(...): the optimal local affine-gap
  *       score of the query against every target of the ChainDatabase
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
@@ -105,9 +105,17 @@ int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uin
 int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
              const s4g_scorer* scorer, int32_t* d_scores, void* stream);
 
+/* s4g_scan with options.  flags: S4G_SCAN_FORCE_I32 = run every query through the int32 kernel (by default
+ * queries whose score bound fits in int16 run in the packed int16x2 kernel, which is exact for them). */
+#define S4G_SCAN_FORCE_I32 1u
+int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                   const s4g_scorer* scorer, int32_t* d_scores, void* stream, uint32_t flags);
+
 /* Same, synchronous, scores copied to host memory h_scores[q_count * n_seqs]. */
 int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
                   const s4g_scorer* scorer, int32_t* h_scores);
+int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                        const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags);
 
 /* Candidate-list mode (what sift4g's wrapper does per query): query i is
  * scored against targets cand_ids[cand_offsets[i] .. cand_offsets[i+1]) only.

@@ -15,6 +15,7 @@ S4G_ERR_NO_DEVICE = -1
 S4G_ERR_INVALID = -2
 S4G_ERR_HIP = -3
 S4G_ERR_NOMEM = -4
+S4G_SCAN_FORCE_I32 = 1
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -40,6 +41,10 @@ SIGNATURES = {
     "s4g_scan_cells": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, c_u64p]),
     "s4g_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s4g_scan_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "s4g_scan_host_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.c_void_p, c_i32p, ctypes.c_uint32]),
     "s4g_scan_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_void_p, c_i32p]),
     "s4g_score_lists_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u32p, ctypes.c_void_p, c_i32p]),

@@ -9,6 +9,7 @@
 #include "matrices.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -64,6 +65,8 @@ struct s4g_scorer {
     int8_t mat32[32 * 32];
     int open, ext;
     int max_score;
+    int row_max[32];        // max(0, max_b table[a][b]): per-row bound on what one DP row can add
+    uint64_t serial;        // identity for caches keyed on the scorer
 };
 
 struct s4g_db {
@@ -83,7 +86,9 @@ struct s4g_db {
     mutable uint64_t ws_bytes = 0;
     mutable unsigned* d_counter = nullptr;
     mutable int8_t* d_mat = nullptr;
-    mutable uint32_t grid_blocks = 0;
+    mutable uint32_t* d_qlist = nullptr;     // query-id lists of the current launch (pairs for i16x2, singles for i32)
+    mutable uint64_t qlist_cap = 0;
+    mutable uint32_t grid_i32 = 0, grid_i16 = 0;
 };
 
 struct s4g_queries {
@@ -93,7 +98,11 @@ struct s4g_queries {
     uint64_t* d_off = nullptr;
     uint32_t* d_len = nullptr;
     std::vector<uint32_t> len;
+    std::vector<uint8_t> codes;              // host copy (unpadded) for per-scorer bounds
+    std::vector<uint64_t> off;
     uint32_t max_len = 0;
+    mutable std::vector<uint64_t> score_bound;
+    mutable uint64_t bound_scorer = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -141,6 +150,12 @@ S4G_API int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_op
             s->mat32[a * 32 + b] = (int8_t)v;
             s->max_score = std::max(s->max_score, v);
         }
+    for (int a = 0; a < 32; ++a) {
+        s->row_max[a] = 0;
+        if (a < 26) for (int b = 0; b < 26; ++b) s->row_max[a] = std::max(s->row_max[a], s->table[a * 26 + b]);
+    }
+    static std::atomic<uint64_t> next_serial{1};
+    s->serial = next_serial.fetch_add(1);
     *out = s;
     return S4G_OK;
 }
@@ -224,7 +239,7 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
     if (!db) return S4G_OK;
     DeviceGuard guard(db->device);
     (void)hipFree(db->d_res); (void)hipFree(db->d_grp_off); (void)hipFree(db->d_grp_len4); (void)hipFree(db->d_grp_perm);
-    (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat);
+    (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat); (void)hipFree(db->d_qlist);
     delete db;
     return S4G_OK;
 }
@@ -259,6 +274,8 @@ S4G_API int s4g_queries_create(s4g_queries** out, int device, const uint8_t* cod
         off[i] = bytes;
         bytes += (l + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;
     }
+    q->off.assign(offsets, offsets + n + 1);
+    q->codes.assign(codes ? codes : (const uint8_t*)"", codes ? codes + offsets[n] : (const uint8_t*)"");
     std::vector<uint8_t> padded(bytes ? bytes : 1, (uint8_t)kPadCode);
     for (uint32_t i = 0; i < n; ++i)
         for (uint32_t j = 0; j < q->len[i]; ++j) {
@@ -300,31 +317,68 @@ S4G_API int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_be
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr int kStripRows = 32;
+constexpr int kStripRows = 32;      // sw_scan_i32
+constexpr int kStripRows16 = 32;    // sw_scan_i16x2
 
 struct Plan {
-    const char* name;
-    uint32_t grid, block, strip;
-    uint64_t ws_slot;   // int32 per wave slot
-    uint64_t ws_bytes;
+    std::vector<uint32_t> pairs;    // i16x2 work: 2 ids per pair (second may be ~0u)
+    std::vector<uint32_t> wide;     // i32 work: query ids whose score bound exceeds int16
+    uint32_t grid_i32 = 0, grid_i16 = 0;
+    uint64_t ws_slot = 0, ws_bytes = 0;
 };
 
-int make_plan(const s4g_db* db, Plan* p) {
-    if (db->grid_blocks == 0) {
+int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
+    if (*cache == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, db->device));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_scan_i32<kStripRows>, kBlock, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
         if (per_cu < 1) per_cu = 1;
-        db->grid_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        *cache = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
-    p->name = "sw_scan_i32<32>";
-    p->grid = db->grid_blocks;
-    p->block = kBlock;
-    p->strip = kStripRows;
-    p->ws_slot = 2ull * (db->max_len4 ? db->max_len4 : 1) * 64 * 4;
-    p->ws_bytes = p->ws_slot * 4 * p->grid * kWavesPerBlock;
     return S4G_OK;
+}
+
+// Which queries may run in packed int16: every reachable H is bounded by sum_i max(0, max_b M[q_i][b]) (each row of the
+// DP adds at most its best substitution score), so the kernel is exact when that bound fits in int16.
+int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* sc,
+              uint32_t flags, Plan* p) {
+    int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &db->grid_i32);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_i16x2<kStripRows16>, &db->grid_i16);
+    if (rc) return rc;
+    p->grid_i32 = db->grid_i32;
+    p->grid_i16 = db->grid_i16;
+    const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
+    std::vector<uint32_t> narrow;
+    for (uint32_t i = 0; i < q_count; ++i) {
+        const uint32_t id = q_begin + i;
+        const bool fits = q->score_bound[id] <= 32767 && gaps16 && !(flags & S4G_SCAN_FORCE_I32);
+        (fits ? narrow : p->wide).push_back(id);
+    }
+    // pair queries of similar length (the pair runs to the longer one); longest pairs first
+    std::stable_sort(narrow.begin(), narrow.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
+    for (size_t i = 0; i < narrow.size(); i += 2) {
+        p->pairs.push_back(narrow[i]);
+        p->pairs.push_back(i + 1 < narrow.size() ? narrow[i + 1] : 0xFFFFFFFFu);
+    }
+    const uint32_t grid = std::max(p->grid_i32, p->grid_i16);
+    p->ws_slot = 2ull * (db->max_len4 ? db->max_len4 : 1) * 64 * 4;
+    p->ws_bytes = p->ws_slot * 4 * grid * kWavesPerBlock;
+    return S4G_OK;
+}
+
+// per-query upper bound of any reachable score under this scorer (host, O(residues), cached per scorer)
+void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
+    if (q->bound_scorer == scorer->serial) return;
+    q->score_bound.assign(q->n, 0);
+    for (uint32_t i = 0; i < q->n; ++i) {
+        uint64_t b = 0;
+        const uint8_t* c = q->codes.data() + q->off[i];
+        for (uint32_t j = 0; j < q->len[i]; ++j) b += (uint64_t)scorer->row_max[c[j]];
+        q->score_bound[i] = b;
+    }
+    q->bound_scorer = scorer->serial;
 }
 
 int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStream_t stream) {
@@ -336,7 +390,18 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
     }
     if (!db->d_counter) HIP_TRY(hipMalloc((void**)&db->d_counter, 256));
     if (!db->d_mat) HIP_TRY(hipMalloc((void**)&db->d_mat, 1024));
+    const uint64_t need = p.pairs.size() + p.wide.size();
+    if (db->qlist_cap < need) {
+        if (db->d_qlist) HIP_TRY(hipFree(db->d_qlist));
+        db->d_qlist = nullptr; db->qlist_cap = 0;
+        HIP_TRY(hipMalloc((void**)&db->d_qlist, need * 4));
+        db->qlist_cap = need;
+    }
     HIP_TRY(hipMemcpyAsync(db->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
+    if (!p.pairs.empty())
+        HIP_TRY(hipMemcpyAsync(db->d_qlist, p.pairs.data(), p.pairs.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!p.wide.empty())
+        HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size(), p.wide.data(), p.wide.size() * 4, hipMemcpyHostToDevice, stream));
     return S4G_OK;
 }
 
@@ -348,19 +413,22 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     DeviceGuard guard(db->device);
     std::lock_guard<std::mutex> lk(db->mu);
+    ensure_bounds(q, scorer);
     Plan p;
-    int rc = make_plan(db, &p);
+    int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
     if (rc) return rc;
-    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", p.name);
-    if (grid_blocks) *grid_blocks = p.grid;
-    if (block_threads) *block_threads = p.block;
-    if (strip_rows) *strip_rows = p.strip;
+    const bool i16 = p.pairs.size() >= p.wide.size();       // report the kernel that carries most of the queries
+    if (kernel_name && kernel_name_cap)
+        snprintf(kernel_name, kernel_name_cap, "%s", i16 ? "sw_scan_i16x2<32>" : "sw_scan_i32<32>");
+    if (grid_blocks) *grid_blocks = i16 ? p.grid_i16 : p.grid_i32;
+    if (block_threads) *block_threads = kBlock;
+    if (strip_rows) *strip_rows = i16 ? kStripRows16 : kStripRows;
     if (workspace_bytes) *workspace_bytes = p.ws_bytes;
     return S4G_OK;
 }
 
-S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
-                     const s4g_scorer* scorer, int32_t* d_scores, void* stream_) {
+S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                           const s4g_scorer* scorer, int32_t* d_scores, void* stream_, uint32_t flags) {
     if (!db || !q || !scorer || (!d_scores && q_count && db->n_seqs)) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
     if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
@@ -369,28 +437,59 @@ S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, u
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
     std::lock_guard<std::mutex> lk(db->mu);
+    ensure_bounds(q, scorer);
     Plan p;
-    int rc = make_plan(db, &p);
+    int rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
     if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 4, stream));
-    ScanArgs a;
-    a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
-    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-    a.mat = db->d_mat;
-    a.scores = d_scores; a.score_stride = db->n_seqs;
-    a.ws = db->d_ws; a.ws_slot = p.ws_slot;
-    a.counter = db->d_counter;
-    a.n_groups = db->n_groups; a.q_begin = q_begin; a.q_count = q_count;
-    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-    hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(p.grid), dim3(p.block), 0, stream, a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 8, stream));
+    if (!p.pairs.empty()) {
+        ScanArgs16 a;
+        a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+        a.pairs = db->d_qlist;
+        a.mat = db->d_mat;
+        a.scores = d_scores; a.score_stride = db->n_seqs;
+        a.ws = db->d_ws; a.ws_slot = p.ws_slot;
+        a.counter = db->d_counter;
+        a.n_groups = db->n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i16x2<kStripRows16>, dim3(p.grid_i16), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!p.wide.empty()) {
+        ScanArgs a;
+        a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+        a.mat = db->d_mat;
+        a.scores = d_scores; a.score_stride = db->n_seqs;
+        a.ws = db->d_ws; a.ws_slot = p.ws_slot;
+        a.counter = db->d_counter + 1;
+        a.n_groups = db->n_groups; a.q_begin = q_begin; a.q_count = (uint32_t)p.wide.size();
+        a.q_list = db->d_qlist + p.pairs.size();
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(p.grid_i32), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
     return S4G_OK;
 }
 
+S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                     const s4g_scorer* scorer, int32_t* d_scores, void* stream) {
+    return s4g_scan_flags(db, q, q_begin, q_count, scorer, d_scores, stream, 0);
+}
+
+S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                                const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags);
+
 S4G_API int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
                           const s4g_scorer* scorer, int32_t* h_scores) {
+    return s4g_scan_host_flags(db, q, q_begin, q_count, scorer, h_scores, 0);
+}
+
+S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                                const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
     if (!h_scores) return fail(S4G_ERR_INVALID, "h_scores is NULL");
@@ -398,7 +497,7 @@ S4G_API int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     int32_t* d = nullptr;
     size_t bytes = (size_t)q_count * db->n_seqs * 4;
     HIP_TRY(hipMalloc((void**)&d, bytes));
-    int rc = s4g_scan(db, q, q_begin, q_count, scorer, d, nullptr);
+    int rc = s4g_scan_flags(db, q, q_begin, q_count, scorer, d, nullptr, flags);
     if (rc == S4G_OK) {
         hipError_t e = hipMemcpy(h_scores, d, bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(S4G_ERR_HIP, "score download failed: %s", hipGetErrorString(e));

@@ -52,7 +52,8 @@ struct ScanArgs {
     uint64_t ws_slot;                       // int32 elements per wave slot
     unsigned* counter;                      // work-queue head, zeroed before launch
     uint32_t n_groups;
-    uint32_t q_begin, q_count;
+    uint32_t q_begin, q_count;               // output row = query id - q_begin
+    const uint32_t* __restrict__ q_list;     // optional: the q_count query ids to score (NULL = q_begin .. q_begin+q_count)
     uint32_t open, ext;
 };
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
         if (item >= n_items) break;
         const unsigned g = item / a.q_count;
         const unsigned qi = item - g * a.q_count;
-        const unsigned q = a.q_begin + qi;
+        const unsigned q = a.q_list ? a.q_list[qi] : a.q_begin + qi;
         const unsigned len4 = a.grp_len4[g];
         const uint32_t* res = a.db_res + a.grp_off[g] + lane;
         const uint8_t* qc = a.q_codes + a.q_off[q];
@@ -194,7 +195,204 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
             }
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
-        if (p != 0xFFFFFFFFu) a.scores[(uint64_t)qi * a.score_stride + p] = best;
+        if (p != 0xFFFFFFFFu) a.scores[(uint64_t)(q - a.q_begin) * a.score_stride + p] = best;
+    }
+}
+
+
+// =====================================================================================================
+// Packed int16 x 2 kernel: the two halves of every 32-bit register carry two DIFFERENT QUERIES against the
+// same database sequence (lane).  v_pk_add_u16 / v_pk_max_i16 / v_pk_sub_u16 clamp update both cells per
+// instruction: 9 VALU ops per pair of cells = 4.5 per cell (no packed max3 exists, so H costs add+max+max and the
+// running maximum one max per row).  Exact by construction when every reachable score fits in int16: the host only
+// routes queries here whose upper bound  sum_i max_b M[q_i][b]  is <= 32767 (ScanArgs16 contract); everything else
+// goes to sw_scan_i32.  Scores are widened to int32 on output.
+//
+// Strip profile (wave-private LDS): prof[kk][t][4 rows] of packed (sB << 16 | sA) int16 pairs, 16 B per (kk, t):
+// one ds_read_b128 per lane per 4 rows.  Strip boundary rows (H, F of the strip's last row) are packed pairs too:
+// 16 B per lane per 4 columns each way for 2 x R cells -> half the HBM bytes per cell of the int32 kernel.
+// The last strip of a query pair runs a variant with only as many rows (multiple of 8) as it needs.
+// =====================================================================================================
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+struct ScanArgs16 {
+    const uint32_t* __restrict__ db_res;
+    const uint64_t* __restrict__ grp_off;
+    const uint32_t* __restrict__ grp_len4;
+    const uint32_t* __restrict__ grp_perm;
+    const uint8_t* __restrict__ q_codes;
+    const uint64_t* __restrict__ q_off;
+    const uint32_t* __restrict__ q_len;
+    const uint32_t* __restrict__ pairs;     // [2 * n_pairs] query ids (absolute); second may be ~0u (no partner)
+    const int8_t* __restrict__ mat;
+    int32_t* __restrict__ scores;
+    uint64_t score_stride;
+    int32_t* __restrict__ ws;
+    uint64_t ws_slot;
+    unsigned* counter;
+    uint32_t n_groups, n_pairs, q_begin;
+    uint32_t open, ext;                      // each < 2^15
+};
+
+__device__ __forceinline__ v2s as_s(v2us x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ v2us as_u(v2s x) { return __builtin_bit_cast(v2us, x); }
+__device__ __forceinline__ v2s as_s(int x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ v2us as_u(int x) { return __builtin_bit_cast(v2us, x); }
+__device__ __forceinline__ int as_i(v2s x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int as_i(v2us x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2us pk_subs(v2us a, v2us b) { return __builtin_elementwise_sub_sat(a, b); }
+
+// 8 rows (row0 .. row0+7) of one column; sc = their 8 packed score pairs
+template <int R>
+__device__ __forceinline__ void pk_rows8(v2s (&H)[R], v2us (&E)[R], int row0, const v4i (&sc)[2], v2s& diag, v2us& F,
+                                         v2s& best, v2us open, v2us ext) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + i;
+        const v2s s = as_s(sc[i / 4][i % 4]);
+        v2s h = pk_max(pk_max(diag + s, as_s(E[r])), as_s(F));
+        best = pk_max(best, h);
+        const v2us hm = pk_subs(as_u(h), open);
+        E[r] = as_u(pk_max(as_s(pk_subs(E[r], ext)), as_s(hm)));
+        F = as_u(pk_max(as_s(pk_subs(F, ext)), as_s(hm)));
+        diag = H[r];
+        H[r] = h;
+    }
+}
+
+__device__ __forceinline__ void pk_load8(v4i (&sc)[2], const char* prof, unsigned taddr, int blk) {
+    sc[0] = *reinterpret_cast<const v4i*>(prof + (2 * blk) * 512 + taddr);
+    sc[1] = *reinterpret_cast<const v4i*>(prof + (2 * blk + 1) * 512 + taddr);
+}
+
+__device__ __forceinline__ unsigned pk_taddr(uint32_t r4, int cc) {
+    return (cc == 0 ? (r4 << 4) : (r4 >> (8 * cc - 4))) & 0x1F0u;
+}
+
+// One strip of RR rows (RR multiple of 8) over all columns of the group.
+template <int R, int RR>
+__device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+                                         bool first, bool last, v2s& best, v2us open, v2us ext) {
+    constexpr int NB = RR / 8;
+    v2s H[R];
+    v2us E[R];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) { H[r] = as_s(0); E[r] = as_u(0); }
+    v2s hdiag = as_s(0);
+    uint32_t res_n = res[0];
+    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+    if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+    v4i sc_n[2];
+    pk_load8(sc_n, prof, pk_taddr(res_n, 0), 0);
+    for (unsigned c = 0; c < len4; ++c) {
+        const uint32_t r4 = res_n;
+        const v4i hb = hb_n, fb = fb_n;
+        const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+        res_n = res[(uint64_t)cn * 64];
+        if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+        v4i ho, fo;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const unsigned taddr = pk_taddr(r4, cc);
+            const unsigned taddr_next = cc < 3 ? pk_taddr(r4, cc + 1) : pk_taddr(res_n, 0);
+            v2s diag = hdiag;
+            v2us F = as_u(fb[cc]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                v4i sc[2] = {sc_n[0], sc_n[1]};
+                if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
+                pk_rows8<R>(H, E, 8 * b, sc, diag, F, best, open, ext);
+            }
+            hdiag = as_s(hb[cc]);
+            ho[cc] = as_i(H[RR - 1]);
+            fo[cc] = as_i(F);
+            asm volatile("" : "+v"(best));          // pin the running maximum per column (see sw_scan_i32)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
+    static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 128);
+
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const unsigned n_items = a.n_groups * a.n_pairs;
+    const v2us open = as_u((int)(a.open | (a.open << 16)));
+    const v2us ext = as_u((int)(a.ext | (a.ext << 16)));
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const unsigned g = item / a.n_pairs;
+        const unsigned pi = item - g * a.n_pairs;
+        const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
+        const bool hasB = qB != 0xFFFFFFFFu;
+        const unsigned len4 = a.grp_len4[g];
+        const uint32_t* res = a.db_res + a.grp_off[g] + lane;
+        const uint8_t* qcA = a.q_codes + a.q_off[qA];
+        const uint8_t* qcB = a.q_codes + a.q_off[hasB ? qB : qA];
+        const unsigned lA = a.q_len[qA], lB = hasB ? a.q_len[qB] : 0u;
+        const unsigned capA = (lA + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;   // readable bytes
+        const unsigned capB = hasB ? (lB + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign : 0u;
+        const unsigned lq = lA > lB ? lA : lB;
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        v2s best = as_s(0);
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            const unsigned rows_left = lq - s * R;
+            const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;   // rows this strip computes
+            // ---- strip profile: prof[kk][t] = 4 rows of (sB << 16 | sA) ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 8 * R; e0 += 64) {
+                const int e = e0 + lane;
+                const int kk = e >> 5, t = e & 31;
+                const unsigned row0 = s * R + 4 * kk;
+                const unsigned cA = row0 < capA ? *reinterpret_cast<const unsigned*>(qcA + row0) : 0x1F1F1F1Fu;
+                const unsigned cB = row0 < capB ? *reinterpret_cast<const unsigned*>(qcB + row0) : 0x1F1F1F1Fu;
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int sA = lmat[((cA >> (8 * d)) & 31u) * 32 + t];
+                    const int sB = lmat[((cB >> (8 * d)) & 31u) * 32 + t];
+                    out[d] = (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16));
+                }
+                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+            bool done = false;
+#define S4G_LAST_STRIP(RR_)                                                                                  \
+            if constexpr (R > RR_) {                                                                         \
+                if (!done && rr == RR_) { pk_strip<R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext); done = true; } \
+            }
+            S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
+#undef S4G_LAST_STRIP
+            if (!done) pk_strip<R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext);   // full strip (or rr > 40)
+        }
+        const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
+        if (p != 0xFFFFFFFFu) {
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = (int)best[0];
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = (int)best[1];
+        }
     }
 }
 

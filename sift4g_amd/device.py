@@ -107,7 +107,7 @@ def scan_plan(db, queries, scorer):
                 workspace_bytes=w.value)
 
 
-def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None):
+def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i32=False):
     """Asynchronous scan into a device tensor `out` (torch int32 [q_count, n_seqs], on db.device).
 
     stream: a torch.cuda.Stream (default: torch's current stream on that device)."""
@@ -117,16 +117,17 @@ def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None):
         raise ValueError("out must be a contiguous CUDA int32 tensor of at least q_count*n_seqs elements")
     if stream is None:
         stream = torch.cuda.current_stream(out.device)
-    check(lib.s4g_scan(db._h, queries._h, q_begin, q_count, scorer._h, ctypes.c_void_p(out.data_ptr()),
-                       ctypes.c_void_p(stream.cuda_stream)), "s4g_scan")
+    check(lib.s4g_scan_flags(db._h, queries._h, q_begin, q_count, scorer._h, ctypes.c_void_p(out.data_ptr()),
+                             ctypes.c_void_p(stream.cuda_stream), _lib.S4G_SCAN_FORCE_I32 if force_i32 else 0), "s4g_scan_flags")
     return out
 
 
-def scan_host(db, queries, scorer, q_begin=0, q_count=None):
+def scan_host(db, queries, scorer, q_begin=0, q_count=None, force_i32=False):
     """Synchronous scan -> numpy int32 [q_count, n_seqs]."""
     q_count = queries.n - q_begin if q_count is None else q_count
     out = np.zeros((q_count, db.n), dtype=np.int32)
-    check(lib.s4g_scan_host(db._h, queries._h, q_begin, q_count, scorer._h, _ptr(out, c_i32p)), "s4g_scan_host")
+    check(lib.s4g_scan_host_flags(db._h, queries._h, q_begin, q_count, scorer._h, _ptr(out, c_i32p),
+                                  _lib.S4G_SCAN_FORCE_I32 if force_i32 else 0), "s4g_scan_host_flags")
     return out
 
 

@@ -22,10 +22,12 @@ def scorer(s4g):
 def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8):
     db = s4g.Database(targets)
     qs = s4g.QuerySet(queries)
-    got = s4g.scan_host(db, qs, scorer)
     exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
-    bad = np.argwhere(got != exp)
-    assert bad.size == 0, f"{len(bad)} mismatches, first {bad[:5].tolist()} got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}"
+    for force_i32 in (False, True):       # default plan (packed int16x2 where exact, int32 otherwise) and the int32 kernel alone
+        got = s4g.scan_host(db, qs, scorer, force_i32=force_i32)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (f"force_i32={force_i32}: {len(bad)} mismatches, first {bad[:5].tolist()} "
+                               f"got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}")
     return got
 
 
@@ -116,6 +118,28 @@ def test_other_gap_penalties(s4g, oracle_mod, blosum62, go, ge):
     qs = rand_seqs(rng, 6, 30, 200)
     ts = rand_seqs(rng, 100, 10, 250) + [np.concatenate([qs[0][:60], qs[0][70:]])]
     _check(s4g, oracle_mod, blosum62, qs, ts, sc, go, ge)
+
+
+def test_int16_bound_routing(s4g, oracle_mod, blosum62, scorer):
+    """queries whose score bound exceeds int16 must leave the packed kernel: W-rich long queries (11 per residue)
+    mixed with ordinary ones, against targets that actually reach > 32767."""
+    rng = np.random.default_rng(25)
+    W = ord("W") - 65
+    long_w = np.full(3300, W, dtype=np.uint8)                 # bound 36300 > 32767 -> int32 kernel
+    edge_w = np.full(2978, W, dtype=np.uint8)                 # bound 32758 <= 32767 -> packed kernel, score at the edge
+    qs = [long_w, edge_w] + rand_seqs(rng, 5, 100, 400)
+    ts = [np.full(3400, W, dtype=np.uint8), np.full(2978, W, dtype=np.uint8)] + rand_seqs(rng, 70, 50, 500)
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert got[0, 0] == 3300 * 11 and got[1, 0] == 2978 * 11 == 32758 and got[1, 1] == 32758
+
+
+def test_odd_query_counts_and_unequal_pairs(s4g, oracle_mod, blosum62, scorer):
+    """packed kernel pairs queries of similar length: odd counts, a lone query, very unequal partners."""
+    rng = np.random.default_rng(26)
+    ts = rand_seqs(rng, 200, 5, 300)
+    for lens in ([77], [10, 700], [33, 34, 35], [1, 2, 3, 250, 251], [64, 64, 64, 64, 64, 64, 65]):
+        qs = [rand_seqs(rng, 1, l, l)[0] for l in lens]
+        _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
 
 
 def test_custom_matrix(s4g, oracle_mod):

@@ -29,6 +29,13 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned a0, unsigned b0
             if (OP == 7) x = x + (unsigned)(int)(signed char)(b0 >> 8);                    // SDWA add (sext byte)
             if (OP == 8) x = __builtin_amdgcn_perm(x, b0, 0x07020500u + i);                // v_perm_b32
             if (OP == 9) x = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x) + __builtin_bit_cast(float, b0));  // v_add_f32
+            if (OP == 10) x = __builtin_bit_cast(unsigned, __builtin_fmaf(__builtin_bit_cast(float, x), 1.0001f, __builtin_bit_cast(float, b0)));  // v_fma_f32
+            if (OP == 11) x = __builtin_bit_cast(unsigned, __builtin_fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, b0 + i)));       // v_max_f32
+            if (OP == 12) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); h2 p = __builtin_bit_cast(h2, x), q = __builtin_bit_cast(h2, b0); p = p + q; x = __builtin_bit_cast(unsigned, p); }  // v_pk_add_f16
+            if (OP == 13) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); h2 p = __builtin_bit_cast(h2, x), q = __builtin_bit_cast(h2, b0 + i); p = __builtin_elementwise_max(p, q); x = __builtin_bit_cast(unsigned, p); }  // v_pk_max_f16
+            if (OP == 14) { asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
+            if (OP == 15) { asm volatile("v_maximum3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
+            if (OP == 16) { asm volatile("v_max3_i16 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
             asm volatile("" : "+v"(x));
             v[c] = x;
         }
@@ -62,10 +69,12 @@ int run(const char* name, int blocks_per_cu) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {2, 8}) {
         run<0>("v_add_u32", w); run<1>("v_max_i32", w); run<2>("v_max3_i32", w); run<3>("v_sub_u32 clamp", w);
         run<4>("v_pk_add_i16", w); run<5>("v_pk_max_i16", w); run<6>("v_pk_sub_u16 clamp", w);
         run<7>("v_add_u32 sdwa", w); run<8>("v_perm_b32", w); run<9>("v_add_f32", w);
+        run<10>("v_fma_f32", w); run<11>("v_max_f32", w); run<12>("v_pk_add_f16", w); run<13>("v_pk_max_f16", w);
+        run<14>("v_pk_maximum3_f16", w); run<15>("v_maximum3_f32", w); run<16>("v_max3_i16", w);
         printf("\n");
     }
     return 0;
