@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=1000, help="queries per GPU")
     ap.add_argument("--targets", type=int, default=100000)
+    ap.add_argument("--qlen", type=int, nargs=2, default=[300, 400], help="query length range (configs[4]: 2000 5000)")
+    ap.add_argument("--force-i32", action="store_true", help="run every query through the int32 kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,20 +87,29 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload: identical generator on every rank; DB replicated, queries sharded ----
-    cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets)
+    t_gen = time.perf_counter()
+    cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen))
+    t_up = time.perf_counter()
     db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"], device=local_rank)
     allq = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"], device=local_rank)
+    torch.cuda.synchronize()
+    t_ready = time.perf_counter()
+    if rank == 0:
+        print(f"bench.py: generate {t_up - t_gen:.1f} s; pack+upload DB ({int(cfg['t_off'][-1])} residues) and queries "
+              f"{t_ready - t_up:.2f} s (host packing + PCIe, outside the timed region)", file=sys.stderr)
     q_begin, q_count = rank * args.queries, args.queries
     scorer = s4g.Scorer("BLOSUM_62", 10, 1)
     cells_rank = scan_cells(db, allq, q_begin, q_count)
     plan = scan_plan(db, allq, scorer)
+    if args.force_i32:
+        plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
     scores = torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count)
+        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32)
         if i is not None:
             ev[i][1].record()
         ids, sc, cnt = s4g.topk_device(db, scores, TOPK, 1)                     # steps 2-3 on the device
@@ -145,7 +156,7 @@ def main():
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16" if "i16" in plan["kernel"] else "int32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.queries} synthetic queries/GPU len U[300,400] x "
+            "config": {"workload": f"BASELINE configs[1] generator: {args.queries} synthetic queries/GPU len U[{args.qlen[0]},{args.qlen[1]}] x "
                                    f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
                                    f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",
                        "cells_per_step": cells_total, "parallelism": f"query-shard x{world}, DB replicated",

@@ -36,6 +36,17 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned a0, unsigned b0
             if (OP == 14) { asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
             if (OP == 15) { asm volatile("v_maximum3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
             if (OP == 16) { asm volatile("v_max3_i16 %0, %0, %1, %2" : "+v"(x) : "v"(b0 + i), "v"(a0)); }
+            if (OP == 17) { asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(x) : "v"(0x3c003c00u), "v"(b0)); }
+            if (OP == 18) { asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(x) : "v"(0x00010001u), "v"(b0)); }
+            if (OP == 19) { asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(x) : "v"(1u), "v"(b0)); }
+            if (OP == 20) { asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(x) : "v"(0x3c00u), "v"(b0)); }
+            if (OP == 21) { asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(1u), "v"(b0)); }
+            if (OP == 22) { asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(0x00010001u)); }
+            if (OP == 23) { asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x) : "v"(b0)); }
+            if (OP == 24) { asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b0), "v"(a0)); }
+            if (OP == 25) { asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(x) : "v"(b0)); }
+            if (OP == 26) { asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x) : "v"(b0)); }
+            if (OP == 27) { asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(x) : "v"(b0), "v"(a0)); }
             asm volatile("" : "+v"(x));
             v[c] = x;
         }
@@ -69,12 +80,15 @@ int run(const char* name, int blocks_per_cu) {
 }
 
 int main() {
-    for (int w : {2, 8}) {
+    for (int w : {3, 8}) {
         run<0>("v_add_u32", w); run<1>("v_max_i32", w); run<2>("v_max3_i32", w); run<3>("v_sub_u32 clamp", w);
         run<4>("v_pk_add_i16", w); run<5>("v_pk_max_i16", w); run<6>("v_pk_sub_u16 clamp", w);
         run<7>("v_add_u32 sdwa", w); run<8>("v_perm_b32", w); run<9>("v_add_f32", w);
         run<10>("v_fma_f32", w); run<11>("v_max_f32", w); run<12>("v_pk_add_f16", w); run<13>("v_pk_max_f16", w);
         run<14>("v_pk_maximum3_f16", w); run<15>("v_maximum3_f32", w); run<16>("v_max3_i16", w);
+        run<17>("v_pk_fma_f16", w); run<18>("v_pk_mad_i16", w); run<19>("v_mad_i32_i24", w); run<20>("v_fma_f16", w);
+        run<21>("v_mad_u32_u24", w); run<22>("v_pk_mul_lo_u16", w); run<23>("v_pk_add_f16 asm", w); run<24>("v_add3_u32", w);
+        run<25>("v_pk_max_i16 asm", w); run<26>("v_pk_min_i16 asm", w); run<27>("v_med3_i32", w);
         printf("\n");
     }
     return 0;
