@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_destroy
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_destroy / s4g_db_info / s4g_db_tiles
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -34,7 +34,7 @@
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
  *       (s4g_score_lists_host = the per-query candidate lists built by
  *       createFilteredDatabase, database_alignment.cpp:136-162)
- *   s4g_topk / s4g_topk_host
+ *   s4g_topk / s4g_topk_host / s4g_scan_topk
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
  *       and the merge semantics of dbAlignmentsMerge (:101-102)
@@ -87,7 +87,13 @@ int s4g_scorer_destroy(s4g_scorer* s);
 /* Upload a database to `device`.  codes[offsets[i] .. offsets[i+1]) are the
  * residue codes of target i.  Host buffers may be freed on return. */
 int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs);
+/* Same with an explicit tile size (sequences per tile, 0 = default 2^20).  The database is always stored as tiles of
+ * the length-sorted order; tiles bound the strip-boundary workspace and the s4g_scan_topk score buffer. */
+int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
+                        uint32_t max_tile_seqs);
 int s4g_db_destroy(s4g_db* db);
+/* number of tiles and (optionally, up to cap entries) sequences per tile */
+int s4g_db_tiles(const s4g_db* db, uint32_t* n_tiles, uint32_t* tile_seqs, uint32_t cap);
 /* any out pointer may be NULL */
 int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, uint64_t* padded_residues, uint64_t* hbm_bytes);
 
@@ -132,6 +138,13 @@ int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t*
  * form the multi-GPU gather consumes.  s4g_topk_host: results in host memory. */
 int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
              uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts, void* stream);
+/* Streaming scan + running top-k for databases whose q_count x n_seqs score matrix does not fit (BASELINE
+ * configs[3]): queries [q_begin, q_begin+q_count) against every tile of the database, keeping only the exact
+ * per-query top-k (same order and tie rule as s4g_topk on the full matrix).  Outputs are DEVICE pointers
+ * [q_count][k] / [q_count]; asynchronous on `stream`; flags as s4g_scan_flags. */
+int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                  uint32_t k, int32_t min_score, uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts,
+                  void* stream, uint32_t flags);
 int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
                   uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream);
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     "s4g_scorer_create": (ctypes.c_int, [c_vpp, c_i32p, ctypes.c_int, ctypes.c_int]),
     "s4g_scorer_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "s4g_db_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32]),
+    "s4g_db_create_tiled": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_uint32]),
+    "s4g_db_tiles": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.c_uint32]),
     "s4g_db_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "s4g_db_info": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, c_u64p, c_u64p]),
     "s4g_queries_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32]),
@@ -50,6 +52,9 @@ SIGNATURES = {
     "s4g_score_lists_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u32p, ctypes.c_void_p, c_i32p]),
     "s4g_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s4g_scan_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                     ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_uint32]),
     "s4g_topk_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                      c_u32p, c_i32p, c_u32p, ctypes.c_void_p]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace s4g;
@@ -69,16 +70,26 @@ struct s4g_scorer {
     uint64_t serial;        // identity for caches keyed on the scorer
 };
 
-struct s4g_db {
-    int device = 0;
+// A tile = a slice of the length-sorted database that is scanned by one launch (per kernel).  Tiles keep the
+// strip-boundary workspace bounded (it scales with the tile's longest sequence) and let huge databases stream
+// through a bounded score buffer (s4g_scan_topk).  Small databases are a single tile.
+struct Tile {
     uint32_t n_seqs = 0, n_groups = 0, max_len4 = 0;
-    uint64_t residues = 0, padded_residues = 0, hbm_bytes = 0;
-    uint32_t* d_res = nullptr;
+    uint64_t residues = 0, padded_residues = 0;
+    uint32_t* d_res = nullptr;          // lane-transposed residues
     uint64_t* d_grp_off = nullptr;
     uint32_t* d_grp_len4 = nullptr;
-    uint32_t* d_grp_perm = nullptr;
-    std::vector<uint32_t> order;   // sorted position -> original index
-    std::vector<uint32_t> rank;    // original index -> sorted position
+    uint32_t* d_perm_global = nullptr;  // [G*64] original target id of (g, lane); ~0u = empty lane
+    uint32_t* d_perm_local = nullptr;   // [G*64] column in the tile's own score buffer = rank of the id inside the tile
+    uint32_t* d_col_ids = nullptr;      // [n_seqs] tile column -> original target id (ascending)
+};
+
+struct s4g_db {
+    int device = 0;
+    uint32_t n_seqs = 0;
+    uint64_t residues = 0, padded_residues = 0, hbm_bytes = 0;
+    uint32_t max_tile_seqs = 0;
+    std::vector<Tile> tiles;
     std::vector<uint32_t> len;     // original index -> length
     // per-device scratch, created lazily and reused (scan calls on one db are serialized)
     mutable std::mutex mu;
@@ -88,6 +99,8 @@ struct s4g_db {
     mutable int8_t* d_mat = nullptr;
     mutable uint32_t* d_qlist = nullptr;     // query-id lists of the current launch (pairs for i16x2, singles for i32)
     mutable uint64_t qlist_cap = 0;
+    mutable int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
+    mutable uint64_t tile_scores_bytes = 0;
     mutable uint32_t grid_i32 = 0, grid_i16 = 0;
 };
 
@@ -163,11 +176,95 @@ S4G_API int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_op
 S4G_API int s4g_scorer_destroy(s4g_scorer* s) { delete s; return S4G_OK; }
 
 // ---------------------------------------------------------------------------
-S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs) {
+namespace {
+
+constexpr uint32_t kTileMaxSeqs = 1u << 20;            // sequences per tile
+constexpr uint64_t kTileMaxResidues = 1ull << 30;      // padded residues per tile
+constexpr uint32_t kLongSeq = 4096;                    // sequences longer than this get tiles of their own
+
+void free_tile(Tile& t) {
+    (void)hipFree(t.d_res); (void)hipFree(t.d_grp_off); (void)hipFree(t.d_grp_len4);
+    (void)hipFree(t.d_perm_global); (void)hipFree(t.d_perm_local); (void)hipFree(t.d_col_ids);
+    t = Tile();
+}
+
+// Packs order[p0, p1) (length-sorted, longest first) into one tile and uploads it.
+hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, size_t p0, size_t p1,
+                      const uint8_t* codes, const uint64_t* offsets, std::string* err) {
+    const uint32_t n = (uint32_t)(p1 - p0);
+    const uint32_t G = (n + 63) / 64;
+    t.n_seqs = n; t.n_groups = G;
+    std::vector<uint64_t> grp_off(G);
+    std::vector<uint32_t> grp_len4(G);
+    uint64_t dwords = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t lg = db->len[order[p0 + (size_t)g * 64]];
+        grp_len4[g] = (lg + 3) / 4;
+        grp_off[g] = dwords;
+        dwords += (uint64_t)grp_len4[g] * 64;
+        t.max_len4 = std::max(t.max_len4, grp_len4[g]);
+    }
+    t.padded_residues = dwords * 4;
+    // tile column of a sequence = rank of its original id inside the tile (ties in top-k break by id)
+    std::vector<uint32_t> col_ids(order.begin() + p0, order.begin() + p1);
+    std::sort(col_ids.begin(), col_ids.end());
+    std::vector<uint32_t> perm_g((size_t)G * 64, 0xFFFFFFFFu), perm_l((size_t)G * 64, 0xFFFFFFFFu);
+    std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
+    std::atomic<bool> bad{false};
+    auto pack = [&](uint32_t g0, uint32_t g1) {
+        for (uint32_t g = g0; g < g1; ++g) {
+            uint8_t* base = reinterpret_cast<uint8_t*>(res.data() + grp_off[g]);
+            const uint32_t lanes = std::min<uint32_t>(64, n - g * 64);
+            for (uint32_t lane = 0; lane < lanes; ++lane) {
+                const uint32_t id = order[p0 + (size_t)g * 64 + lane];
+                perm_g[(size_t)g * 64 + lane] = id;
+                perm_l[(size_t)g * 64 + lane] = (uint32_t)(std::lower_bound(col_ids.begin(), col_ids.end(), id) - col_ids.begin());
+                const uint8_t* src = codes + offsets[id];
+                const uint32_t l = db->len[id];
+                for (uint32_t j = 0; j < l; ++j) {
+                    const uint8_t c = src[j];
+                    if (c >= 26) { bad = true; return; }
+                    base[((size_t)(j >> 2) * 64 + lane) * 4 + (j & 3)] = c;
+                }
+            }
+        }
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nthreads = dwords > (1u << 22) ? hw : 1;
+    if (nthreads == 1) pack(0, G);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nthreads; ++k) th.emplace_back(pack, (uint32_t)((uint64_t)G * k / nthreads), (uint32_t)((uint64_t)G * (k + 1) / nthreads));
+        for (auto& x : th) x.join();
+    }
+    if (bad) { *err = "residue code out of range (codes must be letter - 'A', 0..25)"; return hipErrorInvalidValue; }
+    for (size_t p = p0; p < p1; ++p) t.residues += db->len[order[p]];
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e != hipSuccess) return e;
+        db->hbm_bytes += bytes;
+        return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    hipError_t e;
+    if ((e = up((void**)&t.d_res, res.data(), dwords * 4)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_perm_global, perm_g.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_perm_local, perm_l.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_col_ids, col_ids.data(), (size_t)n * 4)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+}  // namespace
+
+S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
+                                uint32_t max_tile_seqs) {
     if (!out || !offsets || (!codes && n_seqs && offsets[n_seqs])) return fail(S4G_ERR_INVALID, "NULL argument");
     int have = device_count_raw();
     if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
     if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    if (max_tile_seqs == 0) max_tile_seqs = kTileMaxSeqs;
+    max_tile_seqs = (max_tile_seqs + 63) / 64 * 64;
     DeviceGuard guard(device);
 
     s4g_db* db = new s4g_db();
@@ -178,68 +275,57 @@ S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const 
         uint64_t l = offsets[i + 1] - offsets[i];
         if (offsets[i + 1] < offsets[i] || l > 0x7FFFFFF0ull) { delete db; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
         db->len[i] = (uint32_t)l;
-        db->residues += l;
     }
-    // length sort, longest first (ties by original index): items are issued in
-    // this order so the longest work runs first and the tail is short work.
-    db->order.resize(n_seqs);
-    std::iota(db->order.begin(), db->order.end(), 0u);
-    std::stable_sort(db->order.begin(), db->order.end(),
-                     [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
-    db->rank.resize(n_seqs);
-    for (uint32_t p = 0; p < n_seqs; ++p) db->rank[db->order[p]] = p;
+    // length sort, longest first (ties by original index): items are issued in this order so the longest
+    // work runs first and the tail of every launch is short work.
+    std::vector<uint32_t> order(n_seqs);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
 
-    const uint32_t G = (n_seqs + 63) / 64;
-    db->n_groups = G;
-    std::vector<uint64_t> grp_off(G);
-    std::vector<uint32_t> grp_len4(G);
-    std::vector<uint32_t> perm((size_t)G * 64, 0xFFFFFFFFu);
-    uint64_t dwords = 0;
-    for (uint32_t g = 0; g < G; ++g) {
-        uint32_t lg = db->len[db->order[(size_t)g * 64]];
-        grp_len4[g] = (lg + 3) / 4;
-        grp_off[g] = dwords;
-        dwords += (uint64_t)grp_len4[g] * 64;
-        db->max_len4 = std::max(db->max_len4, grp_len4[g]);
-    }
-    db->padded_residues = dwords * 4;
-    std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
-    for (uint32_t p = 0; p < n_seqs; ++p) {
-        const uint32_t g = p >> 6, lane = p & 63, id = db->order[p];
-        perm[p] = id;
-        const uint8_t* src = codes + offsets[id];
-        const uint32_t l = db->len[id];
-        uint8_t* base = reinterpret_cast<uint8_t*>(res.data() + grp_off[g]);
-        for (uint32_t j = 0; j < l; ++j) {
-            uint8_t c = src[j];
-            if (c >= 26) { delete db; return fail(S4G_ERR_INVALID, "residue code %u out of range in target %u", c, id); }
-            base[((size_t)(j >> 2) * 64 + lane) * 4 + (j & 3)] = c;
+    // cut the sorted order into tiles: by count, by padded residues, and at the long-sequence threshold
+    size_t p = 0;
+    while (p < n_seqs) {
+        size_t q = p;
+        uint64_t padded = 0;
+        const bool long_class = db->len[order[p]] > kLongSeq;
+        while (q < n_seqs && (q - p) < max_tile_seqs) {
+            const uint32_t l = db->len[order[q]];
+            if (long_class != (l > kLongSeq)) break;     // long sequences get tiles of their own (partial last group is fine)
+            if (((q - p) % 64) == 0) {
+                const uint64_t add = (uint64_t)((l + 3) / 4 * 4) * 64;     // this group's padded residues
+                if (q > p && padded + add > kTileMaxResidues) break;
+                padded += add;
+            }
+            ++q;
         }
-    }
-    auto cleanup = [&]() { s4g_db_destroy(db); };
-    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
-        if (e != hipSuccess) return e;
-        db->hbm_bytes += bytes;
-        return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
-    };
-    hipError_t e;
-    if ((e = up((void**)&db->d_res, res.data(), dwords * 4)) != hipSuccess ||
-        (e = up((void**)&db->d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess ||
-        (e = up((void**)&db->d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess ||
-        (e = up((void**)&db->d_grp_perm, perm.data(), (size_t)G * 64 * 4)) != hipSuccess) {
-        cleanup();
-        return fail(S4G_ERR_HIP, "database upload failed: %s", hipGetErrorString(e));
+        db->tiles.emplace_back();
+        std::string err;
+        hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err);
+        if (e != hipSuccess) {
+            std::string msg = err.empty() ? std::string(hipGetErrorString(e)) : err;
+            s4g_db_destroy(db);
+            return fail(err.empty() ? S4G_ERR_HIP : S4G_ERR_INVALID, "database upload failed: %s", msg.c_str());
+        }
+        const Tile& t = db->tiles.back();
+        db->residues += t.residues;
+        db->padded_residues += t.padded_residues;
+        db->max_tile_seqs = std::max(db->max_tile_seqs, t.n_seqs);
+        p = q;
     }
     *out = db;
     return S4G_OK;
 }
 
+S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs) {
+    return s4g_db_create_tiled(out, device, codes, offsets, n_seqs, 0);
+}
+
 S4G_API int s4g_db_destroy(s4g_db* db) {
     if (!db) return S4G_OK;
     DeviceGuard guard(db->device);
-    (void)hipFree(db->d_res); (void)hipFree(db->d_grp_off); (void)hipFree(db->d_grp_len4); (void)hipFree(db->d_grp_perm);
+    for (Tile& t : db->tiles) free_tile(t);
     (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat); (void)hipFree(db->d_qlist);
+    (void)hipFree(db->d_tile_scores);
     delete db;
     return S4G_OK;
 }
@@ -249,7 +335,14 @@ S4G_API int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, 
     if (n_seqs) *n_seqs = db->n_seqs;
     if (residues) *residues = db->residues;
     if (padded_residues) *padded_residues = db->padded_residues;
-    if (hbm_bytes) *hbm_bytes = db->hbm_bytes + db->ws_bytes;
+    if (hbm_bytes) *hbm_bytes = db->hbm_bytes + db->ws_bytes + db->tile_scores_bytes;
+    return S4G_OK;
+}
+
+S4G_API int s4g_db_tiles(const s4g_db* db, uint32_t* n_tiles, uint32_t* tile_seqs, uint32_t cap) {
+    if (!db || !n_tiles) return fail(S4G_ERR_INVALID, "NULL argument");
+    *n_tiles = (uint32_t)db->tiles.size();
+    if (tile_seqs) for (uint32_t i = 0; i < cap && i < db->tiles.size(); ++i) tile_seqs[i] = db->tiles[i].n_seqs;
     return S4G_OK;
 }
 
@@ -319,12 +412,14 @@ namespace {
 
 constexpr int kStripRows = 32;      // sw_scan_i32
 constexpr int kStripRows16 = 32;    // sw_scan_i16x2
+constexpr uint64_t kWorkspaceBudget = 24ull << 30;   // strip-boundary workspace cap; long-sequence tiles run on a smaller grid
+constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of the [query batch][tile columns] buffer
 
 struct Plan {
     std::vector<uint32_t> pairs;    // i16x2 work: 2 ids per pair (second may be ~0u)
     std::vector<uint32_t> wide;     // i32 work: query ids whose score bound exceeds int16
-    uint32_t grid_i32 = 0, grid_i16 = 0;
-    uint64_t ws_slot = 0, ws_bytes = 0;
+    uint32_t grid_i32 = 0, grid_i16 = 0;   // full persistent grids
+    uint64_t ws_bytes = 0;                 // workspace needed for the largest tile launch
 };
 
 int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
@@ -337,6 +432,29 @@ int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
         *cache = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
     return S4G_OK;
+}
+
+inline uint64_t ws_slot_elems(const Tile& t) { return 2ull * (t.max_len4 ? t.max_len4 : 1) * 64 * 4; }   // int32 per wave slot
+
+// grid of a tile launch: the full persistent grid unless the tile's sequences are so long that the per-wave
+// strip-boundary workspace would exceed the budget
+inline uint32_t tile_grid(const Tile& t, uint32_t full_grid) {
+    const uint64_t per_block = ws_slot_elems(t) * 4 * kWavesPerBlock;
+    const uint64_t fit = kWorkspaceBudget / per_block;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, fit));
+}
+
+// per-query upper bound of any reachable score under this scorer (host, O(residues), cached per scorer)
+void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
+    if (q->bound_scorer == scorer->serial) return;
+    q->score_bound.assign(q->n, 0);
+    for (uint32_t i = 0; i < q->n; ++i) {
+        uint64_t b = 0;
+        const uint8_t* c = q->codes.data() + q->off[i];
+        for (uint32_t j = 0; j < q->len[i]; ++j) b += (uint64_t)scorer->row_max[c[j]];
+        q->score_bound[i] = b;
+    }
+    q->bound_scorer = scorer->serial;
 }
 
 // Which queries may run in packed int16: every reachable H is bounded by sum_i max(0, max_b M[q_i][b]) (each row of the
@@ -362,23 +480,10 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         p->pairs.push_back(narrow[i]);
         p->pairs.push_back(i + 1 < narrow.size() ? narrow[i + 1] : 0xFFFFFFFFu);
     }
-    const uint32_t grid = std::max(p->grid_i32, p->grid_i16);
-    p->ws_slot = 2ull * (db->max_len4 ? db->max_len4 : 1) * 64 * 4;
-    p->ws_bytes = p->ws_slot * 4 * grid * kWavesPerBlock;
+    const uint32_t full = std::max(p->grid_i32, p->grid_i16);
+    for (const Tile& t : db->tiles)
+        p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
     return S4G_OK;
-}
-
-// per-query upper bound of any reachable score under this scorer (host, O(residues), cached per scorer)
-void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
-    if (q->bound_scorer == scorer->serial) return;
-    q->score_bound.assign(q->n, 0);
-    for (uint32_t i = 0; i < q->n; ++i) {
-        uint64_t b = 0;
-        const uint8_t* c = q->codes.data() + q->off[i];
-        for (uint32_t j = 0; j < q->len[i]; ++j) b += (uint64_t)scorer->row_max[c[j]];
-        q->score_bound[i] = b;
-    }
-    q->bound_scorer = scorer->serial;
 }
 
 int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStream_t stream) {
@@ -402,6 +507,52 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
         HIP_TRY(hipMemcpyAsync(db->d_qlist, p.pairs.data(), p.pairs.size() * 4, hipMemcpyHostToDevice, stream));
     if (!p.wide.empty())
         HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size(), p.wide.data(), p.wide.size() * 4, hipMemcpyHostToDevice, stream));
+    return S4G_OK;
+}
+
+// One tile: the packed launch for the int16-safe query pairs, then the int32 launch for the rest.
+// perm/stride select the output layout: original ids into the caller's [q][n_seqs] matrix, or tile columns.
+int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p, uint32_t q_begin,
+                int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream) {
+    if (t.n_seqs == 0) return S4G_OK;
+    if ((uint64_t)t.n_groups * std::max<uint64_t>(p.pairs.size() / 2, p.wide.size()) >= 0xFFFFFFFFull)
+        return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
+    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 8, stream));
+    if (!p.pairs.empty()) {
+        ScanArgs16 a;
+        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+        a.pairs = db->d_qlist;
+        a.mat = db->d_mat;
+        a.scores = d_scores; a.score_stride = stride;
+        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
+        a.counter = db->d_counter;
+        a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i16x2<kStripRows16>, dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!p.wide.empty()) {
+        ScanArgs a;
+        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+        a.mat = db->d_mat;
+        a.scores = d_scores; a.score_stride = stride;
+        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
+        a.counter = db->d_counter + 1;
+        a.n_groups = t.n_groups; a.q_begin = q_begin; a.q_count = (uint32_t)p.wide.size();
+        a.q_list = db->d_qlist + p.pairs.size();
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(tile_grid(t, p.grid_i32)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return S4G_OK;
+}
+
+int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
     return S4G_OK;
 }
 
@@ -429,48 +580,22 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
 
 S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
                            const s4g_scorer* scorer, int32_t* d_scores, void* stream_, uint32_t flags) {
-    if (!db || !q || !scorer || (!d_scores && q_count && db->n_seqs)) return fail(S4G_ERR_INVALID, "NULL argument");
-    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
-    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    int rc = check_scan_args(db, q, scorer, q_begin, q_count);
+    if (rc) return rc;
     if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
-    if ((uint64_t)db->n_groups * q_count >= 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "too many work items; split the query range");
+    if (!d_scores) return fail(S4G_ERR_INVALID, "d_scores is NULL");
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
     std::lock_guard<std::mutex> lk(db->mu);
     ensure_bounds(q, scorer);
     Plan p;
-    int rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
+    rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
     if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 8, stream));
-    if (!p.pairs.empty()) {
-        ScanArgs16 a;
-        a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-        a.pairs = db->d_qlist;
-        a.mat = db->d_mat;
-        a.scores = d_scores; a.score_stride = db->n_seqs;
-        a.ws = db->d_ws; a.ws_slot = p.ws_slot;
-        a.counter = db->d_counter;
-        a.n_groups = db->n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i16x2<kStripRows16>, dim3(p.grid_i16), dim3(kBlock), 0, stream, a);
-        HIP_TRY(hipGetLastError());
-    }
-    if (!p.wide.empty()) {
-        ScanArgs a;
-        a.db_res = db->d_res; a.grp_off = db->d_grp_off; a.grp_len4 = db->d_grp_len4; a.grp_perm = db->d_grp_perm;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-        a.mat = db->d_mat;
-        a.scores = d_scores; a.score_stride = db->n_seqs;
-        a.ws = db->d_ws; a.ws_slot = p.ws_slot;
-        a.counter = db->d_counter + 1;
-        a.n_groups = db->n_groups; a.q_begin = q_begin; a.q_count = (uint32_t)p.wide.size();
-        a.q_list = db->d_qlist + p.pairs.size();
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(p.grid_i32), dim3(kBlock), 0, stream, a);
-        HIP_TRY(hipGetLastError());
+    for (const Tile& t : db->tiles) {
+        rc = launch_tile(db, t, q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
+        if (rc) return rc;
     }
     return S4G_OK;
 }
@@ -491,6 +616,7 @@ S4G_API int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
 S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
                                 const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
     if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
     if (!h_scores) return fail(S4G_ERR_INVALID, "h_scores is NULL");
     DeviceGuard guard(db->device);
@@ -559,7 +685,8 @@ __device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned
 
 __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k, uint32_t kpad,
                                                         int32_t min_score, uint32_t* __restrict__ out_ids,
-                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
+                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                        const uint32_t* __restrict__ col_ids) {
     __shared__ unsigned hist[kBins];
     __shared__ unsigned long long keys[kTopkMax];
     __shared__ int s_hi, s_cut;
@@ -642,10 +769,48 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
     for (unsigned i = tid; i < k; i += kTopkBlock) {
         const unsigned long long key = keys[i];
         const bool valid = i < m;
-        out_ids[(uint64_t)blockIdx.x * k + i] = valid ? (uint32_t)key : 0xFFFFFFFFu;
+        out_ids[(uint64_t)blockIdx.x * k + i] = valid ? (col_ids ? col_ids[(uint32_t)key] : (uint32_t)key) : 0xFFFFFFFFu;
         out_scores[(uint64_t)blockIdx.x * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
     }
     if (tid == 0) out_counts[blockIdx.x] = m;
+}
+
+// running[q] <- best k of (running[q] U cand[q]) under (score desc, id asc); both inputs hold global ids.
+__global__ __launch_bounds__(kTopkBlock) void merge_rows(uint32_t* __restrict__ run_ids, int32_t* __restrict__ run_sc,
+                                                         uint32_t* __restrict__ run_cnt, const uint32_t* __restrict__ cand_ids,
+                                                         const int32_t* __restrict__ cand_sc, const uint32_t* __restrict__ cand_cnt,
+                                                         uint32_t k, uint32_t kpad2) {
+    __shared__ unsigned long long keys[2 * kTopkMax];
+    const int tid = threadIdx.x;
+    const uint64_t row = (uint64_t)blockIdx.x * k;
+    const unsigned na = run_cnt[blockIdx.x], nb = cand_cnt[blockIdx.x];
+    for (unsigned i = tid; i < kpad2; i += kTopkBlock) {
+        unsigned long long key = ~0ull;
+        if (i < na) key = ((unsigned long long)(unsigned)(0x7FFFFFFF - run_sc[row + i]) << 32) | run_ids[row + i];
+        else if (i - na < nb) key = ((unsigned long long)(unsigned)(0x7FFFFFFF - cand_sc[row + i - na]) << 32) | cand_ids[row + i - na];
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (unsigned size = 2; size <= kpad2; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < kpad2 / 2; t += kTopkBlock) {
+                const unsigned lo = 2 * t - (t & (stride - 1));
+                const unsigned hi2 = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a > b) == up) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned m = na + nb < k ? na + nb : k;
+    for (unsigned i = tid; i < k; i += kTopkBlock) {
+        const unsigned long long key = keys[i];
+        run_ids[row + i] = i < m ? (uint32_t)key : 0xFFFFFFFFu;
+        run_sc[row + i] = i < m ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+    }
+    __syncthreads();
+    if (tid == 0) run_cnt[blockIdx.x] = m;
 }
 
 }  // namespace
@@ -659,8 +824,64 @@ S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count
     uint32_t kpad = 2;
     while (kpad < k) kpad <<= 1;
     hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, k, kpad,
-                       min_score, d_ids, d_top_scores, d_counts);
+                       min_score, d_ids, d_top_scores, d_counts, (const uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// Streaming scan + running top-k: the score matrix is never materialised.  For each batch of queries and each
+// database tile: scan into a [batch][tile columns] buffer, exact tile top-k (ids translated to original ids), merge
+// into the running per-query lists.  Tile columns are ordered by original id, so ties break by id exactly as in
+// s4g_topk on the full matrix.  This is the path for databases whose Q x N scores do not fit (BASELINE configs[3]).
+S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts,
+                          void* stream_, uint32_t flags) {
+    int rc = check_scan_args(db, q, scorer, q_begin, q_count);
+    if (rc) return rc;
+    if (k == 0 || k > (uint32_t)kTopkMax) return fail(S4G_ERR_INVALID, "k must be in 1..%d (got %u)", kTopkMax, k);
+    if (q_count == 0) return S4G_OK;
+    if (!d_ids || !d_top_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    std::lock_guard<std::mutex> lk(db->mu);
+    HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)q_count * k * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_top_scores, 0, (size_t)q_count * k * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)q_count * 4, stream));
+    if (db->n_seqs == 0) return S4G_OK;
+    ensure_bounds(q, scorer);
+    const uint64_t cols = db->max_tile_seqs;
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
+    const uint64_t need = (uint64_t)batch * cols * 4 + (uint64_t)batch * k * 8 + (uint64_t)batch * 4;
+    if (db->tile_scores_bytes < need) {
+        if (db->d_tile_scores) HIP_TRY(hipFree(db->d_tile_scores));
+        db->d_tile_scores = nullptr; db->tile_scores_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&db->d_tile_scores, need));
+        db->tile_scores_bytes = need;
+    }
+    int32_t* d_buf = db->d_tile_scores;
+    uint32_t* c_ids = reinterpret_cast<uint32_t*>(d_buf + (uint64_t)batch * cols);
+    int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + (uint64_t)batch * k);
+    uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + (uint64_t)batch * k);
+    uint32_t kpad = 2, kpad2;
+    while (kpad < k) kpad <<= 1;
+    kpad2 = kpad * 2;
+    for (uint32_t b = 0; b < q_count; b += batch) {
+        const uint32_t cnt = std::min(batch, q_count - b);
+        Plan p;
+        rc = make_plan(db, q, q_begin + b, cnt, scorer, flags, &p);
+        if (rc) return rc;
+        rc = ensure_scratch(db, scorer, p, stream);
+        if (rc) return rc;
+        for (const Tile& t : db->tiles) {
+            rc = launch_tile(db, t, q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
+                               c_sc, c_cnt, (const uint32_t*)t.d_col_ids);
+            hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
+                               d_top_scores + (uint64_t)b * k, d_counts + b, c_ids, c_sc, c_cnt, k, kpad2);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     return S4G_OK;
 }
 

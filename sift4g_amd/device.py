@@ -60,8 +60,9 @@ class _SeqSet:
         self.device = device
         self.lengths = np.diff(self.offsets.astype(np.int64))
         self._h = ctypes.c_void_p()
-        check(type(self)._create(ctypes.byref(self._h), device, _ptr(self.codes, c_u8p), _ptr(self.offsets, c_u64p), self.n),
-              type(self)._create.__name__)
+        create = getattr(self, "_create_override", None) or type(self)._create
+        check(create(ctypes.byref(self._h), device, _ptr(self.codes, c_u8p), _ptr(self.offsets, c_u64p), self.n),
+              create.__name__)
 
     def __len__(self):
         return self.n
@@ -76,9 +77,25 @@ class _SeqSet:
 
 
 class Database(_SeqSet):
-    """chainDatabaseCreate(database, 0, n, cards, cardsLen)  (database_alignment.cpp:80): resident in HBM."""
+    """chainDatabaseCreate(database, 0, n, cards, cardsLen)  (database_alignment.cpp:80): resident in HBM.
+    tile_seqs: sequences per tile of the length-sorted order (0 = library default 2^20)."""
     _create = lib.s4g_db_create
     _destroy = lib.s4g_db_destroy
+
+    def __init__(self, seqs=None, device=0, codes=None, offsets=None, tile_seqs=0):
+        if tile_seqs:
+            def create(out, dev, c, o, n):
+                return lib.s4g_db_create_tiled(out, dev, c, o, n, int(tile_seqs))
+            create.__name__ = "s4g_db_create_tiled"
+            self._create_override = create
+        super().__init__(seqs, device, codes, offsets)
+
+    def tiles(self):
+        n = ctypes.c_uint32()
+        check(lib.s4g_db_tiles(self._h, ctypes.byref(n), None, 0), "s4g_db_tiles")
+        arr = (ctypes.c_uint32 * max(n.value, 1))()
+        check(lib.s4g_db_tiles(self._h, ctypes.byref(n), arr, n.value), "s4g_db_tiles")
+        return list(arr)[: n.value]
 
     def info(self):
         n = ctypes.c_uint32(); r = ctypes.c_uint64(); p = ctypes.c_uint64(); b = ctypes.c_uint64()
@@ -138,6 +155,22 @@ def score_lists(db, queries, scorer, cand_offsets, cand_ids):
     check(lib.s4g_score_lists_host(db._h, queries._h, _ptr(cand_offsets, c_u64p), _ptr(cand_ids, c_u32p), scorer._h,
                                    _ptr(out, c_i32p)), "s4g_score_lists_host")
     return out[: int(cand_offsets[-1])]
+
+
+def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stream=None, force_i32=False):
+    """Streaming scan + running top-k (no score matrix): -> device tensors (ids int32 [q,k] (-1 unused), scores [q,k], counts [q])."""
+    import torch
+    q_count = queries.n - q_begin if q_count is None else q_count
+    device = torch.device("cuda", db.device)
+    ids = torch.empty((q_count, k), dtype=torch.int32, device=device)
+    sc = torch.empty((q_count, k), dtype=torch.int32, device=device)
+    cnt = torch.empty((q_count,), dtype=torch.int32, device=device)
+    if stream is None:
+        stream = torch.cuda.current_stream(device)
+    check(lib.s4g_scan_topk(db._h, queries._h, q_begin, q_count, scorer._h, k, int(min_score), ctypes.c_void_p(ids.data_ptr()),
+                            ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(stream.cuda_stream),
+                            _lib.S4G_SCAN_FORCE_I32 if force_i32 else 0), "s4g_scan_topk")
+    return ids, sc, cnt
 
 
 def topk_device(db, scores, k, min_score=1, stream=None):

@@ -109,3 +109,12 @@ def scan_query_shard(db, queries, scorer, k, min_score=1, group=None, rank=None,
         sc = torch.zeros((0, k), dtype=torch.int32, device=device)
         cnt = torch.zeros((0,), dtype=torch.int32, device=device)
     return gather_query_shards(ids, sc, cnt, queries.n, group)
+
+
+def scan_db_shard(db_shard, global_ids, queries, scorer, k, min_score=1, group=None):
+    """Whole DB-shard job on this rank's GPU: `db_shard` holds this rank's slice of the database (resident in HBM),
+    `global_ids[i]` = global id of its i-th target.  Every rank scans ALL queries with the streaming scan + running
+    top-k (no score matrix), then one RCCL all-gather + K-way merge gives the global top-k on every rank."""
+    from . import device as dev
+    ids, sc, cnt = dev.scan_topk(db_shard, queries, scorer, k, min_score)
+    return gather_db_shards(ids, sc, cnt, torch.as_tensor(global_ids), k, group)

@@ -258,3 +258,50 @@ def test_full_size_properties(s4g, oracle_mod, blosum62, scorer):
     pt = np.concatenate([rng.integers(0, db.n, 3000), [b for _, b in planted[:200]]]).astype(np.uint32)
     exp = oracle_mod.pairs_flat(cfg["q_codes"], cfg["q_off"], cfg["t_codes"], cfg["t_off"], pq, pt, blosum62, 10, 1, threads=8)
     assert np.array_equal(got[pq, pt], exp)
+
+
+def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
+    """the database is stored as tiles of the length-sorted order (incl. a separate long-sequence class):
+    full-matrix scans must not depend on the tiling."""
+    rng = np.random.default_rng(27)
+    qs = rand_seqs(rng, 9, 20, 260)
+    ts = rand_seqs(rng, 700, 1, 300) + [rand_seqs(rng, 1, 4100, 4100)[0], rand_seqs(rng, 1, 5000, 5000)[0]]
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    q = s4g.QuerySet(qs)
+    for tile_seqs in (0, 64, 192, 1000):
+        db = s4g.Database(ts, tile_seqs=tile_seqs)
+        tiles = db.tiles()
+        assert sum(tiles) == len(ts)
+        if tile_seqs == 64:
+            assert len(tiles) >= 11 and tiles[0] == 2          # the two > 4096-residue sequences form their own tile
+        for force in (False, True):
+            assert np.array_equal(s4g.scan_host(db, q, scorer, force_i32=force), exp)
+
+
+def test_streaming_scan_topk_equals_full_matrix_topk(s4g, oracle_mod, blosum62, scorer):
+    """s4g_scan_topk (tile by tile, running merge, score matrix never materialised) == s4g_topk of the full scan,
+    including ties that straddle tiles."""
+    import torch
+    rng = np.random.default_rng(28)
+    qs = rand_seqs(rng, 11, 30, 200)
+    ts = rand_seqs(rng, 900, 5, 260)
+    for j in range(0, 900, 13):                       # many equal-score targets (identical copies) spread over all tiles
+        ts[j] = qs[j % 11][:60].copy()
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    q = s4g.QuerySet(qs)
+    for tile_seqs in (0, 128, 320):
+        db = s4g.Database(ts, tile_seqs=tile_seqs)
+        full = torch.empty((len(qs), len(ts)), dtype=torch.int32, device="cuda:0")
+        s4g.scan(db, q, scorer, full)
+        for k, ms in ((1, 1), (25, 1), (400, 20), (1500, 1)):
+            want = s4g.topk(db, full, k, ms)
+            ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), want[2])
+            assert np.array_equal(sc.cpu().numpy(), want[1])
+            assert np.array_equal(ids.cpu().numpy().astype(np.uint32), want[0])
+            for i in range(len(qs)):                   # and against the oracle directly
+                order = sorted((j for j in range(len(ts)) if exp[i, j] >= ms), key=lambda j: (-exp[i, j], j))[:k]
+                assert ids[i, :len(order)].cpu().tolist() == order
+        sub = s4g.scan_topk(db, q, scorer, 10, 1, q_begin=4, q_count=3)
+        assert np.array_equal(sub[0].cpu().numpy(), s4g.scan_topk(db, q, scorer, 10, 1)[0][4:7].cpu().numpy())
