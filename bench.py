@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--qlen", type=int, nargs=2, default=[300, 400], help="query length range (configs[4]: 2000 5000)")
     ap.add_argument("--force-i32", action="store_true", help="run every query through the int32 kernel")
+    ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard",
+                    help="query-shard (default): DB replicated, --queries per GPU; db-shard: --targets per GPU, every GPU scans "
+                         "all --queries with the streaming scan + running top-k, then all-gather + K-way merge")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,33 +85,54 @@ def main():
             sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("S4G_BENCH_FORCE_DIST") == "1"     # the latter exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # ---- workload: identical generator on every rank; DB replicated, queries sharded ----
+    # ---- workload: identical generator on every rank ----
+    db_shard = args.mode == "db-shard"
     t_gen = time.perf_counter()
-    cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen))
+    if db_shard:      # DB grows with N (each GPU holds --targets of it), every GPU scans all --queries
+        cfg = synth.make_config(2, n_queries=args.queries, n_targets=args.targets * world, q_len=tuple(args.qlen))
+        lengths = np.diff(cfg["t_off"].astype(np.int64))
+        mine = shard.balanced_db_shards(lengths, world)[rank].numpy()
+        my_off = np.zeros(len(mine) + 1, dtype=np.uint64)
+        my_off[1:] = np.cumsum(lengths[mine]).astype(np.uint64)
+        my_codes = np.concatenate([cfg["t_codes"][int(cfg["t_off"][i]):int(cfg["t_off"][i + 1])] for i in mine])
+        t_codes, t_off = my_codes, my_off
+    else:             # DB replicated, queries sharded: --queries per GPU
+        cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen))
+        t_codes, t_off = cfg["t_codes"], cfg["t_off"]
     t_up = time.perf_counter()
-    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"], device=local_rank)
+    db = s4g.Database(codes=t_codes, offsets=t_off, device=local_rank)
     allq = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"], device=local_rank)
     torch.cuda.synchronize()
     t_ready = time.perf_counter()
     if rank == 0:
-        print(f"bench.py: generate {t_up - t_gen:.1f} s; pack+upload DB ({int(cfg['t_off'][-1])} residues) and queries "
+        print(f"bench.py: generate {t_up - t_gen:.1f} s; pack+upload DB ({int(t_off[-1])} residues) and queries "
               f"{t_ready - t_up:.2f} s (host packing + PCIe, outside the timed region)", file=sys.stderr)
-    q_begin, q_count = rank * args.queries, args.queries
+    q_begin, q_count = (0, args.queries) if db_shard else (rank * args.queries, args.queries)
     scorer = s4g.Scorer("BLOSUM_62", 10, 1)
     cells_rank = scan_cells(db, allq, q_begin, q_count)
     plan = scan_plan(db, allq, scorer)
     if args.force_i32:
         plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
-    scores = torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
+    scores = None if db_shard else torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
+    gids = torch.from_numpy(mine.astype(np.int64)).to(dev) if db_shard else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record()
+        if db_shard:
+            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32)    # scan + tile top-k + merge
+            if i is not None:
+                ev[i][1].record()
+            return shard.gather_db_shards(ids, sc, cnt, gids, TOPK)                          # RCCL all-gather + K-way merge
         s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32)
         if i is not None:
             ev[i][1].record()
@@ -116,7 +140,7 @@ def main():
         return shard.gather_query_shards(ids, sc, cnt, allq.n)                  # RCCL all-gather of the hit lists (N > 1)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +156,7 @@ def main():
 
     t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
     c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     dt, kern_ms = float(t[0]), float(t[1])
@@ -159,7 +183,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1] generator: {args.queries} synthetic queries/GPU len U[{args.qlen[0]},{args.qlen[1]}] x "
                                    f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
                                    f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",
-                       "cells_per_step": cells_total, "parallelism": f"query-shard x{world}, DB replicated",
+                       "cells_per_step": cells_total, "parallelism": (f"db-shard x{world}: {args.targets} targets/GPU, all queries on every GPU, all-gather + merge"
+                                       if db_shard else f"query-shard x{world}, DB replicated"),
                        "kernel": plan["kernel"], "grid_blocks": plan["grid_blocks"], "strip_rows": plan["strip_rows"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -170,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

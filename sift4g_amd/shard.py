@@ -34,7 +34,7 @@ def gather_query_shards(ids, scores, counts, n_queries_total, group=None):
     """query-shard mode: rank r holds the hit lists of queries [b_r, b_{r+1}).  Returns the full
     (ids [Q,K], scores [Q,K], counts [Q]) on every rank.  One all-gather of (2K+1) int32 per query."""
     world = _world(group)
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return ids, scores, counts
     bounds = shard_bounds(n_queries_total, world)
     per = max(bounds[r + 1] - bounds[r] for r in range(world))
@@ -76,7 +76,7 @@ def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None):
     valid = local_ids >= 0
     gid = torch.where(valid, global_ids.to(local_ids.device)[local_ids.clamp(min=0).long()].to(torch.int32),
                       torch.full_like(local_ids, -1))
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return merge_topk(gid, scores, k)
     q, kk = gid.shape
     packed = torch.cat([gid, scores], dim=1).contiguous()
