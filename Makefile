@@ -16,7 +16,7 @@ REF     ?= /root/reference
 
 all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so oracle
 
-$(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h $(CSRC)/matrices.h include/s4g_hip.h
+$(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h $(CSRC)/sw_trace.hip.h $(CSRC)/matrices.h include/s4g_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/s4g_hip.hip
 

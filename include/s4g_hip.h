@@ -34,6 +34,8 @@
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
  *       (s4g_score_lists_host = the per-query candidate lists built by
  *       createFilteredDatabase, database_alignment.cpp:136-162)
+ *   s4g_traceback_host
+ *       step 4 of swsharp alignDatabase: traceback of the survivors
  *   s4g_topk / s4g_topk_host / s4g_scan_topk
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
@@ -147,6 +149,16 @@ int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
                   void* stream, uint32_t flags);
 int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
                   uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream);
+
+/* Traceback of surviving pairs on the device (step 4 of alignDatabase: the alignment paths that
+ * /root/reference/sift4g/src/select_alignments.cpp:244-300 walks).  pair_score[i] must be the optimal local score of
+ * (pair_q[i], pair_t[i]) as returned by the scan.  h_out[i*5 .. i*5+4] = q_start, q_end, t_start, t_end (0-based,
+ * inclusive; -1 if the score is 0), path_len.  The path of pair i is written to h_paths[path_off[i] ..] with the
+ * swsharp move codes 1 = DIAG, 2 = LEFT (gap in query), 3 = UP (gap in target), start to end; path_off has
+ * n_pairs+1 entries and must leave at least (query length + target length) bytes per pair.  Synchronous. */
+int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                       const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                       int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);
 
 /* Introspection for measurement (bench.py): name and launch geometry of the
  * kernel s4g_scan dispatches for this (db, queries, scorer) combination. */

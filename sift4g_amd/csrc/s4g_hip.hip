@@ -6,6 +6,7 @@
 // sift4g (/root/reference/sift4g/src/database_alignment.cpp:80-86).
 #include "../../include/s4g_hip.h"
 #include "sw_kernels.hip.h"
+#include "sw_trace.hip.h"
 #include "matrices.h"
 
 #include <algorithm>
@@ -82,6 +83,8 @@ struct Tile {
     uint32_t* d_perm_global = nullptr;  // [G*64] original target id of (g, lane); ~0u = empty lane
     uint32_t* d_perm_local = nullptr;   // [G*64] column in the tile's own score buffer = rank of the id inside the tile
     uint32_t* d_col_ids = nullptr;      // [n_seqs] tile column -> original target id (ascending)
+    std::vector<uint64_t> h_grp_off;    // host copy (traceback addresses lanes of arbitrary targets)
+    uint64_t pos0 = 0;                  // position of the tile's first sequence in the global length-sorted order
 };
 
 struct s4g_db {
@@ -91,6 +94,7 @@ struct s4g_db {
     uint32_t max_tile_seqs = 0;
     std::vector<Tile> tiles;
     std::vector<uint32_t> len;     // original index -> length
+    std::vector<uint32_t> pos_of_id;   // original index -> position in the global length-sorted order
     // per-device scratch, created lazily and reused (scan calls on one db are serialized)
     mutable std::mutex mu;
     mutable int32_t* d_ws = nullptr;
@@ -188,6 +192,18 @@ void free_tile(Tile& t) {
     t = Tile();
 }
 
+template <typename T>
+struct DevBuf {          // scoped device allocation for the non-hot paths
+    T* p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
 // Packs order[p0, p1) (length-sorted, longest first) into one tile and uploads it.
 hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, size_t p0, size_t p1,
                       const uint8_t* codes, const uint64_t* offsets, std::string* err) {
@@ -252,6 +268,8 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
     if ((e = up((void**)&t.d_perm_global, perm_g.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_perm_local, perm_l.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_col_ids, col_ids.data(), (size_t)n * 4)) != hipSuccess) return e;
+    t.h_grp_off.swap(grp_off);
+    t.pos0 = p0;
     return hipSuccess;
 }
 
@@ -282,6 +300,8 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
 
+    db->pos_of_id.resize(n_seqs);
+    for (uint32_t pp = 0; pp < n_seqs; ++pp) db->pos_of_id[order[pp]] = pp;
     // cut the sorted order into tiles: by count, by padded residues, and at the long-sequence threshold
     size_t p = 0;
     while (p < n_seqs) {
@@ -905,4 +925,132 @@ S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_
     }
     (void)hipFree(d_ids); (void)hipFree(d_sc); (void)hipFree(d_counts);
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Traceback of the survivors on the device (step 4 of alignDatabase).
+S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                               const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                               int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (n_pairs == 0) return S4G_OK;
+    if (!pair_q || !pair_t || !pair_score || !h_out || !path_off || !h_paths) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %u out of range", i);
+        if (q->len[pair_q[i]] >= 65535 || db->len[pair_t[i]] >= 65535)
+            return fail(S4G_ERR_INVALID, "pair %u: sequences of 65535 residues or more are not supported by the device traceback", i);
+        if (path_off[i + 1] - path_off[i] < (uint64_t)q->len[pair_q[i]] + db->len[pair_t[i]])
+            return fail(S4G_ERR_INVALID, "pair %u: path capacity must be at least query length + target length", i);
+    }
+    DeviceGuard guard(db->device);
+    std::lock_guard<std::mutex> lk(db->mu);
+    hipStream_t stream = nullptr;
+
+    // items: pairs grouped by query, sorted by target length inside a query, 64 lanes per item
+    std::vector<uint32_t> idx(n_pairs);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (pair_q[a] != pair_q[b]) return pair_q[a] < pair_q[b];
+        return db->len[pair_t[a]] > db->len[pair_t[b]];
+    });
+    struct Item { uint32_t q, len4, first, count; uint64_t dir_dwords; };
+    std::vector<Item> items;
+    for (uint32_t i = 0; i < n_pairs;) {
+        uint32_t j = i;
+        while (j < n_pairs && j - i < 64 && pair_q[idx[j]] == pair_q[idx[i]]) ++j;
+        const uint32_t len4 = (db->len[pair_t[idx[i]]] + 3) / 4;          // longest first
+        const uint32_t nstrips = (q->len[pair_q[idx[i]]] + kTraceR - 1) / kTraceR;
+        items.push_back({pair_q[idx[i]], len4, i, j - i, (uint64_t)nstrips * len4 * kTraceR * 64});
+        i = j;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, db->device));
+    DevBuf<int8_t> d_mat;
+    HIP_TRY(d_mat.alloc(1024));
+    HIP_TRY(hipMemcpy(d_mat.p, scorer->mat32, 1024, hipMemcpyHostToDevice));
+    DevBuf<unsigned> d_counter;
+    HIP_TRY(d_counter.alloc(4));
+
+    const uint64_t dir_budget = (8ull << 30) / 4;       // dwords of direction bytes per batch
+    std::vector<int32_t> out5;
+    for (size_t b0 = 0; b0 < items.size();) {
+        size_t b1 = b0;
+        uint64_t dir_total = 0;
+        uint32_t max_len4 = 0;
+        while (b1 < items.size() && (b1 == b0 || dir_total + items[b1].dir_dwords <= dir_budget)) {
+            dir_total += items[b1].dir_dwords;
+            max_len4 = std::max(max_len4, items[b1].len4);
+            ++b1;
+        }
+        const uint32_t ni = (uint32_t)(b1 - b0);
+        std::vector<uint64_t> lane_res((size_t)ni * 64, 0), dir_off(ni);
+        std::vector<uint32_t> lane_len((size_t)ni * 64, 0), item_q(ni), item_len4(ni), slot_of_pair;
+        std::vector<int32_t> lane_score((size_t)ni * 64, -1);
+        std::vector<uint32_t> pair_ids;                 // original pair index of each slot_of_pair entry
+        std::vector<uint64_t> poff(1, 0);
+        uint64_t off = 0;
+        for (uint32_t k = 0; k < ni; ++k) {
+            const Item& it = items[b0 + k];
+            item_q[k] = it.q; item_len4[k] = it.len4; dir_off[k] = off; off += it.dir_dwords;
+            for (uint32_t l = 0; l < it.count; ++l) {
+                const uint32_t pi = idx[it.first + l];
+                const uint32_t id = pair_t[pi];
+                const uint32_t pos = db->pos_of_id[id];
+                size_t ti = 0;
+                while (ti + 1 < db->tiles.size() && db->tiles[ti + 1].pos0 <= pos) ++ti;
+                const Tile& t = db->tiles[ti];
+                const uint32_t lp = (uint32_t)(pos - t.pos0);
+                lane_res[(size_t)k * 64 + l] = (uint64_t)(uintptr_t)(t.d_res + t.h_grp_off[lp >> 6] + (lp & 63));
+                lane_len[(size_t)k * 64 + l] = db->len[id];
+                lane_score[(size_t)k * 64 + l] = pair_score[pi];
+                slot_of_pair.push_back(k * 64 + l);
+                pair_ids.push_back(pi);
+                poff.push_back(poff.back() + (path_off[pi + 1] - path_off[pi]));
+            }
+            for (uint32_t l = it.count; l < 64; ++l) lane_res[(size_t)k * 64 + l] = lane_res[(size_t)k * 64];   // valid address, length 0
+        }
+        const uint32_t np = (uint32_t)slot_of_pair.size();
+        DevBuf<uint64_t> d_lane_res, d_dir_off, d_poff;
+        DevBuf<uint32_t> d_lane_len, d_item_q, d_item_len4, d_dirs, d_end, d_slot;
+        DevBuf<int32_t> d_lane_score, d_best, d_ws, d_out;
+        DevBuf<uint8_t> d_paths;
+        HIP_TRY(d_lane_res.upload(lane_res)); HIP_TRY(d_dir_off.upload(dir_off)); HIP_TRY(d_poff.upload(poff));
+        HIP_TRY(d_lane_len.upload(lane_len)); HIP_TRY(d_item_q.upload(item_q)); HIP_TRY(d_item_len4.upload(item_len4));
+        HIP_TRY(d_slot.upload(slot_of_pair)); HIP_TRY(d_lane_score.upload(lane_score));
+        HIP_TRY(d_dirs.alloc(off)); HIP_TRY(d_end.alloc((size_t)ni * 64)); HIP_TRY(d_best.alloc((size_t)ni * 64));
+        HIP_TRY(d_out.alloc((size_t)np * 5)); HIP_TRY(d_paths.alloc(poff.back()));
+        const uint32_t grid = std::max(1u, std::min<uint32_t>((ni + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)prop.multiProcessorCount * 2));
+        const uint64_t ws_slot = 2ull * std::max(1u, max_len4) * 64 * 4;
+        HIP_TRY(d_ws.alloc(ws_slot * grid * kWavesPerBlock));
+        HIP_TRY(hipMemsetAsync(d_counter.p, 0, 4, stream));
+        TraceArgs a;
+        a.lane_res = d_lane_res.p; a.lane_len = d_lane_len.p; a.lane_score = d_lane_score.p; a.item_q = d_item_q.p;
+        a.item_len4 = d_item_len4.p; a.item_dir_off = d_dir_off.p;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = d_mat.p;
+        a.dirs = d_dirs.p; a.ws = d_ws.p; a.ws_slot = ws_slot; a.counter = d_counter.p; a.n_items = ni;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.end_key = d_end.p; a.best = d_best.p;
+        hipLaunchKernelGGL(sw_trace_fill, dim3(grid), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        WalkArgs w;
+        w.dirs = d_dirs.p; w.item_dir_off = d_dir_off.p; w.item_len4 = d_item_len4.p; w.end_key = d_end.p;
+        w.slot_of_pair = d_slot.p; w.path_off = d_poff.p; w.paths = d_paths.p; w.out = d_out.p; w.n_pairs = np;
+        hipLaunchKernelGGL(sw_trace_walk, dim3((np + 63) / 64), dim3(64), 0, stream, w);
+        HIP_TRY(hipGetLastError());
+        out5.resize((size_t)np * 5);
+        std::vector<uint8_t> paths(poff.back() ? poff.back() : 1);
+        std::vector<int32_t> best((size_t)ni * 64);
+        HIP_TRY(hipMemcpy(out5.data(), d_out.p, out5.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(paths.data(), d_paths.p, poff.back(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(best.data(), d_best.p, best.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t x = 0; x < np; ++x) {
+            const uint32_t pi = pair_ids[x];
+            if (best[slot_of_pair[x]] != pair_score[pi])
+                return fail(S4G_ERR_INVALID, "pair %u: score %d passed in, traceback kernel computed %d", pi, pair_score[pi], best[slot_of_pair[x]]);
+            memcpy(h_out + (size_t)pi * 5, out5.data() + (size_t)x * 5, 20);
+            memcpy(h_paths + path_off[pi], paths.data() + poff[x], (size_t)out5[(size_t)x * 5 + 4]);
+        }
+        b0 = b1;
+    }
+    return S4G_OK;
 }

@@ -4,7 +4,8 @@
 //   1. score the query against every target       -> libs4g_hip (HIP, MI355X); NO host scoring path
 //   2. valueFunction(values, scores, ...)          -> caller's callback (e-values, :129-134)
 //   3. keep value <= threshold, sort, top maxAlignments
-//   4. traceback of the survivors                  -> host C++ below (<= 400 pairs per query)
+//   4. traceback of the survivors                  -> libs4g_hip (s4g_traceback_host: device fill + walk kernels);
+//                                                     the host traceback below serves alignPair and dbAlignmentsFromScores
 // ASSUMPTIONS (unpinned, swsharp source absent): order = value ascending, then score descending, then target index
 // ascending; traceback ties = first maximum in row-major order as end cell, then DIAG before UP before LEFT.
 #include "impl.hpp"
@@ -215,12 +216,10 @@ void* trace_task(void* p) {
 
 }  // namespace
 
-SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,
-                                   Chain** database, int databaseLen, const int* scores, Scorer* scorer, int maxAlignments,
-                                   ValueFunction valueFunction, void* valueFunctionParam, double valueThreshold) {
-    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
-    *dbAlignments = NULL;
-    *dbAlignmentsLen = 0;
+// steps 2-3: values, threshold, order, cut
+static void select_survivors(std::vector<Survivor>& keep, Chain* query, Chain** database, int databaseLen, const int* scores,
+                             int maxAlignments, ValueFunction valueFunction, void* valueFunctionParam, double valueThreshold) {
+    keep.clear();
     if (databaseLen <= 0) return;
     std::vector<double> values(databaseLen);
     if (valueFunction) {
@@ -229,7 +228,6 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
     } else {
         for (int i = 0; i < databaseLen; ++i) values[i] = -(double)scores[i];
     }
-    std::vector<Survivor> keep;
     for (int i = 0; i < databaseLen; ++i)
         if (scores[i] > 0 && (!valueFunction || values[i] <= valueThreshold)) keep.push_back({i, scores[i], values[i]});
     std::sort(keep.begin(), keep.end(), [](const Survivor& a, const Survivor& b) {
@@ -238,6 +236,16 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
         return a.idx < b.idx;
     });
     if (maxAlignments >= 0 && (int)keep.size() > maxAlignments) keep.resize(maxAlignments);
+}
+
+SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,
+                                   Chain** database, int databaseLen, const int* scores, Scorer* scorer, int maxAlignments,
+                                   ValueFunction valueFunction, void* valueFunctionParam, double valueThreshold) {
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    *dbAlignments = NULL;
+    *dbAlignmentsLen = 0;
+    std::vector<Survivor> keep;
+    select_survivors(keep, query, database, databaseLen, scores, maxAlignments, valueFunction, valueFunctionParam, valueThreshold);
     const int n = (int)keep.size();
     if (n == 0) return;
     std::vector<TraceJob> jobs(n);
@@ -283,25 +291,75 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
     // batches bound the host score matrix to ~1 GiB
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)queriesLen, (1ull << 28) / (uint64_t)cdb->length));
     std::vector<int32_t> scores((size_t)batch * cdb->length);
-    std::vector<int> picked;
+    Chain** targets = subset.empty() ? cdb->chains : sub_chains.data();
+    const int n_targets = subset.empty() ? cdb->length : (int)subset.size();
+
+    struct SelectJob {
+        Chain* query; Chain** targets; int n; const int32_t* row; const std::vector<int>* subset; int maxAlignments;
+        ValueFunction vf; void* vfp; double thr; std::vector<Survivor> keep;
+    };
+    auto select_task = [](void* p) -> void* {
+        SelectJob* jb = (SelectJob*)p;
+        if (jb->subset->empty()) {
+            select_survivors(jb->keep, jb->query, jb->targets, jb->n, jb->row, jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
+        } else {
+            std::vector<int> picked(jb->subset->size());
+            for (size_t k = 0; k < picked.size(); ++k) picked[k] = jb->row[(*jb->subset)[k]];
+            select_survivors(jb->keep, jb->query, jb->targets, jb->n, picked.data(), jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
+        }
+        return NULL;
+    };
+
     for (uint32_t b = 0; b < (uint32_t)queriesLen; b += batch) {
         const uint32_t cnt = std::min<uint32_t>(batch, (uint32_t)queriesLen - b);
         if (s4g_scan_host(cdb->dev, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
             SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        // steps 2-3 on the host, one pool task per query (the value callback is the caller's double-precision code)
+        std::vector<SelectJob> sel(cnt);
+        std::vector<ThreadPoolTask*> tasks(cnt);
         for (uint32_t i = 0; i < cnt; ++i) {
-            const int32_t* row = scores.data() + (size_t)i * cdb->length;
-            DbAlignment** out = NULL; int n = 0;
-            if (subset.empty()) {
-                dbAlignmentsFromScores(&out, &n, type, queries[b + i], cdb->chains, cdb->length, row, scorer, maxAlignments,
-                                       valueFunction, valueFunctionParam, valueThreshold);
-            } else {
-                picked.resize(subset.size());
-                for (size_t k = 0; k < subset.size(); ++k) picked[k] = row[subset[k]];
-                dbAlignmentsFromScores(&out, &n, type, queries[b + i], sub_chains.data(), (int)subset.size(), picked.data(),
-                                       scorer, maxAlignments, valueFunction, valueFunctionParam, valueThreshold);
-                for (int k = 0; k < n; ++k) out[k]->target_idx = subset[out[k]->target_idx];
+            sel[i] = {queries[b + i], targets, n_targets, scores.data() + (size_t)i * cdb->length, &subset, maxAlignments,
+                      valueFunction, valueFunctionParam, valueThreshold, {}};
+            tasks[i] = threadPoolSubmit(select_task, &sel[i]);
+        }
+        std::vector<uint32_t> pair_q, pair_t;
+        std::vector<int32_t> pair_score;
+        std::vector<uint64_t> path_off(1, 0);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            threadPoolTaskWait(tasks[i]);
+            threadPoolTaskDelete(tasks[i]);
+            for (const Survivor& sv : sel[i].keep) {
+                const int tidx = subset.empty() ? sv.idx : subset[sv.idx];
+                pair_q.push_back(b + i);
+                pair_t.push_back((uint32_t)tidx);
+                pair_score.push_back(sv.score);
+                path_off.push_back(path_off.back() + (uint64_t)chainGetLength(queries[b + i]) + (uint64_t)chainGetLength(cdb->chains[tidx]));
             }
-            for (int k = 0; k < n; ++k) out[k]->query_idx = (int)(b + i);
+        }
+        // step 4 on the device: one batched traceback of every survivor of this query batch
+        const uint32_t np = (uint32_t)pair_q.size();
+        std::vector<int32_t> out5((size_t)np * 5);
+        std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
+        if (np && s4g_traceback_host(cdb->dev, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
+                                     path_off.data(), paths.data()) != S4G_OK)
+            SW_FATAL("traceback failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        uint32_t x = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int n = (int)sel[i].keep.size();
+            DbAlignment** out = n ? (DbAlignment**)malloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
+            for (int k = 0; k < n; ++k, ++x) {
+                const Survivor& sv = sel[i].keep[k];
+                DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
+                a->query = queries[b + i]; a->query_idx = (int)(b + i);
+                a->target = cdb->chains[pair_t[x]]; a->target_idx = (int)pair_t[x];
+                a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
+                a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
+                a->score = sv.score; a->value = sv.value; a->scorer = scorer;
+                a->path_len = out5[(size_t)x * 5 + 4];
+                a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+                memcpy(a->path, paths.data() + path_off[x], a->path_len);
+                out[k] = a;
+            }
             (*dbAlignments)[b + i] = out;
             (*dbAlignmentsLens)[b + i] = n;
         }

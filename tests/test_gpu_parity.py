@@ -305,3 +305,41 @@ def test_streaming_scan_topk_equals_full_matrix_topk(s4g, oracle_mod, blosum62, 
                 assert ids[i, :len(order)].cpu().tolist() == order
         sub = s4g.scan_topk(db, q, scorer, 10, 1, q_begin=4, q_count=3)
         assert np.array_equal(sub[0].cpu().numpy(), s4g.scan_topk(db, q, scorer, 10, 1)[0][4:7].cpu().numpy())
+
+
+def test_device_traceback_equals_oracle(s4g, oracle_mod, blosum62, scorer):
+    """s4g_traceback_host: end cell, start cell and the whole move string of every pair equal the oracle's traceback
+    (same tie rules as the host traceback in libswsharp)."""
+    rng = np.random.default_rng(29)
+    qs = rand_seqs(rng, 6, 40, 300) + [rand_seqs(rng, 1, 1, 1)[0], rand_seqs(rng, 1, 33, 33)[0]]
+    ts = rand_seqs(rng, 150, 1, 350)
+    for k in range(60):                                   # homologs with indels and low-complexity runs (ties)
+        src = qs[k % 6]
+        cut = int(rng.integers(5, len(src) - 5))
+        gap = int(rng.integers(1, 12))
+        ts[k] = np.concatenate([src[:cut], rand_seqs(rng, 1, gap, gap)[0], src[cut + (k % 4):]]) if k % 2 else np.concatenate([src[:cut], src[cut + gap:]])
+    ts[60] = np.full(120, 0, dtype=np.uint8); qs.append(np.full(90, 0, dtype=np.uint8))          # poly-A vs poly-A: massive ties
+    ts[61] = np.tile(np.array([0, 2], dtype=np.uint8), 70); qs.append(np.tile(np.array([2, 0], dtype=np.uint8), 50))
+    MOVE = {0: 1, 1: 2, 2: 3}
+    for tile_seqs in (0, 64):
+        db = s4g.Database(ts, tile_seqs=tile_seqs)
+        q = s4g.QuerySet(qs)
+        scores = s4g.scan_host(db, q, scorer)
+        pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+        pq, pt = pq.ravel(), pt.ravel()
+        perm = rng.permutation(len(pq))                    # arbitrary pair order, > 64 survivors per query -> several items
+        pq, pt = pq[perm], pt[perm]
+        res = s4g.traceback(db, q, scorer, pq, pt, scores[pq, pt])
+        n_pos = 0
+        for a, b, r in zip(pq, pt, res):
+            o = oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1)
+            assert o["score"] == r["score"]
+            if o["score"] == 0:
+                assert len(r["path"]) == 0 and r["q_start"] == -1
+                continue
+            n_pos += 1
+            assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"]), (a, b)
+            assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (a, b)
+        assert n_pos > 1000
+    with pytest.raises(Exception):                         # a wrong score is detected, not silently traced
+        s4g.traceback(db, q, scorer, [0], [0], [int(scores[0, 0]) + 1])
