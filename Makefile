@@ -14,7 +14,11 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Iinclude
 SWSRC   := $(CSRC)/swsharp/core.cpp $(CSRC)/swsharp/evalue.cpp $(CSRC)/swsharp/align.cpp $(CSRC)/swsharp/output.cpp
 REF     ?= /root/reference
 
-all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so oracle
+all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so build/shotgun_demo oracle
+
+build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
+	@mkdir -p build
+	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 $(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h $(CSRC)/sw_trace.hip.h $(CSRC)/matrices.h include/s4g_hip.h
 	@mkdir -p $(LIBDIR)

@@ -41,3 +41,14 @@ def flatten(seqs):
     if total:
         codes[:total] = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs])
     return codes, off
+
+
+def write_fasta(path, names, codes, offsets, width=60):
+    """writes sequences given as concatenated codes + offsets"""
+    with open(path, "w") as fh:
+        letters = (np.asarray(codes, dtype=np.uint8) + 65).tobytes().decode("ascii")
+        for i, name in enumerate(names):
+            s = letters[int(offsets[i]):int(offsets[i + 1])]
+            fh.write(f">{name}\n")
+            for k in range(0, len(s), width):
+                fh.write(s[k:k + width] + "\n")
