@@ -105,7 +105,8 @@ def main():
         my_codes = np.concatenate([cfg["t_codes"][int(cfg["t_off"][i]):int(cfg["t_off"][i + 1])] for i in mine])
         t_codes, t_off = my_codes, my_off
     else:             # DB replicated, queries sharded: --queries per GPU
-        cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen))
+        cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen),
+                                homologs_per_query=max(1, 50 // world))     # same number of planted homologs in the DB at every N
         t_codes, t_off = cfg["t_codes"], cfg["t_off"]
     t_up = time.perf_counter()
     db = s4g.Database(codes=t_codes, offsets=t_off, device=local_rank)

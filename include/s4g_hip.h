@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_create_tiled / s4g_db_destroy / s4g_db_info / s4g_db_tiles
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -94,6 +94,10 @@ int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t
 int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
                         uint32_t max_tile_seqs);
 int s4g_db_destroy(s4g_db* db);
+/* Packed on-disk format: the tiles exactly as they sit in HBM.  s4g_db_save writes a database created from
+ * sequences; s4g_db_load places a saved one on `device` without parsing or packing. */
+int s4g_db_save(const s4g_db* db, const char* path);
+int s4g_db_load(s4g_db** out, int device, const char* path);
 /* number of tiles and (optionally, up to cap entries) sequences per tile */
 int s4g_db_tiles(const s4g_db* db, uint32_t* n_tiles, uint32_t* tile_seqs, uint32_t cap);
 /* any out pointer may be NULL */

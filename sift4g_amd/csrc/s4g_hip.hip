@@ -106,6 +106,7 @@ struct s4g_db {
     mutable int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
     mutable uint64_t tile_scores_bytes = 0;
     mutable uint32_t grid_i32 = 0, grid_i16 = 0;
+    mutable hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
 };
 
 struct s4g_queries {
@@ -346,6 +347,7 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
     for (Tile& t : db->tiles) free_tile(t);
     (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat); (void)hipFree(db->d_qlist);
     (void)hipFree(db->d_tile_scores);
+    if (db->last_use) (void)hipEventDestroy(db->last_use);
     delete db;
     return S4G_OK;
 }
@@ -356,6 +358,96 @@ S4G_API int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, 
     if (residues) *residues = db->residues;
     if (padded_residues) *padded_residues = db->padded_residues;
     if (hbm_bytes) *hbm_bytes = db->hbm_bytes + db->ws_bytes + db->tile_scores_bytes;
+    return S4G_OK;
+}
+
+// ---- packed on-disk format: the length-sorted, lane-transposed tiles exactly as they sit in HBM,
+// so a database is parsed and packed once and later runs only stream it to the device.
+namespace {
+constexpr char kDbMagic[8] = {'S', '4', 'G', 'D', 'B', '0', '0', '2'};
+struct TileHeader { uint32_t n_seqs, n_groups, max_len4, pad; uint64_t residues, padded_residues, pos0, dwords; };
+
+bool put(FILE* f, const void* p, size_t bytes) { return bytes == 0 || fwrite(p, 1, bytes, f) == bytes; }
+bool get(FILE* f, void* p, size_t bytes) { return bytes == 0 || fread(p, 1, bytes, f) == bytes; }
+
+template <typename T>
+bool put_dev(FILE* f, const T* d, size_t n) {
+    std::vector<T> h(n ? n : 1);
+    if (n && hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return put(f, h.data(), n * sizeof(T));
+}
+template <typename T>
+bool get_dev(FILE* f, T** d, size_t n, uint64_t* hbm) {
+    std::vector<T> h(n ? n : 1);
+    if (!get(f, h.data(), n * sizeof(T))) return false;
+    if (hipMalloc((void**)d, (n ? n : 1) * sizeof(T)) != hipSuccess) return false;
+    *hbm += n * sizeof(T);
+    return n == 0 || hipMemcpy(*d, h.data(), n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+}  // namespace
+
+S4G_API int s4g_db_save(const s4g_db* db, const char* path) {
+    if (!db || !path) return fail(S4G_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(db->device);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(S4G_ERR_INVALID, "cannot open '%s' for writing", path);
+    const uint32_t nt = (uint32_t)db->tiles.size();
+    bool ok = put(f, kDbMagic, 8) && put(f, &db->n_seqs, 4) && put(f, &nt, 4) && put(f, &db->residues, 8) &&
+              put(f, &db->padded_residues, 8) && put(f, db->len.data(), (size_t)db->n_seqs * 4) &&
+              put(f, db->pos_of_id.data(), (size_t)db->n_seqs * 4);
+    for (const Tile& t : db->tiles) {
+        if (!ok) break;
+        const uint64_t dwords = t.padded_residues / 4;
+        TileHeader h = {t.n_seqs, t.n_groups, t.max_len4, 0, t.residues, t.padded_residues, t.pos0, dwords};
+        ok = put(f, &h, sizeof h) && put(f, t.h_grp_off.data(), (size_t)t.n_groups * 8) &&
+             put_dev(f, t.d_grp_len4, t.n_groups) && put_dev(f, t.d_perm_global, (size_t)t.n_groups * 64) &&
+             put_dev(f, t.d_perm_local, (size_t)t.n_groups * 64) && put_dev(f, t.d_col_ids, t.n_seqs) && put_dev(f, t.d_res, dwords);
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? S4G_OK : fail(S4G_ERR_HIP, "writing '%s' failed", path);
+}
+
+S4G_API int s4g_db_load(s4g_db** out, int device, const char* path) {
+    if (!out || !path) return fail(S4G_ERR_INVALID, "NULL argument");
+    int have = device_count_raw();
+    if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
+    if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(S4G_ERR_INVALID, "cannot open '%s'", path);
+    DeviceGuard guard(device);
+    s4g_db* db = new s4g_db();
+    db->device = device;
+    char magic[8];
+    uint32_t nt = 0;
+    bool ok = get(f, magic, 8) && memcmp(magic, kDbMagic, 8) == 0 && get(f, &db->n_seqs, 4) && get(f, &nt, 4) &&
+              get(f, &db->residues, 8) && get(f, &db->padded_residues, 8);
+    if (ok) {
+        db->len.resize(db->n_seqs); db->pos_of_id.resize(db->n_seqs);
+        ok = get(f, db->len.data(), (size_t)db->n_seqs * 4) && get(f, db->pos_of_id.data(), (size_t)db->n_seqs * 4);
+    }
+    for (uint32_t i = 0; ok && i < nt; ++i) {
+        TileHeader h;
+        ok = get(f, &h, sizeof h);
+        if (!ok) break;
+        db->tiles.emplace_back();
+        Tile& t = db->tiles.back();
+        t.n_seqs = h.n_seqs; t.n_groups = h.n_groups; t.max_len4 = h.max_len4; t.residues = h.residues;
+        t.padded_residues = h.padded_residues; t.pos0 = h.pos0;
+        t.h_grp_off.resize(h.n_groups);
+        ok = get(f, t.h_grp_off.data(), (size_t)h.n_groups * 8);
+        if (ok) {
+            ok = hipMalloc((void**)&t.d_grp_off, (h.n_groups ? h.n_groups : 1) * 8) == hipSuccess &&
+                 (h.n_groups == 0 || hipMemcpy(t.d_grp_off, t.h_grp_off.data(), (size_t)h.n_groups * 8, hipMemcpyHostToDevice) == hipSuccess);
+            db->hbm_bytes += (uint64_t)h.n_groups * 8;
+        }
+        ok = ok && get_dev(f, &t.d_grp_len4, h.n_groups, &db->hbm_bytes) && get_dev(f, &t.d_perm_global, (size_t)h.n_groups * 64, &db->hbm_bytes) &&
+             get_dev(f, &t.d_perm_local, (size_t)h.n_groups * 64, &db->hbm_bytes) && get_dev(f, &t.d_col_ids, h.n_seqs, &db->hbm_bytes) &&
+             get_dev(f, &t.d_res, h.dwords, &db->hbm_bytes);
+        db->max_tile_seqs = std::max(db->max_tile_seqs, t.n_seqs);
+    }
+    fclose(f);
+    if (!ok) { s4g_db_destroy(db); return fail(S4G_ERR_INVALID, "'%s' is not a readable s4g database file", path); }
+    *out = db;
     return S4G_OK;
 }
 
@@ -569,6 +661,18 @@ int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g
     return S4G_OK;
 }
 
+// The scratch buffers (workspace, work-queue counter, query lists) are shared by all launches on this database:
+// a launch on another stream must not start before the previous one has finished with them.
+int scratch_acquire(const s4g_db* db, hipStream_t stream) {
+    if (!db->last_use) HIP_TRY(hipEventCreateWithFlags(&db->last_use, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, db->last_use, 0));
+    return S4G_OK;
+}
+int scratch_release(const s4g_db* db, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(db->last_use, stream));
+    return S4G_OK;
+}
+
 int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
@@ -611,13 +715,15 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     Plan p;
     rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
     if (rc) return rc;
+    rc = scratch_acquire(db, stream);
+    if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
     for (const Tile& t : db->tiles) {
         rc = launch_tile(db, t, q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
         if (rc) return rc;
     }
-    return S4G_OK;
+    return scratch_release(db, stream);
 }
 
 S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
@@ -864,10 +970,12 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
     std::lock_guard<std::mutex> lk(db->mu);
+    rc = scratch_acquire(db, stream);
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)q_count * k * 4, stream));
     HIP_TRY(hipMemsetAsync(d_top_scores, 0, (size_t)q_count * k * 4, stream));
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)q_count * 4, stream));
-    if (db->n_seqs == 0) return S4G_OK;
+    if (db->n_seqs == 0) return scratch_release(db, stream);
     ensure_bounds(q, scorer);
     const uint64_t cols = db->max_tile_seqs;
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
@@ -887,6 +995,7 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     kpad2 = kpad * 2;
     for (uint32_t b = 0; b < q_count; b += batch) {
         const uint32_t cnt = std::min(batch, q_count - b);
+        if (b) HIP_TRY(hipStreamSynchronize(stream));   // the next batch rewrites the query lists the previous launches read
         Plan p;
         rc = make_plan(db, q, q_begin + b, cnt, scorer, flags, &p);
         if (rc) return rc;
@@ -902,7 +1011,7 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             HIP_TRY(hipGetLastError());
         }
     }
-    return S4G_OK;
+    return scratch_release(db, stream);
 }
 
 S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,

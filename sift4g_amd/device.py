@@ -90,6 +90,23 @@ class Database(_SeqSet):
             self._create_override = create
         super().__init__(seqs, device, codes, offsets)
 
+    def save(self, path):
+        """write the packed tiles (as resident in HBM) to `path`"""
+        check(lib.s4g_db_save(self._h, str(path).encode()), "s4g_db_save")
+
+    @classmethod
+    def load(cls, path, device=0):
+        """place a database saved with save() on `device` without parsing or packing"""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        check(lib.s4g_db_load(ctypes.byref(self._h), device, str(path).encode()), "s4g_db_load")
+        self.device = device
+        info = self.info()
+        self.n = info["n_seqs"]
+        self.codes = self.offsets = None
+        self.lengths = None
+        return self
+
     def tiles(self):
         n = ctypes.c_uint32()
         check(lib.s4g_db_tiles(self._h, ctypes.byref(n), None, 0), "s4g_db_tiles")

@@ -343,3 +343,25 @@ def test_device_traceback_equals_oracle(s4g, oracle_mod, blosum62, scorer):
         assert n_pos > 1000
     with pytest.raises(Exception):                         # a wrong score is detected, not silently traced
         s4g.traceback(db, q, scorer, [0], [0], [int(scores[0, 0]) + 1])
+
+
+def test_packed_database_file_roundtrip(s4g, oracle_mod, blosum62, scorer, tmp_path):
+    """s4g_db_save / s4g_db_load: a database placed from its packed file scans identically (full matrix, streaming
+    top-k and traceback all work off the loaded tiles)."""
+    rng = np.random.default_rng(30)
+    qs = rand_seqs(rng, 5, 40, 200)
+    ts = rand_seqs(rng, 300, 1, 280) + [qs[0][10:150].copy(), rand_seqs(rng, 1, 4200, 4200)[0]]
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    db = s4g.Database(ts, tile_seqs=128)
+    path = tmp_path / "db.s4g"
+    db.save(path)
+    db2 = s4g.Database.load(path)
+    assert db2.n == len(ts) and db2.tiles() == db.tiles() and db2.info()["residues"] == db.info()["residues"]
+    q = s4g.QuerySet(qs)
+    got = s4g.scan_host(db2, q, scorer)
+    assert np.array_equal(got, exp)
+    a = s4g.scan_topk(db, q, scorer, 20, 1); b = s4g.scan_topk(db2, q, scorer, 20, 1)
+    assert all(np.array_equal(x.cpu().numpy(), y.cpu().numpy()) for x, y in zip(a, b))
+    (path.parent / "junk.s4g").write_bytes(b"not a database")
+    with pytest.raises(Exception):
+        s4g.Database.load(path.parent / "junk.s4g")
