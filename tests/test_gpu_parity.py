@@ -365,3 +365,40 @@ def test_packed_database_file_roundtrip(s4g, oracle_mod, blosum62, scorer, tmp_p
     (path.parent / "junk.s4g").write_bytes(b"not a database")
     with pytest.raises(Exception):
         s4g.Database.load(path.parent / "junk.s4g")
+
+
+def test_randomized_configurations(s4g, oracle_mod):
+    """seeded fuzz over everything at once: random symmetric/asymmetric tables, gap penalties, length mixes (empties,
+    singletons, long tails), tile sizes and kernel choice; scan, streaming top-k and traceback against the oracle."""
+    rng = np.random.default_rng(2024)
+    MOVE = {0: 1, 1: 2, 2: 3}
+    for it in range(24):
+        M = rng.integers(-9, 12, size=(26, 26)).astype(np.int32)
+        if it % 3:
+            M = np.triu(M) + np.triu(M, 1).T                 # symmetric most of the time
+        np.fill_diagonal(M, rng.integers(3, 14, size=26))
+        go = int(rng.integers(1, 16)); ge = int(rng.integers(0, go + 1))
+        sc = s4g.Scorer(M, go, ge)
+        nq, nt = int(rng.integers(1, 9)), int(rng.integers(1, 260))
+        qs = rand_seqs(rng, nq, 0, int(rng.choice([5, 40, 130, 400])), 26)
+        ts = rand_seqs(rng, nt, 0, int(rng.choice([3, 60, 200, 700])), 26)
+        if nt > 3 and len(qs[0]) > 20:                       # a few related pairs so scores are not all tiny
+            ts[1] = qs[0][3:].copy()
+            ts[2] = np.concatenate([qs[0][:10], rand_seqs(rng, 1, 4, 4, 26)[0], qs[0][10:]])
+        exp = oracle_mod.scan(qs, ts, M, go, ge, threads=8)
+        db = s4g.Database(ts, tile_seqs=int(rng.choice([0, 64, 128])))
+        q = s4g.QuerySet(qs)
+        force = bool(it % 2)
+        got = s4g.scan_host(db, q, sc, force_i32=force)
+        assert np.array_equal(got, exp), (it, go, ge)
+        k = int(rng.integers(1, 50))
+        ids, tsc, cnt = s4g.scan_topk(db, q, sc, k, 1, force_i32=force)
+        for i in range(nq):
+            order = sorted((j for j in range(nt) if exp[i, j] >= 1), key=lambda j: (-exp[i, j], j))[:k]
+            assert ids[i, :len(order)].cpu().tolist() == order and int(cnt[i]) == len(order)
+        pq = rng.integers(0, nq, size=40); pt = rng.integers(0, nt, size=40)
+        for a, b, r in zip(pq, pt, s4g.traceback(db, q, sc, pq, pt, exp[pq, pt])):
+            o = oracle_mod.sw_align(qs[a], ts[b], M, go, ge)
+            assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (it, a, b)
+            if o["score"]:
+                assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
