@@ -117,9 +117,11 @@ int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uin
 int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
              const s4g_scorer* scorer, int32_t* d_scores, void* stream);
 
-/* s4g_scan with options.  flags: S4G_SCAN_FORCE_I32 = run every query through the int32 kernel (by default
- * queries whose score bound fits in int16 run in the packed int16x2 kernel, which is exact for them). */
+/* s4g_scan with options.  By default every query runs in the fastest kernel that is EXACT for it, decided from
+ * its score bound sum_i max(0, max_b table[q_i][b]): packed f16 (bound <= 4096), packed int16 (bound <= 32767),
+ * else int32.  flags: S4G_SCAN_FORCE_I32 = int32 kernel for every query; S4G_SCAN_NO_F16 = skip the f16 tier. */
 #define S4G_SCAN_FORCE_I32 1u
+#define S4G_SCAN_NO_F16    2u   /* do not use the packed f16 kernel (queries with score bound <= 4096 then run in int16) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
                    const s4g_scorer* scorer, int32_t* d_scores, void* stream, uint32_t flags);
 

@@ -105,7 +105,7 @@ struct s4g_db {
     mutable uint64_t qlist_cap = 0;
     mutable int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
     mutable uint64_t tile_scores_bytes = 0;
-    mutable uint32_t grid_i32 = 0, grid_i16 = 0;
+    mutable uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0;
     mutable hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
 };
 
@@ -529,8 +529,9 @@ constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of 
 
 struct Plan {
     std::vector<uint32_t> pairs;    // i16x2 work: 2 ids per pair (second may be ~0u)
+    std::vector<uint32_t> hpairs;   // f16x2 work: pairs whose score bound fits the 4096-wide exact f16 window
     std::vector<uint32_t> wide;     // i32 work: query ids whose score bound exceeds int16
-    uint32_t grid_i32 = 0, grid_i16 = 0;   // full persistent grids
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0;   // full persistent grids
     uint64_t ws_bytes = 0;                 // workspace needed for the largest tile launch
 };
 
@@ -575,24 +576,34 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
               uint32_t flags, Plan* p) {
     int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &db->grid_i32);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_i16x2<kStripRows16>, &db->grid_i16);
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &db->grid_i16);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithF16, kStripRows16>, &db->grid_f16);
     if (rc) return rc;
     p->grid_i32 = db->grid_i32;
     p->grid_i16 = db->grid_i16;
+    p->grid_f16 = db->grid_f16;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
-    std::vector<uint32_t> narrow;
+    const bool gapsf16 = sc->open <= 2048 && sc->ext <= 2048;
+    std::vector<uint32_t> narrow, tiny;
     for (uint32_t i = 0; i < q_count; ++i) {
         const uint32_t id = q_begin + i;
-        const bool fits = q->score_bound[id] <= 32767 && gaps16 && !(flags & S4G_SCAN_FORCE_I32);
-        (fits ? narrow : p->wide).push_back(id);
+        const uint64_t b = q->score_bound[id];
+        if (b <= 4096 && gapsf16 && !(flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16))) tiny.push_back(id);
+        else if (b <= 32767 && gaps16 && !(flags & S4G_SCAN_FORCE_I32)) narrow.push_back(id);
+        else p->wide.push_back(id);
     }
     // pair queries of similar length (the pair runs to the longer one); longest pairs first
-    std::stable_sort(narrow.begin(), narrow.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
-    for (size_t i = 0; i < narrow.size(); i += 2) {
-        p->pairs.push_back(narrow[i]);
-        p->pairs.push_back(i + 1 < narrow.size() ? narrow[i + 1] : 0xFFFFFFFFu);
-    }
-    const uint32_t full = std::max(p->grid_i32, p->grid_i16);
+    auto make_pairs = [&](std::vector<uint32_t>& ids, std::vector<uint32_t>& out) {
+        std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
+        for (size_t i = 0; i < ids.size(); i += 2) {
+            out.push_back(ids[i]);
+            out.push_back(i + 1 < ids.size() ? ids[i + 1] : 0xFFFFFFFFu);
+        }
+    };
+    make_pairs(narrow, p->pairs);
+    make_pairs(tiny, p->hpairs);
+    const uint32_t full = std::max(std::max(p->grid_i32, p->grid_i16), p->grid_f16);
     for (const Tile& t : db->tiles)
         p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
     return S4G_OK;
@@ -607,7 +618,7 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
     }
     if (!db->d_counter) HIP_TRY(hipMalloc((void**)&db->d_counter, 256));
     if (!db->d_mat) HIP_TRY(hipMalloc((void**)&db->d_mat, 1024));
-    const uint64_t need = p.pairs.size() + p.wide.size();
+    const uint64_t need = p.pairs.size() + p.hpairs.size() + p.wide.size();
     if (db->qlist_cap < need) {
         if (db->d_qlist) HIP_TRY(hipFree(db->d_qlist));
         db->d_qlist = nullptr; db->qlist_cap = 0;
@@ -619,6 +630,8 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
         HIP_TRY(hipMemcpyAsync(db->d_qlist, p.pairs.data(), p.pairs.size() * 4, hipMemcpyHostToDevice, stream));
     if (!p.wide.empty())
         HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size(), p.wide.data(), p.wide.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!p.hpairs.empty())
+        HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size() + p.wide.size(), p.hpairs.data(), p.hpairs.size() * 4, hipMemcpyHostToDevice, stream));
     return S4G_OK;
 }
 
@@ -627,9 +640,23 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
 int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p, uint32_t q_begin,
                 int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream) {
     if (t.n_seqs == 0) return S4G_OK;
-    if ((uint64_t)t.n_groups * std::max<uint64_t>(p.pairs.size() / 2, p.wide.size()) >= 0xFFFFFFFFull)
+    if ((uint64_t)t.n_groups * std::max<uint64_t>(std::max(p.pairs.size(), p.hpairs.size()) / 2, p.wide.size()) >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
-    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 12, stream));
+    if (!p.hpairs.empty()) {
+        ScanArgs16 a;
+        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+        a.pairs = db->d_qlist + p.pairs.size() + p.wide.size();
+        a.mat = db->d_mat;
+        a.scores = d_scores; a.score_stride = stride;
+        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
+        a.counter = db->d_counter + 2;
+        a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.hpairs.size() / 2); a.q_begin = q_begin;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
     if (!p.pairs.empty()) {
         ScanArgs16 a;
         a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
@@ -641,7 +668,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g
         a.counter = db->d_counter;
         a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i16x2<kStripRows16>, dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (!p.wide.empty()) {
@@ -692,12 +719,13 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     Plan p;
     int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
     if (rc) return rc;
-    const bool i16 = p.pairs.size() >= p.wide.size();       // report the kernel that carries most of the queries
-    if (kernel_name && kernel_name_cap)
-        snprintf(kernel_name, kernel_name_cap, "%s", i16 ? "sw_scan_i16x2<32>" : "sw_scan_i32<32>");
-    if (grid_blocks) *grid_blocks = i16 ? p.grid_i16 : p.grid_i32;
+    // report the kernel that carries most of the queries
+    const size_t nh = p.hpairs.size(), ni = p.pairs.size(), nw = p.wide.size() * 2;
+    const char* name = (nh >= ni && nh >= nw) ? "sw_scan_pk<ArithF16,32>" : (ni >= nw ? "sw_scan_pk<ArithI16,32>" : "sw_scan_i32<32>");
+    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", name);
+    if (grid_blocks) *grid_blocks = (nh >= ni && nh >= nw) ? p.grid_f16 : (ni >= nw ? p.grid_i16 : p.grid_i32);
     if (block_threads) *block_threads = kBlock;
-    if (strip_rows) *strip_rows = i16 ? kStripRows16 : kStripRows;
+    if (strip_rows) *strip_rows = (nh >= ni || ni >= nw) ? kStripRows16 : kStripRows;
     if (workspace_bytes) *workspace_bytes = p.ws_bytes;
     return S4G_OK;
 }

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
 // routes queries here whose upper bound  sum_i max_b M[q_i][b]  is <= 32767 (ScanArgs16 contract); everything else
 // goes to sw_scan_i32.  Scores are widened to int32 on output.
 //
+// A second arithmetic policy (ArithF16, below) runs the same kernel in packed f16 with gfx950's v_pk_maximum3_f16
+// for queries whose score bound is <= 4096: 7.5 ops per pair of cells.
+//
 // Strip profile (wave-private LDS): prof[kk][t][4 rows] of packed (sB << 16 | sA) int16 pairs, 16 B per (kk, t):
 // one ds_read_b128 per lane per 4 rows.  Strip boundary rows (H, F of the strip's last row) are packed pairs too:
 // 16 B per lane per 4 columns each way for 2 x R cells -> half the HBM bytes per cell of the int32 kernel.
@@ -244,19 +247,63 @@ __device__ __forceinline__ int as_i(v2us x) { return __builtin_bit_cast(int, x);
 __device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ v2us pk_subs(v2us a, v2us b) { return __builtin_elementwise_sub_sat(a, b); }
 
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2h as_h(int x) { return __builtin_bit_cast(v2h, x); }
+__device__ __forceinline__ int as_i(v2h x) { return __builtin_bit_cast(int, x); }
+
+// ---- arithmetic policies of the packed kernel: every register is a raw 32-bit pair ----
+// ArithI16: packed int16, E/F clamped at 0 by saturating subtracts.  9 ops per pair of cells.
+struct ArithI16 {
+    static constexpr bool kMax3 = false;
+    static __device__ __forceinline__ int floor_() { return 0; }
+    static __device__ __forceinline__ int pen(unsigned p) { return (int)(p | (p << 16)); }
+    static __device__ __forceinline__ int add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
+    static __device__ __forceinline__ int hmax(int s, int e, int f) { return as_i(pk_max(pk_max(as_s(s), as_s(e)), as_s(f))); }
+    static __device__ __forceinline__ int sub(int x, int p) { return as_i(pk_subs(as_u(x), as_u(p))); }
+    static __device__ __forceinline__ int gmax(int a, int b) { return as_i(pk_max(as_s(a), as_s(b))); }
+    static __device__ __forceinline__ int best1(int best, int h) { return as_i(pk_max(as_s(best), as_s(h))); }
+    static __device__ __forceinline__ int best2(int best, int h0, int h1) { return best1(best1(best, h0), h1); }
+    static __device__ __forceinline__ int pair(int sA, int sB) { return (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16)); }
+    static __device__ __forceinline__ int out(int best, int half) { return (int)as_s(best)[half]; }
+};
+
+// ArithF16: packed f16 holding the integer H - 2048 (f16 is exact on integers in [-2048, 2048], so any score up to
+// 4096 is exact; values below the floor -2048 may round, but rounding is monotone and they are floored away).
+// gfx950's v_pk_maximum3_f16 is the only packed 3-input max: H = maximum3(diag+s, E, F), E' = maximum3(E-ext,
+// h-open, floor), running max over row pairs -> 7.5 ops per pair of cells.
+struct ArithF16 {
+    static constexpr bool kMax3 = true;
+    static __device__ __forceinline__ int floor_() { return (int)0xE800E800u; }          // (-2048.0h, -2048.0h)
+    static __device__ __forceinline__ int pen(unsigned p) { const _Float16 v = (_Float16)(-(float)p); v2h x = {v, v}; return as_i(x); }
+    static __device__ __forceinline__ int max3(int a, int b, int c) {
+        int d;
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
+    static __device__ __forceinline__ int add(int a, int b) { return as_i(as_h(a) + as_h(b)); }
+    static __device__ __forceinline__ int hmax(int s, int e, int f) { return max3(s, e, f); }
+    static __device__ __forceinline__ int sub(int x, int p) { return add(x, p); }          // p holds -penalty; floored by gmax
+    static __device__ __forceinline__ int gmax(int a, int b) { return max3(a, b, floor_()); }
+    static __device__ __forceinline__ int best1(int best, int h) { return max3(best, h, h); }
+    static __device__ __forceinline__ int best2(int best, int h0, int h1) { return max3(best, h0, h1); }
+    static __device__ __forceinline__ int pair(int sA, int sB) { v2h x = {(_Float16)(float)sA, (_Float16)(float)sB}; return as_i(x); }
+    static __device__ __forceinline__ int out(int best, int half) { return (int)(float)as_h(best)[half] + 2048; }
+};
+
 // 8 rows (row0 .. row0+7) of one column; sc = their 8 packed score pairs
-template <int R>
-__device__ __forceinline__ void pk_rows8(v2s (&H)[R], v2us (&E)[R], int row0, const v4i (&sc)[2], v2s& diag, v2us& F,
-                                         v2s& best, v2us open, v2us ext) {
+template <class A, int R>
+__device__ __forceinline__ void pk_rows8(int (&H)[R], int (&E)[R], int row0, const v4i (&sc)[2], int& diag, int& F,
+                                         int& best, int open, int ext) {
+    int hprev = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = row0 + i;
-        const v2s s = as_s(sc[i / 4][i % 4]);
-        v2s h = pk_max(pk_max(diag + s, as_s(E[r])), as_s(F));
-        best = pk_max(best, h);
-        const v2us hm = pk_subs(as_u(h), open);
-        E[r] = as_u(pk_max(as_s(pk_subs(E[r], ext)), as_s(hm)));
-        F = as_u(pk_max(as_s(pk_subs(F, ext)), as_s(hm)));
+        const int h = A::hmax(A::add(diag, sc[i / 4][i % 4]), E[r], F);
+        if constexpr (A::kMax3) { if (i & 1) best = A::best2(best, hprev, h); else hprev = h; }
+        else best = A::best1(best, h);
+        const int hm = A::sub(h, open);
+        E[r] = A::gmax(A::sub(E[r], ext), hm);
+        F = A::gmax(A::sub(F, ext), hm);
         diag = H[r];
         H[r] = h;
     }
@@ -272,17 +319,18 @@ __device__ __forceinline__ unsigned pk_taddr(uint32_t r4, int cc) {
 }
 
 // One strip of RR rows (RR multiple of 8) over all columns of the group.
-template <int R, int RR>
+template <class A, int R, int RR>
 __device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
-                                         bool first, bool last, v2s& best, v2us open, v2us ext) {
+                                         bool first, bool last, int& best, int open, int ext) {
     constexpr int NB = RR / 8;
-    v2s H[R];
-    v2us E[R];
+    const int fl = A::floor_();
+    int H[R];
+    int E[R];
 #pragma unroll
-    for (int r = 0; r < RR; ++r) { H[r] = as_s(0); E[r] = as_u(0); }
-    v2s hdiag = as_s(0);
+    for (int r = 0; r < RR; ++r) { H[r] = fl; E[r] = fl; }
+    int hdiag = fl;
     uint32_t res_n = res[0];
-    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+    v4i hb_n = {fl, fl, fl, fl}, fb_n = {fl, fl, fl, fl};
     if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
     v4i sc_n[2];
     pk_load8(sc_n, prof, pk_taddr(res_n, 0), 0);
@@ -297,17 +345,17 @@ __device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, con
         for (int cc = 0; cc < 4; ++cc) {
             const unsigned taddr = pk_taddr(r4, cc);
             const unsigned taddr_next = cc < 3 ? pk_taddr(r4, cc + 1) : pk_taddr(res_n, 0);
-            v2s diag = hdiag;
-            v2us F = as_u(fb[cc]);
+            int diag = hdiag;
+            int F = fb[cc];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 v4i sc[2] = {sc_n[0], sc_n[1]};
                 if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
-                pk_rows8<R>(H, E, 8 * b, sc, diag, F, best, open, ext);
+                pk_rows8<A, R>(H, E, 8 * b, sc, diag, F, best, open, ext);
             }
-            hdiag = as_s(hb[cc]);
-            ho[cc] = as_i(H[RR - 1]);
-            fo[cc] = as_i(F);
+            hdiag = hb[cc];
+            ho[cc] = H[RR - 1];
+            fo[cc] = F;
             asm volatile("" : "+v"(best));          // pin the running maximum per column (see sw_scan_i32)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -315,8 +363,8 @@ __device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, con
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
+template <class A, int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
     __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 128];
     const int lane = threadIdx.x & 63;
@@ -331,8 +379,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
     const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
     v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
     const unsigned n_items = a.n_groups * a.n_pairs;
-    const v2us open = as_u((int)(a.open | (a.open << 16)));
-    const v2us ext = as_u((int)(a.ext | (a.ext << 16)));
+    const int open = A::pen(a.open);
+    const int ext = A::pen(a.ext);
 
     for (;;) {
         unsigned item = 0;
@@ -353,12 +401,12 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
-        v2s best = as_s(0);
+        int best = A::floor_();
 
         for (unsigned s = 0; s < nstrips; ++s) {
             const unsigned rows_left = lq - s * R;
             const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;   // rows this strip computes
-            // ---- strip profile: prof[kk][t] = 4 rows of (sB << 16 | sA) ----
+            // ---- strip profile: prof[kk][t] = 4 rows of packed (query A, query B) scores ----
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int e0 = 0; e0 < 8 * R; e0 += 64) {
@@ -369,11 +417,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
                 const unsigned cB = row0 < capB ? *reinterpret_cast<const unsigned*>(qcB + row0) : 0x1F1F1F1Fu;
                 v4i out;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int sA = lmat[((cA >> (8 * d)) & 31u) * 32 + t];
-                    const int sB = lmat[((cB >> (8 * d)) & 31u) * 32 + t];
-                    out[d] = (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16));
-                }
+                for (int d = 0; d < 4; ++d)
+                    out[d] = A::pair(lmat[((cA >> (8 * d)) & 31u) * 32 + t], lmat[((cB >> (8 * d)) & 31u) * 32 + t]);
                 *reinterpret_cast<v4i*>(prof + e * 16) = out;
             }
             __builtin_amdgcn_wave_barrier();
@@ -382,16 +427,16 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i16x2(const ScanArgs16 a) {
             bool done = false;
 #define S4G_LAST_STRIP(RR_)                                                                                  \
             if constexpr (R > RR_) {                                                                         \
-                if (!done && rr == RR_) { pk_strip<R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext); done = true; } \
+                if (!done && rr == RR_) { pk_strip<A, R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext); done = true; } \
             }
             S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
 #undef S4G_LAST_STRIP
-            if (!done) pk_strip<R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext);   // full strip (or rr > 40)
+            if (!done) pk_strip<A, R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext);   // full strip (or rr > 40)
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) {
-            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = (int)best[0];
-            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = (int)best[1];
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = A::out(best, 0);
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = A::out(best, 1);
         }
     }
 }

@@ -23,10 +23,11 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     db = s4g.Database(targets)
     qs = s4g.QuerySet(queries)
     exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
-    for force_i32 in (False, True):       # default plan (packed int16x2 where exact, int32 otherwise) and the int32 kernel alone
-        got = s4g.scan_host(db, qs, scorer, force_i32=force_i32)
+    # default plan (fastest exact kernel per query: packed f16 / packed int16 / int32), without the f16 tier, int32 alone
+    for mode in (dict(), dict(no_f16=True), dict(force_i32=True)):
+        got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
-        assert bad.size == 0, (f"force_i32={force_i32}: {len(bad)} mismatches, first {bad[:5].tolist()} "
+        assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
                                f"got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}")
     return got
 
@@ -131,6 +132,24 @@ def test_int16_bound_routing(s4g, oracle_mod, blosum62, scorer):
     ts = [np.full(3400, W, dtype=np.uint8), np.full(2978, W, dtype=np.uint8)] + rand_seqs(rng, 70, 50, 500)
     got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
     assert got[0, 0] == 3300 * 11 and got[1, 0] == 2978 * 11 == 32758 and got[1, 1] == 32758
+
+
+def test_f16_window_routing(s4g, oracle_mod, blosum62, scorer):
+    """the packed f16 kernel is exact on scores up to 4096 (integers H - 2048 in f16): queries whose bound is just
+    inside / outside the window, scores that reach the top of the window, and large gap penalties."""
+    W, A = ord("W") - 65, 0
+    inside = np.full(372, W, dtype=np.uint8)                   # bound 4092 <= 4096 -> f16 kernel, score up to 4092
+    outside = np.full(373, W, dtype=np.uint8)                  # bound 4103 -> packed int16
+    rng = np.random.default_rng(32)
+    qs = [inside, outside, np.full(1000, A, dtype=np.uint8)] + rand_seqs(rng, 5, 100, 700)   # poly-A 1000: bound 4000
+    ts = [np.full(400, W, dtype=np.uint8), np.full(372, W, dtype=np.uint8), np.full(1500, A, dtype=np.uint8),
+          np.concatenate([np.full(186, W, dtype=np.uint8), rand_seqs(rng, 1, 3, 3)[0], np.full(186, W, dtype=np.uint8)])]
+    ts += rand_seqs(rng, 80, 50, 600)
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert got[0, 0] == 4092 and got[1, 0] == 4103 and got[2, 2] == 4000
+    for go, ge in ((2048, 2048), (40, 1), (3000, 7)):          # gap penalties at / beyond the f16 window
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        _check(s4g, oracle_mod, blosum62, qs[:4], ts[:30], sc, go, ge)
 
 
 def test_odd_query_counts_and_unequal_pairs(s4g, oracle_mod, blosum62, scorer):
@@ -274,8 +293,8 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         assert sum(tiles) == len(ts)
         if tile_seqs == 64:
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 4096-residue sequences form their own tile
-        for force in (False, True):
-            assert np.array_equal(s4g.scan_host(db, q, scorer, force_i32=force), exp)
+        for mode in (dict(), dict(no_f16=True), dict(force_i32=True)):
+            assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
 def test_streaming_scan_topk_equals_full_matrix_topk(s4g, oracle_mod, blosum62, scorer):
@@ -388,11 +407,11 @@ def test_randomized_configurations(s4g, oracle_mod):
         exp = oracle_mod.scan(qs, ts, M, go, ge, threads=8)
         db = s4g.Database(ts, tile_seqs=int(rng.choice([0, 64, 128])))
         q = s4g.QuerySet(qs)
-        force = bool(it % 2)
-        got = s4g.scan_host(db, q, sc, force_i32=force)
-        assert np.array_equal(got, exp), (it, go, ge)
+        mode = [dict(), dict(no_f16=True), dict(force_i32=True)][it % 3]
+        got = s4g.scan_host(db, q, sc, **mode)
+        assert np.array_equal(got, exp), (it, go, ge, mode)
         k = int(rng.integers(1, 50))
-        ids, tsc, cnt = s4g.scan_topk(db, q, sc, k, 1, force_i32=force)
+        ids, tsc, cnt = s4g.scan_topk(db, q, sc, k, 1, **mode)
         for i in range(nq):
             order = sorted((j for j in range(nt) if exp[i, j] >= 1), key=lambda j: (-exp[i, j], j))[:k]
             assert ids[i, :len(order)].cpu().tolist() == order and int(cnt[i]) == len(order)
