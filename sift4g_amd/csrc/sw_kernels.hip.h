@@ -275,10 +275,8 @@ struct ArithF16 {
     static constexpr bool kMax3 = true;
     static __device__ __forceinline__ int floor_() { return (int)0xE800E800u; }          // (-2048.0h, -2048.0h)
     static __device__ __forceinline__ int pen(unsigned p) { const _Float16 v = (_Float16)(-(float)p); v2h x = {v, v}; return as_i(x); }
-    static __device__ __forceinline__ int max3(int a, int b, int c) {
-        int d;
-        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-        return d;
+    static __device__ __forceinline__ int max3(int a, int b, int c) {   // hipcc fuses this into one v_pk_maximum3_f16 (no asm: an
+        return as_i(__builtin_elementwise_maximum(__builtin_elementwise_maximum(as_h(a), as_h(b)), as_h(c)));   // asm statement costs an s_nop pad)
     }
     static __device__ __forceinline__ int add(int a, int b) { return as_i(as_h(a) + as_h(b)); }
     static __device__ __forceinline__ int hmax(int s, int e, int f) { return max3(s, e, f); }
