@@ -123,7 +123,7 @@ def main():
     plan = scan_plan(db, allq, scorer)
     if args.force_i32:
         plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
-    elif args.no_f16 and "F16" in plan["kernel"]:
+    elif args.no_f16 and "M3" in plan["kernel"]:
         plan["kernel"] = "sw_scan_pk<ArithI16,32>"
     scores = None if db_shard else torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
     gids = torch.from_numpy(mine.astype(np.int64)).to(dev) if db_shard else None
@@ -183,7 +183,7 @@ def main():
             "metric": "GCUPS (SW cell updates/s) on query x DB scan",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if "F16" in plan["kernel"] else ("int16" if "I16" in plan["kernel"] else "int32"), "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if "I16" in plan["kernel"] else ("f16" if "F16" in plan["kernel"] else "int32"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] generator: {args.queries} synthetic queries/GPU len U[{args.qlen[0]},{args.qlen[1]}] x "
                                    f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
                                    f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",

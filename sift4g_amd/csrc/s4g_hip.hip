@@ -66,7 +66,7 @@ struct s4g_scorer {
     int32_t table[26 * 26];
     int8_t mat32[32 * 32];
     int open, ext;
-    int max_score;
+    int max_score, min_score;
     int row_max[32];        // max(0, max_b table[a][b]): per-row bound on what one DP row can add
     uint64_t serial;        // identity for caches keyed on the scorer
 };
@@ -159,6 +159,7 @@ S4G_API int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_op
     s->open = gap_open;
     s->ext = gap_extend;
     s->max_score = 0;
+    s->min_score = 0;
     for (int i = 0; i < 32 * 32; ++i) s->mat32[i] = (int8_t)kPadScore;
     for (int a = 0; a < 26; ++a)
         for (int b = 0; b < 26; ++b) {
@@ -167,6 +168,7 @@ S4G_API int s4g_scorer_create(s4g_scorer** out, const int32_t* table, int gap_op
             s->table[a * 26 + b] = v;
             s->mat32[a * 32 + b] = (int8_t)v;
             s->max_score = std::max(s->max_score, v);
+            s->min_score = std::min(s->min_score, v);
         }
     for (int a = 0; a < 32; ++a) {
         s->row_max[a] = 0;
@@ -529,7 +531,9 @@ constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of 
 
 struct Plan {
     std::vector<uint32_t> pairs;    // i16x2 work: 2 ids per pair (second may be ~0u)
-    std::vector<uint32_t> hpairs;   // f16x2 work: pairs whose score bound fits the 4096-wide exact f16 window
+    std::vector<uint32_t> hpairs;   // maximum3 tier: pairs whose score bound fits the window of the v_pk_maximum3_f16 policy
+    bool f16_arith = false;         // maximum3 tier runs ArithF16 (window 4096) instead of ArithI16M3 (window 0x7BFF - bias)
+    uint32_t bias = 0;              // ArithI16M3 bias B
     std::vector<uint32_t> wide;     // i32 work: query ids whose score bound exceeds int16
     uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0;   // full persistent grids
     uint64_t ws_bytes = 0;                 // workspace needed for the largest tile launch
@@ -578,18 +582,23 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     if (rc) return rc;
     rc = grid_for(db, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &db->grid_i16);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_pk<ArithF16, kStripRows16>, &db->grid_f16);
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &db->grid_f16);
     if (rc) return rc;
     p->grid_i32 = db->grid_i32;
     p->grid_i16 = db->grid_i16;
     p->grid_f16 = db->grid_f16;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
-    const bool gapsf16 = sc->open <= 2048 && sc->ext <= 2048;
+    // maximum3 tier: ArithI16M3 keeps every operand a non-negative int16 below the f16 infinity pattern (0x7C00) with the
+    // bias B = max(64 = -pad score, open, ext, -min table entry); ArithF16 (on request) is exact on scores up to 4096.
+    p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
+    p->bias = (uint32_t)std::max(std::max(-kPadScore, -sc->min_score), std::max(sc->open, sc->ext));
+    const uint64_t m3_window = p->f16_arith ? 4096 : (p->bias < 0x7BFF ? 0x7BFF - p->bias : 0);
+    const bool m3_gaps = p->f16_arith ? (sc->open <= 2048 && sc->ext <= 2048) : gaps16;
     std::vector<uint32_t> narrow, tiny;
     for (uint32_t i = 0; i < q_count; ++i) {
         const uint32_t id = q_begin + i;
         const uint64_t b = q->score_bound[id];
-        if (b <= 4096 && gapsf16 && !(flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16))) tiny.push_back(id);
+        if (b <= m3_window && m3_gaps && !(flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16))) tiny.push_back(id);
         else if (b <= 32767 && gaps16 && !(flags & S4G_SCAN_FORCE_I32)) narrow.push_back(id);
         else p->wide.push_back(id);
     }
@@ -654,7 +663,13 @@ int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g
         a.counter = db->d_counter + 2;
         a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.hpairs.size() / 2); a.q_begin = q_begin;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+        if (p.f16_arith) {
+            a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
+            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+        } else {
+            a.floor_bits = p.bias | (p.bias << 16);
+            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (!p.pairs.empty()) {
@@ -668,6 +683,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g
         a.counter = db->d_counter;
         a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        a.floor_bits = 0;
         hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
@@ -721,7 +737,7 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     if (rc) return rc;
     // report the kernel that carries most of the queries
     const size_t nh = p.hpairs.size(), ni = p.pairs.size(), nw = p.wide.size() * 2;
-    const char* name = (nh >= ni && nh >= nw) ? "sw_scan_pk<ArithF16,32>" : (ni >= nw ? "sw_scan_pk<ArithI16,32>" : "sw_scan_i32<32>");
+    const char* name = (nh >= ni && nh >= nw) ? "sw_scan_pk<ArithI16M3,32>" : (ni >= nw ? "sw_scan_pk<ArithI16,32>" : "sw_scan_i32<32>");
     if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", name);
     if (grid_blocks) *grid_blocks = (nh >= ni && nh >= nw) ? p.grid_f16 : (ni >= nw ? p.grid_i16 : p.grid_i32);
     if (block_threads) *block_threads = kBlock;

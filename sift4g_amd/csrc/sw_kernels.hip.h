@@ -208,8 +208,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
 // routes queries here whose upper bound  sum_i max_b M[q_i][b]  is <= 32767 (ScanArgs16 contract); everything else
 // goes to sw_scan_i32.  Scores are widened to int32 on output.
 //
-// A second arithmetic policy (ArithF16, below) runs the same kernel in packed f16 with gfx950's v_pk_maximum3_f16
-// for queries whose score bound is <= 4096: 7.5 ops per pair of cells.
+// Further arithmetic policies (ArithI16M3, ArithF16 below) run the same kernel with gfx950's v_pk_maximum3_f16 as the
+// three-input max: 7.5 ops per pair of cells.
 //
 // Strip profile (wave-private LDS): prof[kk][t][4 rows] of packed (sB << 16 | sA) int16 pairs, 16 B per (kk, t):
 // one ds_read_b128 per lane per 4 rows.  Strip boundary rows (H, F of the strip's last row) are packed pairs too:
@@ -236,6 +236,7 @@ struct ScanArgs16 {
     unsigned* counter;
     uint32_t n_groups, n_pairs, q_begin;
     uint32_t open, ext;                      // each < 2^15
+    uint32_t floor_bits;                     // packed floor of the arithmetic policy (see Arith*)
 };
 
 __device__ __forceinline__ v2s as_s(v2us x) { return __builtin_bit_cast(v2s, x); }
@@ -251,47 +252,68 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2h as_h(int x) { return __builtin_bit_cast(v2h, x); }
 __device__ __forceinline__ int as_i(v2h x) { return __builtin_bit_cast(int, x); }
 
-// ---- arithmetic policies of the packed kernel: every register is a raw 32-bit pair ----
-// ArithI16: packed int16, E/F clamped at 0 by saturating subtracts.  9 ops per pair of cells.
+// ---- arithmetic policies of the packed kernel: every register is a raw 32-bit pair; `fl` = packed floor value ----
+// ArithI16: packed int16, E/F clamped at 0 by saturating subtracts.  9 ops per pair of cells.  fl = 0.
 struct ArithI16 {
     static constexpr bool kMax3 = false;
-    static __device__ __forceinline__ int floor_() { return 0; }
     static __device__ __forceinline__ int pen(unsigned p) { return (int)(p | (p << 16)); }
     static __device__ __forceinline__ int add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
     static __device__ __forceinline__ int hmax(int s, int e, int f) { return as_i(pk_max(pk_max(as_s(s), as_s(e)), as_s(f))); }
     static __device__ __forceinline__ int sub(int x, int p) { return as_i(pk_subs(as_u(x), as_u(p))); }
-    static __device__ __forceinline__ int gmax(int a, int b) { return as_i(pk_max(as_s(a), as_s(b))); }
+    static __device__ __forceinline__ int gmax(int a, int b, int) { return as_i(pk_max(as_s(a), as_s(b))); }
     static __device__ __forceinline__ int best1(int best, int h) { return as_i(pk_max(as_s(best), as_s(h))); }
     static __device__ __forceinline__ int best2(int best, int h0, int h1) { return best1(best1(best, h0), h1); }
     static __device__ __forceinline__ int pair(int sA, int sB) { return (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16)); }
-    static __device__ __forceinline__ int out(int best, int half) { return (int)as_s(best)[half]; }
+    static __device__ __forceinline__ int out(int best, int half, int) { return (int)as_s(best)[half]; }
 };
 
-// ArithF16: packed f16 holding the integer H - 2048 (f16 is exact on integers in [-2048, 2048], so any score up to
-// 4096 is exact; values below the floor -2048 may round, but rounding is monotone and they are floored away).
-// gfx950's v_pk_maximum3_f16 is the only packed 3-input max: H = maximum3(diag+s, E, F), E' = maximum3(E-ext,
-// h-open, floor), running max over row pairs -> 7.5 ops per pair of cells.
+// v_pk_maximum3_f16 is gfx950's only packed three-input max.  Both policies below emit it from nested
+// __builtin_elementwise_maximum (an asm statement would cost an s_nop pad each).
+__device__ __forceinline__ int pk_maximum3(int a, int b, int c) {
+    return as_i(__builtin_elementwise_maximum(__builtin_elementwise_maximum(as_h(a), as_h(b)), as_h(c)));
+}
+
+// ArithI16M3: packed int16 whose three-input max is v_pk_maximum3_f16 applied to the RAW INTEGER BIT PATTERNS.
+// For bit patterns 0x0000 .. 0x7BFF (non-negative, below the f16 infinity encoding) the IEEE-754 order of the f16
+// values equals the order of the integers, and a max returns one of its inputs bit for bit (kernels run with f16
+// denormals preserved: .amdhsa_float_denorm_mode_16_64 3, hipcc's default), so on such operands the instruction IS an
+// integer max3.  Every value is kept >= 0 by storing H, E, F with a bias `fl` = B >= max(open, ext, -min score):
+// diag+s >= 0, E-ext >= 0, h-open >= 0, and the floor max(., B) replaces the clamp at 0.  Exact while
+// bound + B <= 0x7BFF.  4 integer add/sub + 3.5 maximum3 = 7.5 ops per pair of cells.
+struct ArithI16M3 {
+    static constexpr bool kMax3 = true;
+    static __device__ __forceinline__ int pen(unsigned p) { return (int)(p | (p << 16)); }
+    static __device__ __forceinline__ int add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
+    static __device__ __forceinline__ int hmax(int s, int e, int f) { return pk_maximum3(s, e, f); }
+    static __device__ __forceinline__ int sub(int x, int p) { return as_i(as_s(x) - as_s(p)); }       // never wraps: x >= B >= p
+    static __device__ __forceinline__ int gmax(int a, int b, int fl) { return pk_maximum3(a, b, fl); }
+    static __device__ __forceinline__ int best1(int best, int h) { return pk_maximum3(best, h, h); }
+    static __device__ __forceinline__ int best2(int best, int h0, int h1) { return pk_maximum3(best, h0, h1); }
+    static __device__ __forceinline__ int pair(int sA, int sB) { return (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16)); }
+    static __device__ __forceinline__ int out(int best, int half, int fl) { return (int)as_s(best)[half] - (int)as_s(fl)[0]; }
+};
+
+// ArithF16: packed f16 ARITHMETIC on the integer H - 2048 (f16 is exact on integers in [-2048, 2048], so any score up
+// to 4096 is exact; values below the floor may round, but rounding is monotone and they are floored away).
+// fl = (-2048.0h, -2048.0h).  Same 7.5 ops as ArithI16M3 with a much narrower window; kept as an independent
+// implementation of the same tier (selected by S4G_SCAN_F16_ARITH) that does not rely on the bit-pattern argument.
 struct ArithF16 {
     static constexpr bool kMax3 = true;
-    static __device__ __forceinline__ int floor_() { return (int)0xE800E800u; }          // (-2048.0h, -2048.0h)
     static __device__ __forceinline__ int pen(unsigned p) { const _Float16 v = (_Float16)(-(float)p); v2h x = {v, v}; return as_i(x); }
-    static __device__ __forceinline__ int max3(int a, int b, int c) {   // hipcc fuses this into one v_pk_maximum3_f16 (no asm: an
-        return as_i(__builtin_elementwise_maximum(__builtin_elementwise_maximum(as_h(a), as_h(b)), as_h(c)));   // asm statement costs an s_nop pad)
-    }
     static __device__ __forceinline__ int add(int a, int b) { return as_i(as_h(a) + as_h(b)); }
-    static __device__ __forceinline__ int hmax(int s, int e, int f) { return max3(s, e, f); }
+    static __device__ __forceinline__ int hmax(int s, int e, int f) { return pk_maximum3(s, e, f); }
     static __device__ __forceinline__ int sub(int x, int p) { return add(x, p); }          // p holds -penalty; floored by gmax
-    static __device__ __forceinline__ int gmax(int a, int b) { return max3(a, b, floor_()); }
-    static __device__ __forceinline__ int best1(int best, int h) { return max3(best, h, h); }
-    static __device__ __forceinline__ int best2(int best, int h0, int h1) { return max3(best, h0, h1); }
+    static __device__ __forceinline__ int gmax(int a, int b, int fl) { return pk_maximum3(a, b, fl); }
+    static __device__ __forceinline__ int best1(int best, int h) { return pk_maximum3(best, h, h); }
+    static __device__ __forceinline__ int best2(int best, int h0, int h1) { return pk_maximum3(best, h0, h1); }
     static __device__ __forceinline__ int pair(int sA, int sB) { v2h x = {(_Float16)(float)sA, (_Float16)(float)sB}; return as_i(x); }
-    static __device__ __forceinline__ int out(int best, int half) { return (int)(float)as_h(best)[half] + 2048; }
+    static __device__ __forceinline__ int out(int best, int half, int) { return (int)(float)as_h(best)[half] + 2048; }
 };
 
 // 8 rows (row0 .. row0+7) of one column; sc = their 8 packed score pairs
 template <class A, int R>
 __device__ __forceinline__ void pk_rows8(int (&H)[R], int (&E)[R], int row0, const v4i (&sc)[2], int& diag, int& F,
-                                         int& best, int open, int ext) {
+                                         int& best, int open, int ext, int fl) {
     int hprev = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -300,8 +322,8 @@ __device__ __forceinline__ void pk_rows8(int (&H)[R], int (&E)[R], int row0, con
         if constexpr (A::kMax3) { if (i & 1) best = A::best2(best, hprev, h); else hprev = h; }
         else best = A::best1(best, h);
         const int hm = A::sub(h, open);
-        E[r] = A::gmax(A::sub(E[r], ext), hm);
-        F = A::gmax(A::sub(F, ext), hm);
+        E[r] = A::gmax(A::sub(E[r], ext), hm, fl);
+        F = A::gmax(A::sub(F, ext), hm, fl);
         diag = H[r];
         H[r] = h;
     }
@@ -319,9 +341,8 @@ __device__ __forceinline__ unsigned pk_taddr(uint32_t r4, int cc) {
 // One strip of RR rows (RR multiple of 8) over all columns of the group.
 template <class A, int R, int RR>
 __device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
-                                         bool first, bool last, int& best, int open, int ext) {
+                                         bool first, bool last, int& best, int open, int ext, int fl) {
     constexpr int NB = RR / 8;
-    const int fl = A::floor_();
     int H[R];
     int E[R];
 #pragma unroll
@@ -349,7 +370,7 @@ __device__ __forceinline__ void pk_strip(const uint32_t* res, unsigned len4, con
             for (int b = 0; b < NB; ++b) {
                 v4i sc[2] = {sc_n[0], sc_n[1]};
                 if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
-                pk_rows8<A, R>(H, E, 8 * b, sc, diag, F, best, open, ext);
+                pk_rows8<A, R>(H, E, 8 * b, sc, diag, F, best, open, ext, fl);
             }
             hdiag = hb[cc];
             ho[cc] = H[RR - 1];
@@ -379,6 +400,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
     const unsigned n_items = a.n_groups * a.n_pairs;
     const int open = A::pen(a.open);
     const int ext = A::pen(a.ext);
+    const int fl = (int)a.floor_bits;        // packed floor: 0 (ArithI16), bias B (ArithI16M3), -2048.0h (ArithF16)
 
     for (;;) {
         unsigned item = 0;
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
-        int best = A::floor_();
+        int best = fl;
 
         for (unsigned s = 0; s < nstrips; ++s) {
             const unsigned rows_left = lq - s * R;
@@ -425,16 +447,16 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
             bool done = false;
 #define S4G_LAST_STRIP(RR_)                                                                                  \
             if constexpr (R > RR_) {                                                                         \
-                if (!done && rr == RR_) { pk_strip<A, R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext); done = true; } \
+                if (!done && rr == RR_) { pk_strip<A, R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext, fl); done = true; } \
             }
             S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
 #undef S4G_LAST_STRIP
-            if (!done) pk_strip<A, R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext);   // full strip (or rr > 40)
+            if (!done) pk_strip<A, R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext, fl);   // full strip (or rr > 40)
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) {
-            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = A::out(best, 0);
-            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = A::out(best, 1);
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = A::out(best, 0, fl);
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = A::out(best, 1, fl);
         }
     }
 }

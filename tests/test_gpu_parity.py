@@ -23,8 +23,9 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     db = s4g.Database(targets)
     qs = s4g.QuerySet(queries)
     exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
-    # default plan (fastest exact kernel per query: packed f16 / packed int16 / int32), without the f16 tier, int32 alone
-    for mode in (dict(), dict(no_f16=True), dict(force_i32=True)):
+    # default plan (fastest exact kernel per query: maximum3-int16 / plain packed int16 / int32), the f16-arithmetic form
+    # of the maximum3 tier, no maximum3 tier, int32 alone
+    for mode in (dict(), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
@@ -150,6 +151,22 @@ def test_f16_window_routing(s4g, oracle_mod, blosum62, scorer):
     for go, ge in ((2048, 2048), (40, 1), (3000, 7)):          # gap penalties at / beyond the f16 window
         sc = s4g.Scorer("BLOSUM_62", go, ge)
         _check(s4g, oracle_mod, blosum62, qs[:4], ts[:30], sc, go, ge)
+
+
+def test_maximum3_int16_window_routing(s4g, oracle_mod, blosum62, scorer):
+    """ArithI16M3 (v_pk_maximum3_f16 on biased int16 bit patterns) is exact while bound + bias <= 0x7BFF = 31743:
+    scores right at the top of the window, small values (f16 denormal patterns), large gap penalties (big bias)."""
+    W = ord("W") - 65
+    rng = np.random.default_rng(33)
+    top = np.full(2879, W, dtype=np.uint8)                     # bound 31669 + bias 64 = 31733 <= 31743 -> maximum3 tier
+    over = np.full(2880, W, dtype=np.uint8)                    # bound 31680 + 64 > 31743 -> plain packed int16
+    qs = [top, over] + rand_seqs(rng, 4, 5, 60)                # short queries: every score stays in the denormal range
+    ts = [np.full(3000, W, dtype=np.uint8), np.full(2879, W, dtype=np.uint8)] + rand_seqs(rng, 60, 1, 80)
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert got[0, 0] == 31669 and got[1, 0] == 31680
+    for go, ge in ((5000, 3), (31000, 31000)):                 # bias = open: shrinks the window, far beyond any real penalty
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        _check(s4g, oracle_mod, blosum62, qs[2:] + [np.full(60, W, dtype=np.uint8)], ts[1:40], sc, go, ge)
 
 
 def test_odd_query_counts_and_unequal_pairs(s4g, oracle_mod, blosum62, scorer):
@@ -293,7 +310,7 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         assert sum(tiles) == len(ts)
         if tile_seqs == 64:
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 4096-residue sequences form their own tile
-        for mode in (dict(), dict(no_f16=True), dict(force_i32=True)):
+        for mode in (dict(), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
@@ -407,7 +424,7 @@ def test_randomized_configurations(s4g, oracle_mod):
         exp = oracle_mod.scan(qs, ts, M, go, ge, threads=8)
         db = s4g.Database(ts, tile_seqs=int(rng.choice([0, 64, 128])))
         q = s4g.QuerySet(qs)
-        mode = [dict(), dict(no_f16=True), dict(force_i32=True)][it % 3]
+        mode = [dict(), dict(no_f16=True), dict(force_i32=True), dict(f16_arith=True)][it % 4]
         got = s4g.scan_host(db, q, sc, **mode)
         assert np.array_equal(got, exp), (it, go, ge, mode)
         k = int(rng.integers(1, 50))
