@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--qlen", type=int, nargs=2, default=[300, 400], help="query length range (configs[4]: 2000 5000)")
     ap.add_argument("--force-i32", action="store_true", help="run every query through the int32 kernel")
-    ap.add_argument("--no-f16", action="store_true", help="skip the packed f16 tier (packed int16 instead)")
+    ap.add_argument("--no-f16", action="store_true", help="skip the maximum3-based tiers (plain packed int16 instead)")
+    ap.add_argument("--no-drift", action="store_true", help="skip the drifting-frame kernel (maximum3 tier instead)")
     ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard",
                     help="query-shard (default): DB replicated, --queries per GPU; db-shard: --targets per GPU, every GPU scans "
                          "all --queries with the streaming scan + running top-k, then all-gather + K-way merge")
@@ -123,8 +124,10 @@ def main():
     plan = scan_plan(db, allq, scorer)
     if args.force_i32:
         plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
-    elif args.no_f16 and "M3" in plan["kernel"]:
+    elif args.no_f16 and ("M3" in plan["kernel"] or "pkd" in plan["kernel"]):
         plan["kernel"] = "sw_scan_pk<ArithI16,32>"
+    elif args.no_drift and "pkd" in plan["kernel"]:
+        plan["kernel"] = "sw_scan_pk<ArithI16M3,32>"
     scores = None if db_shard else torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
     gids = torch.from_numpy(mine.astype(np.int64)).to(dev) if db_shard else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -133,11 +136,11 @@ def main():
         if i is not None:
             ev[i][0].record()
         if db_shard:
-            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32, no_f16=args.no_f16)    # scan + tile top-k + merge
+            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift)    # scan + tile top-k + merge
             if i is not None:
                 ev[i][1].record()
             return shard.gather_db_shards(ids, sc, cnt, gids, TOPK)                          # RCCL all-gather + K-way merge
-        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32, no_f16=args.no_f16)
+        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift)
         if i is not None:
             ev[i][1].record()
         ids, sc, cnt = s4g.topk_device(db, scores, TOPK, 1)                     # steps 2-3 on the device
@@ -183,7 +186,7 @@ def main():
             "metric": "GCUPS (SW cell updates/s) on query x DB scan",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16" if "I16" in plan["kernel"] else ("f16" if "F16" in plan["kernel"] else "int32"), "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if ("I16" in plan["kernel"] or "pkd" in plan["kernel"]) else ("f16" if "F16" in plan["kernel"] else "int32"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] generator: {args.queries} synthetic queries/GPU len U[{args.qlen[0]},{args.qlen[1]}] x "
                                    f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
                                    f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",

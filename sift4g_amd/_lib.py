@@ -18,6 +18,7 @@ S4G_ERR_NOMEM = -4
 S4G_SCAN_FORCE_I32 = 1
 S4G_SCAN_NO_F16 = 2
 S4G_SCAN_F16_ARITH = 4
+S4G_SCAN_NO_DRIFT = 8
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)

@@ -105,7 +105,7 @@ struct s4g_db {
     mutable uint64_t qlist_cap = 0;
     mutable int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
     mutable uint64_t tile_scores_bytes = 0;
-    mutable uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0;
+    mutable uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
     mutable hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
 };
 
@@ -529,14 +529,27 @@ constexpr int kStripRows16 = 32;    // sw_scan_i16x2
 constexpr uint64_t kWorkspaceBudget = 24ull << 30;   // strip-boundary workspace cap; long-sequence tiles run on a smaller grid
 constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of the [query batch][tile columns] buffer
 
+// Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
+// is EXACT for it (score bound = sum_i max(0, max_b M[q_i][b]); see sw_kernels.hip.h for each window):
+//   drift  sw_scan_pkd          bound + B + (rows + tile columns) * ext <= 0x7BFF      6.5 ops / pair of cells
+//   m3     sw_scan_pk<I16M3>    bound + B <= 0x7BFF   (or ArithF16: bound <= 4096)     7.5
+//   pk     sw_scan_pk<I16>      bound <= 32767                                          9
+//   wide   sw_scan_i32          anything                                                7.5 per single cell
+struct TileWork {
+    uint32_t off_drift = 0, n_drift = 0;   // offsets / pair counts into Plan::flat (pairs = 2 ids each)
+    uint32_t off_m3 = 0, n_m3 = 0;
+    uint32_t off_pk = 0, n_pk = 0;
+    uint32_t off_wide = 0, n_wide = 0;     // single ids
+};
+
 struct Plan {
-    std::vector<uint32_t> pairs;    // i16x2 work: 2 ids per pair (second may be ~0u)
-    std::vector<uint32_t> hpairs;   // maximum3 tier: pairs whose score bound fits the window of the v_pk_maximum3_f16 policy
-    bool f16_arith = false;         // maximum3 tier runs ArithF16 (window 4096) instead of ArithI16M3 (window 0x7BFF - bias)
-    uint32_t bias = 0;              // ArithI16M3 bias B
-    std::vector<uint32_t> wide;     // i32 work: query ids whose score bound exceeds int16
-    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0;   // full persistent grids
-    uint64_t ws_bytes = 0;                 // workspace needed for the largest tile launch
+    std::vector<TileWork> tiles;    // one per database tile
+    std::vector<uint32_t> flat;     // all id lists, uploaded once per call
+    bool f16_arith = false;         // m3 tier runs ArithF16 instead of ArithI16M3
+    uint32_t bias = 0;              // bias B of the maximum3-based tiers
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_m3 = 0, grid_drift = 0;   // full persistent grids
+    uint64_t ws_bytes = 0;          // workspace needed for the largest tile launch
+    uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
 };
 
 int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
@@ -574,8 +587,6 @@ void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
     q->bound_scorer = scorer->serial;
 }
 
-// Which queries may run in packed int16: every reachable H is bounded by sum_i max(0, max_b M[q_i][b]) (each row of the
-// DP adds at most its best substitution score), so the kernel is exact when that bound fits in int16.
 int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* sc,
               uint32_t flags, Plan* p) {
     int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &db->grid_i32);
@@ -584,37 +595,55 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     if (rc) return rc;
     rc = grid_for(db, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &db->grid_f16);
     if (rc) return rc;
-    p->grid_i32 = db->grid_i32;
-    p->grid_i16 = db->grid_i16;
-    p->grid_f16 = db->grid_f16;
+    rc = grid_for(db, (const void*)sw_scan_pkd<kStripRows16>, &db->grid_drift);
+    if (rc) return rc;
+    p->grid_i32 = db->grid_i32; p->grid_i16 = db->grid_i16; p->grid_m3 = db->grid_f16; p->grid_drift = db->grid_drift;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
-    // maximum3 tier: ArithI16M3 keeps every operand a non-negative int16 below the f16 infinity pattern (0x7C00) with the
-    // bias B = max(64 = -pad score, open, ext, -min table entry); ArithF16 (on request) is exact on scores up to 4096.
     p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
-    p->bias = (uint32_t)std::max(std::max(-kPadScore, -sc->min_score), std::max(sc->open, sc->ext));
-    const uint64_t m3_window = p->f16_arith ? 4096 : (p->bias < 0x7BFF ? 0x7BFF - p->bias : 0);
+    // bias of the maximum3-on-bit-patterns tiers: keeps diag+s, h-open, E-ext (and H~(0,-1) = B - ext in the drift frame) >= 0
+    p->bias = (uint32_t)std::max(std::max(-kPadScore, -sc->min_score), std::max(sc->open, 2 * sc->ext));
+    const uint64_t cap = 0x7BFF;     // largest int16 bit pattern that is a finite f16
+    const uint64_t m3_window = p->f16_arith ? 4096 : (p->bias < cap ? cap - p->bias : 0);
     const bool m3_gaps = p->f16_arith ? (sc->open <= 2048 && sc->ext <= 2048) : gaps16;
-    std::vector<uint32_t> narrow, tiny;
-    for (uint32_t i = 0; i < q_count; ++i) {
-        const uint32_t id = q_begin + i;
-        const uint64_t b = q->score_bound[id];
-        if (b <= m3_window && m3_gaps && !(flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16))) tiny.push_back(id);
-        else if (b <= 32767 && gaps16 && !(flags & S4G_SCAN_FORCE_I32)) narrow.push_back(id);
-        else p->wide.push_back(id);
-    }
-    // pair queries of similar length (the pair runs to the longer one); longest pairs first
-    auto make_pairs = [&](std::vector<uint32_t>& ids, std::vector<uint32_t>& out) {
-        std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
-        for (size_t i = 0; i < ids.size(); i += 2) {
-            out.push_back(ids[i]);
-            out.push_back(i + 1 < ids.size() ? ids[i + 1] : 0xFFFFFFFFu);
+    const bool no_m3 = (flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16)) != 0;
+    const bool no_drift = no_m3 || p->f16_arith || (flags & S4G_SCAN_NO_DRIFT) != 0;
+
+    std::vector<uint32_t> ids[4];
+    auto add_pairs = [&](std::vector<uint32_t>& v, uint32_t* off, uint32_t* n) {
+        // pair queries of similar length (the pair runs to the longer one); longest pairs first
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
+        *off = (uint32_t)p->flat.size();
+        for (size_t i = 0; i < v.size(); i += 2) {
+            p->flat.push_back(v[i]);
+            p->flat.push_back(i + 1 < v.size() ? v[i + 1] : 0xFFFFFFFFu);
         }
+        *n = (uint32_t)((v.size() + 1) / 2);
     };
-    make_pairs(narrow, p->pairs);
-    make_pairs(tiny, p->hpairs);
-    const uint32_t full = std::max(std::max(p->grid_i32, p->grid_i16), p->grid_f16);
-    for (const Tile& t : db->tiles)
+    const uint32_t full = std::max(std::max(p->grid_i32, p->grid_i16), std::max(p->grid_m3, p->grid_drift));
+    for (const Tile& t : db->tiles) {
+        for (auto& v : ids) v.clear();
+        const uint64_t cols = (uint64_t)t.max_len4 * 4 + 8;
+        for (uint32_t i = 0; i < q_count; ++i) {
+            const uint32_t id = q_begin + i;
+            const uint64_t b = q->score_bound[id];
+            const uint64_t rows = (uint64_t)q->len[id] + 2 * kStripRows16;          // padded rows of the pair's strips
+            int tier;
+            if (!no_drift && gaps16 && b + p->bias + (rows + cols) * (uint64_t)sc->ext <= cap) tier = 0;
+            else if (!no_m3 && m3_gaps && b <= m3_window) tier = 1;
+            else if (!(flags & S4G_SCAN_FORCE_I32) && gaps16 && b <= 32767) tier = 2;
+            else tier = 3;
+            ids[tier].push_back(id);
+            p->n_by_tier[tier]++;
+        }
+        TileWork w;
+        add_pairs(ids[0], &w.off_drift, &w.n_drift);
+        add_pairs(ids[1], &w.off_m3, &w.n_m3);
+        add_pairs(ids[2], &w.off_pk, &w.n_pk);
+        w.off_wide = (uint32_t)p->flat.size(); w.n_wide = (uint32_t)ids[3].size();
+        p->flat.insert(p->flat.end(), ids[3].begin(), ids[3].end());
+        p->tiles.push_back(w);
         p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
+    }
     return S4G_OK;
 }
 
@@ -627,7 +656,7 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
     }
     if (!db->d_counter) HIP_TRY(hipMalloc((void**)&db->d_counter, 256));
     if (!db->d_mat) HIP_TRY(hipMalloc((void**)&db->d_mat, 1024));
-    const uint64_t need = p.pairs.size() + p.hpairs.size() + p.wide.size();
+    const uint64_t need = p.flat.size();
     if (db->qlist_cap < need) {
         if (db->d_qlist) HIP_TRY(hipFree(db->d_qlist));
         db->d_qlist = nullptr; db->qlist_cap = 0;
@@ -635,70 +664,62 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
         db->qlist_cap = need;
     }
     HIP_TRY(hipMemcpyAsync(db->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
-    if (!p.pairs.empty())
-        HIP_TRY(hipMemcpyAsync(db->d_qlist, p.pairs.data(), p.pairs.size() * 4, hipMemcpyHostToDevice, stream));
-    if (!p.wide.empty())
-        HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size(), p.wide.data(), p.wide.size() * 4, hipMemcpyHostToDevice, stream));
-    if (!p.hpairs.empty())
-        HIP_TRY(hipMemcpyAsync(db->d_qlist + p.pairs.size() + p.wide.size(), p.hpairs.data(), p.hpairs.size() * 4, hipMemcpyHostToDevice, stream));
+    if (need) HIP_TRY(hipMemcpyAsync(db->d_qlist, p.flat.data(), need * 4, hipMemcpyHostToDevice, stream));
     return S4G_OK;
 }
 
-// One tile: the packed launch for the int16-safe query pairs, then the int32 launch for the rest.
-// perm/stride select the output layout: original ids into the caller's [q][n_seqs] matrix, or tile columns.
-int launch_tile(const s4g_db* db, const Tile& t, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p, uint32_t q_begin,
-                int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream) {
+// One tile: one launch per non-empty tier.  perm/stride select the output layout: original ids into the caller's
+// [q][n_seqs] matrix, or tile columns.
+int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
+                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream) {
     if (t.n_seqs == 0) return S4G_OK;
-    if ((uint64_t)t.n_groups * std::max<uint64_t>(std::max(p.pairs.size(), p.hpairs.size()) / 2, p.wide.size()) >= 0xFFFFFFFFull)
+    const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+    if ((uint64_t)t.n_groups * most >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
-    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 12, stream));
-    if (!p.hpairs.empty()) {
-        ScanArgs16 a;
-        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-        a.pairs = db->d_qlist + p.pairs.size() + p.wide.size();
-        a.mat = db->d_mat;
-        a.scores = d_scores; a.score_stride = stride;
-        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
-        a.counter = db->d_counter + 2;
-        a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.hpairs.size() / 2); a.q_begin = q_begin;
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 16, stream));
+    ScanArgs16 a;
+    a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.mat = db->d_mat;
+    a.scores = d_scores; a.score_stride = stride;
+    a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
+    a.n_groups = t.n_groups; a.q_begin = q_begin;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    if (w.n_drift) {
+        a.pairs = db->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = db->d_counter + 3;
+        a.floor_bits = p.bias | (p.bias << 16);
+        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(tile_grid(t, p.grid_drift)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (w.n_m3) {
+        a.pairs = db->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = db->d_counter + 2;
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
-            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_m3)), dim3(kBlock), 0, stream, a);
         } else {
             a.floor_bits = p.bias | (p.bias << 16);
-            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(tile_grid(t, p.grid_f16)), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(tile_grid(t, p.grid_m3)), dim3(kBlock), 0, stream, a);
         }
         HIP_TRY(hipGetLastError());
     }
-    if (!p.pairs.empty()) {
-        ScanArgs16 a;
-        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-        a.pairs = db->d_qlist;
-        a.mat = db->d_mat;
-        a.scores = d_scores; a.score_stride = stride;
-        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
-        a.counter = db->d_counter;
-        a.n_groups = t.n_groups; a.n_pairs = (uint32_t)(p.pairs.size() / 2); a.q_begin = q_begin;
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    if (w.n_pk) {
+        a.pairs = db->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = db->d_counter;
         a.floor_bits = 0;
         hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
-    if (!p.wide.empty()) {
-        ScanArgs a;
-        a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-        a.mat = db->d_mat;
-        a.scores = d_scores; a.score_stride = stride;
-        a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
-        a.counter = db->d_counter + 1;
-        a.n_groups = t.n_groups; a.q_begin = q_begin; a.q_count = (uint32_t)p.wide.size();
-        a.q_list = db->d_qlist + p.pairs.size();
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(tile_grid(t, p.grid_i32)), dim3(kBlock), 0, stream, a);
+    if (w.n_wide) {
+        ScanArgs b;
+        b.db_res = t.d_res; b.grp_off = t.d_grp_off; b.grp_len4 = t.d_grp_len4; b.grp_perm = perm;
+        b.q_codes = q->d_codes; b.q_off = q->d_off; b.q_len = q->d_len;
+        b.mat = db->d_mat;
+        b.scores = d_scores; b.score_stride = stride;
+        b.ws = db->d_ws; b.ws_slot = ws_slot_elems(t);
+        b.counter = db->d_counter + 1;
+        b.n_groups = t.n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
+        b.q_list = db->d_qlist + w.off_wide;
+        b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(tile_grid(t, p.grid_i32)), dim3(kBlock), 0, stream, b);
         HIP_TRY(hipGetLastError());
     }
     return S4G_OK;
@@ -736,12 +757,15 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
     if (rc) return rc;
     // report the kernel that carries most of the queries
-    const size_t nh = p.hpairs.size(), ni = p.pairs.size(), nw = p.wide.size() * 2;
-    const char* name = (nh >= ni && nh >= nw) ? "sw_scan_pk<ArithI16M3,32>" : (ni >= nw ? "sw_scan_pk<ArithI16,32>" : "sw_scan_i32<32>");
-    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", name);
-    if (grid_blocks) *grid_blocks = (nh >= ni && nh >= nw) ? p.grid_f16 : (ni >= nw ? p.grid_i16 : p.grid_i32);
+    int top = 0;
+    for (int k = 1; k < 4; ++k) if (p.n_by_tier[k] > p.n_by_tier[top]) top = k;
+    const char* names[4] = {"sw_scan_pkd<32>", p.f16_arith ? "sw_scan_pk<ArithF16,32>" : "sw_scan_pk<ArithI16M3,32>", "sw_scan_pk<ArithI16,32>",
+                            "sw_scan_i32<32>"};
+    const uint32_t grids[4] = {p.grid_drift, p.grid_m3, p.grid_i16, p.grid_i32};
+    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", names[top]);
+    if (grid_blocks) *grid_blocks = grids[top];
     if (block_threads) *block_threads = kBlock;
-    if (strip_rows) *strip_rows = (nh >= ni || ni >= nw) ? kStripRows16 : kStripRows;
+    if (strip_rows) *strip_rows = top == 3 ? kStripRows : kStripRows16;
     if (workspace_bytes) *workspace_bytes = p.ws_bytes;
     return S4G_OK;
 }
@@ -763,8 +787,9 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
-    for (const Tile& t : db->tiles) {
-        rc = launch_tile(db, t, q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
+    for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+        const Tile& t = db->tiles[ti];
+        rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
         if (rc) return rc;
     }
     return scratch_release(db, stream);
@@ -1045,8 +1070,9 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         if (rc) return rc;
         rc = ensure_scratch(db, scorer, p, stream);
         if (rc) return rc;
-        for (const Tile& t : db->tiles) {
-            rc = launch_tile(db, t, q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
             if (rc) return rc;
             hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
                                c_sc, c_cnt, (const uint32_t*)t.d_col_ids);

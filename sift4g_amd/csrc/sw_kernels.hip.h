@@ -461,4 +461,169 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
     }
 }
 
+
+// =====================================================================================================
+// sw_scan_pkd: packed int16 pair kernel in a DRIFTING FRAME -- 6.5 VALU ops per pair of cells.
+//
+// Store every DP value with a bias that grows by `ext` per anti-diagonal:   X~(i,j) = X(i,j) + B + (i+j)*ext.
+// Then (o = open, e = ext):
+//     H~(i,j)   = max3( H~(i-1,j-1) + (s + 2e),  E~(i,j),  F~(i,j) )            s + 2e comes from the strip profile
+//     E~(i,j+1) = max3( E~(i,j),  H~(i,j) + (e - o),  z(i,j+1) )                 z(i,j) = B + (i+j)e  (floor: E >= 0)
+//     F~(i+1,j) = max ( F~(i,j),  H~(i,j) + (e - o) )                            F >= -o needs no floor
+//     best      = max3( best,  H~ - z(i,j)  [two rows per instruction] )         true H, back in the fixed frame
+// Both gap updates lose their "- ext" and share one add.  z(i,j) is uniform over the wave (i and j are), so it
+// lives in an SGPR that the scalar unit advances by e per row (SALU is otherwise idle): add, max3, sub, 1/2 max3,
+// add, max3, max = 6.5 vector ops.  The three-input max is v_pk_maximum3_f16 on the raw integer bit patterns
+// (see ArithI16M3): every operand stays in 0 .. 0x7BFF because B >= max(64, o, 2e, -min score) and the host only
+// routes here (query pair, tile) combinations with  bound + B + (rows + columns) * e <= 0x7BFF.
+// =====================================================================================================
+template <int R>
+__device__ __forceinline__ void pkd_rows8(int (&H)[R], int (&E)[R], int row0, const v4i (&sc)[2], int& diag, int& F, int& best,
+                                          int eo, int& zcur, int e2) {
+    int tprev = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + i;
+        const int h = pk_maximum3(as_i(as_s(diag) + as_s(sc[i / 4][i % 4])), E[r], F);
+        const int t = as_i(as_s(h) - as_s(zcur));                      // true H of both cells (>= 0)
+        if (i & 1) best = pk_maximum3(best, tprev, t); else tprev = t;
+        zcur += e2;                                                    // scalar: z(i+1, j) = z(i, j+1)
+        const int hm = as_i(as_s(h) + as_s(eo));
+        E[r] = pk_maximum3(E[r], hm, zcur);
+        F = as_i(pk_max(as_s(F), as_s(hm)));
+        diag = H[r];
+        H[r] = h;
+    }
+}
+
+template <int R, int RR>
+__device__ __forceinline__ void pkd_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+                                          bool first, bool last, int& best, int eo, int e2, int zrow0) {
+    constexpr int NB = RR / 8;
+    // zrow0 = packed z(i0, 0) = B + i0*e for the strip's first row i0
+    int H[R];
+    int E[R];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) { H[r] = zrow0 + (r - 1) * e2; E[r] = zrow0 + r * e2; }   // H~(i,-1), E~(i,0) for H = E = 0
+    int zcol = zrow0;                       // z(i0, j) of the current column
+    int hdiag = zrow0 - 2 * e2;             // H~(i0-1, -1)
+    uint32_t res_n = res[0];
+    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+    if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+    v4i sc_n[2];
+    pk_load8(sc_n, prof, pk_taddr(res_n, 0), 0);
+    for (unsigned c = 0; c < len4; ++c) {
+        const uint32_t r4 = res_n;
+        const v4i hb = hb_n, fb = fb_n;
+        const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+        res_n = res[(uint64_t)cn * 64];
+        if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+        v4i ho, fo;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const unsigned taddr = pk_taddr(r4, cc);
+            const unsigned taddr_next = cc < 3 ? pk_taddr(r4, cc + 1) : pk_taddr(res_n, 0);
+            int diag = hdiag;
+            int F = first ? zcol : fb[cc];           // first strip: F~(0,j) = z(0,j) (F = 0)
+            int zcur = zcol;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                v4i sc[2] = {sc_n[0], sc_n[1]};
+                if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
+                pkd_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, zcur, e2);
+            }
+            hdiag = first ? zcol - e2 : hb[cc];      // first strip: H~(-1, j) = z(0,j) - e
+            zcol += e2;
+            ho[cc] = H[RR - 1];
+            fo[cc] = F;
+            asm volatile("" : "+v"(best));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
+    static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 128);
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const unsigned n_items = a.n_groups * a.n_pairs;
+    const int e2 = (int)(a.ext | (a.ext << 16));
+    const int eo = (int)(((a.ext - a.open) & 0xFFFFu) * 0x10001u);     // packed (e - o), two's complement per half
+    const int B2 = (int)a.floor_bits;                                   // packed bias B
+    const int two_e = 2 * (int)a.ext;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const unsigned g = item / a.n_pairs;
+        const unsigned pi = item - g * a.n_pairs;
+        const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
+        const bool hasB = qB != 0xFFFFFFFFu;
+        const unsigned len4 = a.grp_len4[g];
+        const uint32_t* res = a.db_res + a.grp_off[g] + lane;
+        const uint8_t* qcA = a.q_codes + a.q_off[qA];
+        const uint8_t* qcB = a.q_codes + a.q_off[hasB ? qB : qA];
+        const unsigned lA = a.q_len[qA], lB = hasB ? a.q_len[qB] : 0u;
+        const unsigned capA = (lA + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;
+        const unsigned capB = hasB ? (lB + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign : 0u;
+        const unsigned lq = lA > lB ? lA : lB;
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        int best = 0;
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            const unsigned rows_left = lq - s * R;
+            const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
+            // ---- strip profile: packed (sA + 2e, sB + 2e) ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 8 * R; e0 += 64) {
+                const int e = e0 + lane;
+                const int kk = e >> 5, t = e & 31;
+                const unsigned row0 = s * R + 4 * kk;
+                const unsigned cA = row0 < capA ? *reinterpret_cast<const unsigned*>(qcA + row0) : 0x1F1F1F1Fu;
+                const unsigned cB = row0 < capB ? *reinterpret_cast<const unsigned*>(qcB + row0) : 0x1F1F1F1Fu;
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int sA = lmat[((cA >> (8 * d)) & 31u) * 32 + t] + two_e;
+                    const int sB = lmat[((cB >> (8 * d)) & 31u) * 32 + t] + two_e;
+                    out[d] = (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16));
+                }
+                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+            const int zrow0 = B2 + (int)(s * R) * e2;                  // packed z(i0, 0); no carry between halves (values < 0x7C00)
+            bool done = false;
+#define S4G_LAST_STRIP(RR_)                                                                                  \
+            if constexpr (R > RR_) {                                                                         \
+                if (!done && rr == RR_) { pkd_strip<R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, eo, e2, zrow0); done = true; } \
+            }
+            S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
+#undef S4G_LAST_STRIP
+            if (!done) pkd_strip<R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, eo, e2, zrow0);
+        }
+        const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
+        if (p != 0xFFFFFFFFu) {
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = (int)as_s(best)[0];
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = (int)as_s(best)[1];
+        }
+    }
+}
+
 }  // namespace s4g

@@ -23,9 +23,9 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     db = s4g.Database(targets)
     qs = s4g.QuerySet(queries)
     exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
-    # default plan (fastest exact kernel per query: maximum3-int16 / plain packed int16 / int32), the f16-arithmetic form
-    # of the maximum3 tier, no maximum3 tier, int32 alone
-    for mode in (dict(), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+    # default plan (fastest exact kernel per query: drifting-frame int16 / maximum3-int16 / plain packed int16 / int32),
+    # without the drift kernel, the f16-arithmetic form of the maximum3 tier, no maximum3 at all, int32 alone
+    for mode in (dict(), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
@@ -169,6 +169,23 @@ def test_maximum3_int16_window_routing(s4g, oracle_mod, blosum62, scorer):
         _check(s4g, oracle_mod, blosum62, qs[2:] + [np.full(60, W, dtype=np.uint8)], ts[1:40], sc, go, ge)
 
 
+def test_drift_frame_window_routing(s4g, oracle_mod, blosum62):
+    """sw_scan_pkd stores X + B + (i+j)*ext: exact while bound + B + (rows + columns)*ext <= 0x7BFF.  Large ext makes the
+    drift dominate; long targets push single tiles out of the window while short-target tiles stay in."""
+    W = ord("W") - 65
+    rng = np.random.default_rng(34)
+    qs = rand_seqs(rng, 6, 50, 400) + [np.full(1500, W, dtype=np.uint8)]
+    ts = rand_seqs(rng, 150, 10, 500) + [rand_seqs(rng, 1, 9000, 9000)[0], np.full(2000, W, dtype=np.uint8),
+                                          np.concatenate([qs[0], qs[0], qs[0]])]
+    for go, ge in ((10, 1), (12, 4), (30, 30), (11, 0), (200, 9)):
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        got = _check(s4g, oracle_mod, blosum62, qs, ts, sc, go, ge)
+        assert got[6, 151] == 1500 * 11
+    db = s4g.Database(ts, tile_seqs=64)                        # the 9000-residue target gets a tile of its own
+    exp = oracle_mod.scan(qs, ts, blosum62, 12, 3, threads=8)
+    assert np.array_equal(s4g.scan_host(db, s4g.QuerySet(qs), s4g.Scorer("BLOSUM_62", 12, 3)), exp)
+
+
 def test_odd_query_counts_and_unequal_pairs(s4g, oracle_mod, blosum62, scorer):
     """packed kernel pairs queries of similar length: odd counts, a lone query, very unequal partners."""
     rng = np.random.default_rng(26)
@@ -310,7 +327,7 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         assert sum(tiles) == len(ts)
         if tile_seqs == 64:
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 4096-residue sequences form their own tile
-        for mode in (dict(), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+        for mode in (dict(), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
@@ -424,7 +441,7 @@ def test_randomized_configurations(s4g, oracle_mod):
         exp = oracle_mod.scan(qs, ts, M, go, ge, threads=8)
         db = s4g.Database(ts, tile_seqs=int(rng.choice([0, 64, 128])))
         q = s4g.QuerySet(qs)
-        mode = [dict(), dict(no_f16=True), dict(force_i32=True), dict(f16_arith=True)][it % 4]
+        mode = [dict(), dict(no_f16=True), dict(force_i32=True), dict(f16_arith=True), dict(no_drift=True), dict()][it % 6]
         got = s4g.scan_host(db, q, sc, **mode)
         assert np.array_equal(got, exp), (it, go, ge, mode)
         k = int(rng.integers(1, 50))
