@@ -815,16 +815,13 @@ S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t
     if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
     if (!h_scores) return fail(S4G_ERR_INVALID, "h_scores is NULL");
     DeviceGuard guard(db->device);
-    int32_t* d = nullptr;
-    size_t bytes = (size_t)q_count * db->n_seqs * 4;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
-    int rc = s4g_scan_flags(db, q, q_begin, q_count, scorer, d, nullptr, flags);
-    if (rc == S4G_OK) {
-        hipError_t e = hipMemcpy(h_scores, d, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(S4G_ERR_HIP, "score download failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d);
-    return rc;
+    DevBuf<int32_t> d;
+    const size_t bytes = (size_t)q_count * db->n_seqs * 4;
+    HIP_TRY(d.alloc((size_t)q_count * db->n_seqs));
+    int rc = s4g_scan_flags(db, q, q_begin, q_count, scorer, d.p, nullptr, flags);
+    if (rc != S4G_OK) return rc;
+    HIP_TRY(hipMemcpy(h_scores, d.p, bytes, hipMemcpyDeviceToHost));
+    return S4G_OK;
 }
 
 S4G_API int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t* cand_offsets,
@@ -1090,20 +1087,18 @@ S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_
     if (q_count == 0) return S4G_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
-    uint32_t *d_ids = nullptr, *d_counts = nullptr; int32_t* d_sc = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_ids, (size_t)q_count * k * 4));
-    HIP_TRY(hipMalloc((void**)&d_sc, (size_t)q_count * k * 4));
-    HIP_TRY(hipMalloc((void**)&d_counts, (size_t)q_count * 4));
-    int rc = s4g_topk(db, d_scores, q_count, k, min_score, d_ids, d_sc, d_counts, stream_);
-    if (rc == S4G_OK) {
-        hipError_t e = hipMemcpyAsync(h_counts, d_counts, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_ids, d_ids, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_scores, d_sc, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) rc = fail(S4G_ERR_HIP, "top-k download failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_ids); (void)hipFree(d_sc); (void)hipFree(d_counts);
-    return rc;
+    DevBuf<uint32_t> d_ids, d_counts;
+    DevBuf<int32_t> d_sc;
+    HIP_TRY(d_ids.alloc((size_t)q_count * k));
+    HIP_TRY(d_sc.alloc((size_t)q_count * k));
+    HIP_TRY(d_counts.alloc(q_count));
+    int rc = s4g_topk(db, d_scores, q_count, k, min_score, d_ids.p, d_sc.p, d_counts.p, stream_);
+    if (rc != S4G_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts.p, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_ids, d_ids.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_scores, d_sc.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return S4G_OK;
 }
 
 // ---------------------------------------------------------------------------
