@@ -107,6 +107,12 @@ struct s4g_db {
     mutable uint64_t tile_scores_bytes = 0;
     mutable uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
     mutable hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
+    // long-sequence tiles have few, huge items: they run on a side stream (own workspace and counters) underneath the
+    // main tiles instead of as a tail-dominated launch of their own
+    mutable hipStream_t side_stream = nullptr;
+    mutable hipEvent_t side_fork = nullptr, side_join = nullptr;
+    mutable int32_t* d_ws_side = nullptr;
+    mutable uint64_t ws_side_bytes = 0;
 };
 
 struct s4g_queries {
@@ -187,7 +193,8 @@ namespace {
 
 constexpr uint32_t kTileMaxSeqs = 1u << 20;            // sequences per tile
 constexpr uint64_t kTileMaxResidues = 1ull << 30;      // padded residues per tile
-constexpr uint32_t kLongSeq = 4096;                    // sequences longer than this get tiles of their own
+constexpr uint32_t kLongSeq = 12288;                   // sequences longer than this get tiles of their own: beyond ~16k residues
+                                                       // the per-wave strip-boundary workspace no longer fits the budget at full grid
 
 void free_tile(Tile& t) {
     (void)hipFree(t.d_res); (void)hipFree(t.d_grp_off); (void)hipFree(t.d_grp_len4);
@@ -350,6 +357,10 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
     (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat); (void)hipFree(db->d_qlist);
     (void)hipFree(db->d_tile_scores);
     if (db->last_use) (void)hipEventDestroy(db->last_use);
+    if (db->side_fork) (void)hipEventDestroy(db->side_fork);
+    if (db->side_join) (void)hipEventDestroy(db->side_join);
+    if (db->side_stream) (void)hipStreamDestroy(db->side_stream);
+    (void)hipFree(db->d_ws_side);
     delete db;
     return S4G_OK;
 }
@@ -635,6 +646,33 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             ids[tier].push_back(id);
             p->n_by_tier[tier]++;
         }
+        // Every tier is its own launch, and a launch can never finish before its largest item does (one wave walks the
+        // whole (query pair, group) DP).  With few queries the tiers' launches become short and tail-dominated, so
+        // fold a tier into the next slower one whenever the estimate says one launch beats two.  Units: VALU ops.
+        {
+            static const double ops[4] = {6.5, 7.5, 9.0, 15.0};     // per pair of cells (int32: two single-query items)
+            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double cols_sum = (double)t.padded_residues / 64.0;           // sum over groups of padded length
+            const double cols_max = (double)t.max_len4 * 4.0;
+            auto launch_time = [&](const std::vector<uint32_t>& v, int tier) -> double {
+                if (v.empty()) return 0.0;
+                double rows_sum = 0, rows_max = 0;
+                for (uint32_t id : v) { rows_sum += q->len[id]; rows_max = std::max<double>(rows_max, q->len[id]); }
+                if (tier < 3) rows_sum *= 0.5;                                   // two queries share an item
+                return ops[tier] * std::max(rows_sum * cols_sum / waves, rows_max * cols_max);
+            };
+            for (int tier = 0; tier < 3; ++tier) {
+                if (ids[tier].empty() || ids[tier + 1].empty()) continue;
+                std::vector<uint32_t> merged(ids[tier + 1]);
+                merged.insert(merged.end(), ids[tier].begin(), ids[tier].end());
+                if (launch_time(merged, tier + 1) <= launch_time(ids[tier], tier) + launch_time(ids[tier + 1], tier + 1)) {
+                    p->n_by_tier[tier] -= ids[tier].size();
+                    p->n_by_tier[tier + 1] += ids[tier].size();
+                    ids[tier + 1].swap(merged);
+                    ids[tier].clear();
+                }
+            }
+        }
         TileWork w;
         add_pairs(ids[0], &w.off_drift, &w.n_drift);
         add_pairs(ids[1], &w.off_m3, &w.n_m3);
@@ -671,41 +709,48 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
 // One tile: one launch per non-empty tier.  perm/stride select the output layout: original ids into the caller's
 // [q][n_seqs] matrix, or tile columns.
 int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
-                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream) {
+                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream, bool side = false) {
     if (t.n_seqs == 0) return S4G_OK;
+    int32_t* const ws = side ? db->d_ws_side : db->d_ws;
+    unsigned* const counters = db->d_counter + (side ? 8 : 0);
+    // a persistent grid larger than the number of items only launches blocks that exit at once
+    auto grid_of = [&](uint32_t full, uint64_t items) {
+        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), (items + kWavesPerBlock - 1) / kWavesPerBlock));
+    };
     const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
     if ((uint64_t)t.n_groups * most >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
-    HIP_TRY(hipMemsetAsync(db->d_counter, 0, 16, stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, 16, stream));
     ScanArgs16 a;
     a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
     a.mat = db->d_mat;
     a.scores = d_scores; a.score_stride = stride;
-    a.ws = db->d_ws; a.ws_slot = ws_slot_elems(t);
+    a.ws = ws; a.ws_slot = ws_slot_elems(t);
     a.n_groups = t.n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     if (w.n_drift) {
-        a.pairs = db->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = db->d_counter + 3;
+        a.pairs = db->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3;
         a.floor_bits = p.bias | (p.bias << 16);
-        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(tile_grid(t, p.grid_drift)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)t.n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
-        a.pairs = db->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = db->d_counter + 2;
+        a.pairs = db->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2;
+        const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)t.n_groups * w.n_m3);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
-            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(tile_grid(t, p.grid_m3)), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
         } else {
             a.floor_bits = p.bias | (p.bias << 16);
-            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(tile_grid(t, p.grid_m3)), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
         }
         HIP_TRY(hipGetLastError());
     }
     if (w.n_pk) {
-        a.pairs = db->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = db->d_counter;
+        a.pairs = db->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters;
         a.floor_bits = 0;
-        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(tile_grid(t, p.grid_i16)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)t.n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_wide) {
@@ -714,12 +759,12 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         b.q_codes = q->d_codes; b.q_off = q->d_off; b.q_len = q->d_len;
         b.mat = db->d_mat;
         b.scores = d_scores; b.score_stride = stride;
-        b.ws = db->d_ws; b.ws_slot = ws_slot_elems(t);
-        b.counter = db->d_counter + 1;
+        b.ws = ws; b.ws_slot = ws_slot_elems(t);
+        b.counter = counters + 1;
         b.n_groups = t.n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
         b.q_list = db->d_qlist + w.off_wide;
         b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(tile_grid(t, p.grid_i32)), dim3(kBlock), 0, stream, b);
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)t.n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
         HIP_TRY(hipGetLastError());
     }
     return S4G_OK;
@@ -787,11 +832,45 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
+    // long-sequence tiles first, on the side stream with their own workspace: their few huge items then run underneath
+    // the main tiles' launches instead of as a tail-dominated launch of their own
+    bool forked = false;
+    const uint32_t full = std::max(std::max(p.grid_i32, p.grid_i16), std::max(p.grid_m3, p.grid_drift));
+    if (db->tiles.size() > 1) {
+        uint64_t need = 0;
+        for (const Tile& t : db->tiles)
+            if ((uint64_t)t.max_len4 * 4 > kLongSeq) need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
+        if (need) {
+            if (!db->side_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&db->side_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&db->side_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&db->side_join, hipEventDisableTiming));
+            }
+            if (db->ws_side_bytes < need) {
+                if (db->d_ws_side) HIP_TRY(hipFree(db->d_ws_side));
+                db->d_ws_side = nullptr; db->ws_side_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&db->d_ws_side, need));
+                db->ws_side_bytes = need;
+            }
+            HIP_TRY(hipEventRecord(db->side_fork, stream));                 // after the uploads of this call
+            HIP_TRY(hipStreamWaitEvent(db->side_stream, db->side_fork, 0));
+            for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+                const Tile& t = db->tiles[ti];
+                if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, db->side_stream, true);
+                if (rc) return rc;
+            }
+            HIP_TRY(hipEventRecord(db->side_join, db->side_stream));
+            forked = true;
+        }
+    }
     for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
         const Tile& t = db->tiles[ti];
+        if (forked && (uint64_t)t.max_len4 * 4 > kLongSeq) continue;
         rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
         if (rc) return rc;
     }
+    if (forked) HIP_TRY(hipStreamWaitEvent(stream, db->side_join, 0));
     return scratch_release(db, stream);
 }
 

@@ -175,13 +175,13 @@ def test_drift_frame_window_routing(s4g, oracle_mod, blosum62):
     W = ord("W") - 65
     rng = np.random.default_rng(34)
     qs = rand_seqs(rng, 6, 50, 400) + [np.full(1500, W, dtype=np.uint8)]
-    ts = rand_seqs(rng, 150, 10, 500) + [rand_seqs(rng, 1, 9000, 9000)[0], np.full(2000, W, dtype=np.uint8),
+    ts = rand_seqs(rng, 150, 10, 500) + [rand_seqs(rng, 1, 13000, 13000)[0], np.full(2000, W, dtype=np.uint8),
                                           np.concatenate([qs[0], qs[0], qs[0]])]
     for go, ge in ((10, 1), (12, 4), (30, 30), (11, 0), (200, 9)):
         sc = s4g.Scorer("BLOSUM_62", go, ge)
         got = _check(s4g, oracle_mod, blosum62, qs, ts, sc, go, ge)
         assert got[6, 151] == 1500 * 11
-    db = s4g.Database(ts, tile_seqs=64)                        # the 9000-residue target gets a tile of its own
+    db = s4g.Database(ts, tile_seqs=64)                        # the 13000-residue target gets a tile of its own
     exp = oracle_mod.scan(qs, ts, blosum62, 12, 3, threads=8)
     assert np.array_equal(s4g.scan_host(db, s4g.QuerySet(qs), s4g.Scorer("BLOSUM_62", 12, 3)), exp)
 
@@ -318,7 +318,7 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
     full-matrix scans must not depend on the tiling."""
     rng = np.random.default_rng(27)
     qs = rand_seqs(rng, 9, 20, 260)
-    ts = rand_seqs(rng, 700, 1, 300) + [rand_seqs(rng, 1, 4100, 4100)[0], rand_seqs(rng, 1, 5000, 5000)[0]]
+    ts = rand_seqs(rng, 700, 1, 300) + [rand_seqs(rng, 1, 12300, 12300)[0], rand_seqs(rng, 1, 13000, 13000)[0]]
     exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
     q = s4g.QuerySet(qs)
     for tile_seqs in (0, 64, 192, 1000):
@@ -326,7 +326,7 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         tiles = db.tiles()
         assert sum(tiles) == len(ts)
         if tile_seqs == 64:
-            assert len(tiles) >= 11 and tiles[0] == 2          # the two > 4096-residue sequences form their own tile
+            assert len(tiles) >= 11 and tiles[0] == 2          # the two > 12288-residue sequences form their own tile (side stream)
         for mode in (dict(), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
@@ -403,7 +403,7 @@ def test_packed_database_file_roundtrip(s4g, oracle_mod, blosum62, scorer, tmp_p
     top-k and traceback all work off the loaded tiles)."""
     rng = np.random.default_rng(30)
     qs = rand_seqs(rng, 5, 40, 200)
-    ts = rand_seqs(rng, 300, 1, 280) + [qs[0][10:150].copy(), rand_seqs(rng, 1, 4200, 4200)[0]]
+    ts = rand_seqs(rng, 300, 1, 280) + [qs[0][10:150].copy(), rand_seqs(rng, 1, 12400, 12400)[0]]
     exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
     db = s4g.Database(ts, tile_seqs=128)
     path = tmp_path / "db.s4g"
