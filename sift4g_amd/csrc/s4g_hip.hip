@@ -95,25 +95,46 @@ struct s4g_db {
     std::vector<Tile> tiles;
     std::vector<uint32_t> len;     // original index -> length
     std::vector<uint32_t> pos_of_id;   // original index -> position in the global length-sorted order
-    // per-device scratch, created lazily and reused (scan calls on one db are serialized)
-    mutable std::mutex mu;
-    mutable int32_t* d_ws = nullptr;
-    mutable uint64_t ws_bytes = 0;
-    mutable unsigned* d_counter = nullptr;
-    mutable int8_t* d_mat = nullptr;
-    mutable uint32_t* d_qlist = nullptr;     // query-id lists of the current launch (pairs for i16x2, singles for i32)
-    mutable uint64_t qlist_cap = 0;
-    mutable int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
-    mutable uint64_t tile_scores_bytes = 0;
-    mutable uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
-    mutable hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
+};
+
+// Per-device scratch shared by every database on that device: strip-boundary workspace, work-queue counters, query
+// lists, the streaming score buffer, a grow-only arena for the traceback.  sift4g's wrapper creates and destroys one
+// ChainDatabase per (query, chunk) (database_alignment.cpp:80,92); keeping the scratch here instead of in s4g_db
+// removes a multi-hundred-MB hipMalloc/hipFree pair from every such call.  All launches on a device serialize on
+// `mu` at enqueue time and on `last_use` across streams.
+struct DeviceCtx {
+    std::mutex mu;
+    int device = 0;
+    bool have_prop = false;
+    hipDeviceProp_t prop;
+    int32_t* d_ws = nullptr;
+    uint64_t ws_bytes = 0;
+    unsigned* d_counter = nullptr;
+    int8_t* d_mat = nullptr;
+    uint32_t* d_qlist = nullptr;     // query-id lists of the current call (pairs for the packed tiers, singles for int32)
+    uint64_t qlist_cap = 0;
+    int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
+    uint64_t tile_scores_bytes = 0;
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
+    hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
     // long-sequence tiles have few, huge items: they run on a side stream (own workspace and counters) underneath the
     // main tiles instead of as a tail-dominated launch of their own
-    mutable hipStream_t side_stream = nullptr;
-    mutable hipEvent_t side_fork = nullptr, side_join = nullptr;
-    mutable int32_t* d_ws_side = nullptr;
-    mutable uint64_t ws_side_bytes = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    int32_t* d_ws_side = nullptr;
+    uint64_t ws_side_bytes = 0;
+    char* arena = nullptr;              // traceback temporaries
+    uint64_t arena_bytes = 0;
 };
+
+namespace {
+DeviceCtx g_ctx[64];
+DeviceCtx* device_ctx(int device) {
+    DeviceCtx* c = &g_ctx[device & 63];
+    c->device = device;
+    return c;
+}
+}  // namespace
 
 struct s4g_queries {
     int device = 0;
@@ -353,14 +374,12 @@ S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const 
 S4G_API int s4g_db_destroy(s4g_db* db) {
     if (!db) return S4G_OK;
     DeviceGuard guard(db->device);
+    {   // launches that still read the tiles must have finished before they are freed
+        DeviceCtx* cx = device_ctx(db->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (cx->last_use) (void)hipEventSynchronize(cx->last_use);
+    }
     for (Tile& t : db->tiles) free_tile(t);
-    (void)hipFree(db->d_ws); (void)hipFree(db->d_counter); (void)hipFree(db->d_mat); (void)hipFree(db->d_qlist);
-    (void)hipFree(db->d_tile_scores);
-    if (db->last_use) (void)hipEventDestroy(db->last_use);
-    if (db->side_fork) (void)hipEventDestroy(db->side_fork);
-    if (db->side_join) (void)hipEventDestroy(db->side_join);
-    if (db->side_stream) (void)hipStreamDestroy(db->side_stream);
-    (void)hipFree(db->d_ws_side);
     delete db;
     return S4G_OK;
 }
@@ -370,7 +389,10 @@ S4G_API int s4g_db_info(const s4g_db* db, uint32_t* n_seqs, uint64_t* residues, 
     if (n_seqs) *n_seqs = db->n_seqs;
     if (residues) *residues = db->residues;
     if (padded_residues) *padded_residues = db->padded_residues;
-    if (hbm_bytes) *hbm_bytes = db->hbm_bytes + db->ws_bytes + db->tile_scores_bytes;
+    if (hbm_bytes) {
+        DeviceCtx* cx = device_ctx(db->device);
+        *hbm_bytes = db->hbm_bytes + cx->ws_bytes + cx->ws_side_bytes + cx->tile_scores_bytes + cx->arena_bytes;
+    }
     return S4G_OK;
 }
 
@@ -563,14 +585,23 @@ struct Plan {
     uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
 };
 
+int device_props(DeviceCtx* cx) {
+    if (!cx->have_prop) {
+        HIP_TRY(hipGetDeviceProperties(&cx->prop, cx->device));
+        cx->have_prop = true;
+    }
+    return S4G_OK;
+}
+
 int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
     if (*cache == 0) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, db->device));
+        DeviceCtx* cx = device_ctx(db->device);
+        int rc = device_props(cx);
+        if (rc) return rc;
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
         if (per_cu < 1) per_cu = 1;
-        *cache = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        *cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)per_cu;
     }
     return S4G_OK;
 }
@@ -600,15 +631,16 @@ void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
 
 int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* sc,
               uint32_t flags, Plan* p) {
-    int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &db->grid_i32);
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &cx->grid_i32);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &db->grid_i16);
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &cx->grid_i16);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &db->grid_f16);
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &cx->grid_f16);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_pkd<kStripRows16>, &db->grid_drift);
+    rc = grid_for(db, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
     if (rc) return rc;
-    p->grid_i32 = db->grid_i32; p->grid_i16 = db->grid_i16; p->grid_m3 = db->grid_f16; p->grid_drift = db->grid_drift;
+    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = cx->grid_drift;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
     p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
     // bias of the maximum3-on-bit-patterns tiers: keeps diag+s, h-open, E-ext (and H~(0,-1) = B - ext in the drift frame) >= 0
@@ -680,29 +712,33 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         w.off_wide = (uint32_t)p->flat.size(); w.n_wide = (uint32_t)ids[3].size();
         p->flat.insert(p->flat.end(), ids[3].begin(), ids[3].end());
         p->tiles.push_back(w);
-        p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
+        // workspace: one slot per wave of the largest launch of this tile (grids are capped by the item count)
+        const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+        p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
     }
     return S4G_OK;
 }
 
 int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStream_t stream) {
-    if (db->ws_bytes < p.ws_bytes) {
-        if (db->d_ws) HIP_TRY(hipFree(db->d_ws));
-        db->d_ws = nullptr; db->ws_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&db->d_ws, p.ws_bytes));
-        db->ws_bytes = p.ws_bytes;
+    DeviceCtx* cx = device_ctx(db->device);
+    if (cx->ws_bytes < p.ws_bytes) {
+        if (cx->d_ws) HIP_TRY(hipFree(cx->d_ws));
+        cx->d_ws = nullptr; cx->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_ws, p.ws_bytes));
+        cx->ws_bytes = p.ws_bytes;
     }
-    if (!db->d_counter) HIP_TRY(hipMalloc((void**)&db->d_counter, 256));
-    if (!db->d_mat) HIP_TRY(hipMalloc((void**)&db->d_mat, 1024));
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
     const uint64_t need = p.flat.size();
-    if (db->qlist_cap < need) {
-        if (db->d_qlist) HIP_TRY(hipFree(db->d_qlist));
-        db->d_qlist = nullptr; db->qlist_cap = 0;
-        HIP_TRY(hipMalloc((void**)&db->d_qlist, need * 4));
-        db->qlist_cap = need;
+    if (cx->qlist_cap < need) {
+        if (cx->d_qlist) HIP_TRY(hipFree(cx->d_qlist));
+        cx->d_qlist = nullptr; cx->qlist_cap = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_qlist, need * 4));
+        cx->qlist_cap = need;
     }
-    HIP_TRY(hipMemcpyAsync(db->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
-    if (need) HIP_TRY(hipMemcpyAsync(db->d_qlist, p.flat.data(), need * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
+    if (need) HIP_TRY(hipMemcpyAsync(cx->d_qlist, p.flat.data(), need * 4, hipMemcpyHostToDevice, stream));
     return S4G_OK;
 }
 
@@ -711,8 +747,9 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
 int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
                 uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream, bool side = false) {
     if (t.n_seqs == 0) return S4G_OK;
-    int32_t* const ws = side ? db->d_ws_side : db->d_ws;
-    unsigned* const counters = db->d_counter + (side ? 8 : 0);
+    DeviceCtx* cx = device_ctx(db->device);
+    int32_t* const ws = side ? cx->d_ws_side : cx->d_ws;
+    unsigned* const counters = cx->d_counter + (side ? 8 : 0);
     // a persistent grid larger than the number of items only launches blocks that exit at once
     auto grid_of = [&](uint32_t full, uint64_t items) {
         return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), (items + kWavesPerBlock - 1) / kWavesPerBlock));
@@ -724,19 +761,19 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     ScanArgs16 a;
     a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
-    a.mat = db->d_mat;
+    a.mat = cx->d_mat;
     a.scores = d_scores; a.score_stride = stride;
     a.ws = ws; a.ws_slot = ws_slot_elems(t);
     a.n_groups = t.n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     if (w.n_drift) {
-        a.pairs = db->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3;
+        a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3;
         a.floor_bits = p.bias | (p.bias << 16);
         hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)t.n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
-        a.pairs = db->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2;
+        a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2;
         const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)t.n_groups * w.n_m3);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
@@ -748,7 +785,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         HIP_TRY(hipGetLastError());
     }
     if (w.n_pk) {
-        a.pairs = db->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters;
+        a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters;
         a.floor_bits = 0;
         hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)t.n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
@@ -757,12 +794,12 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         ScanArgs b;
         b.db_res = t.d_res; b.grp_off = t.d_grp_off; b.grp_len4 = t.d_grp_len4; b.grp_perm = perm;
         b.q_codes = q->d_codes; b.q_off = q->d_off; b.q_len = q->d_len;
-        b.mat = db->d_mat;
+        b.mat = cx->d_mat;
         b.scores = d_scores; b.score_stride = stride;
         b.ws = ws; b.ws_slot = ws_slot_elems(t);
         b.counter = counters + 1;
         b.n_groups = t.n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
-        b.q_list = db->d_qlist + w.off_wide;
+        b.q_list = cx->d_qlist + w.off_wide;
         b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
         hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)t.n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
         HIP_TRY(hipGetLastError());
@@ -773,12 +810,14 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
 // The scratch buffers (workspace, work-queue counter, query lists) are shared by all launches on this database:
 // a launch on another stream must not start before the previous one has finished with them.
 int scratch_acquire(const s4g_db* db, hipStream_t stream) {
-    if (!db->last_use) HIP_TRY(hipEventCreateWithFlags(&db->last_use, hipEventDisableTiming));
-    else HIP_TRY(hipStreamWaitEvent(stream, db->last_use, 0));
+    DeviceCtx* cx = device_ctx(db->device);
+    if (!cx->last_use) HIP_TRY(hipEventCreateWithFlags(&cx->last_use, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
     return S4G_OK;
 }
 int scratch_release(const s4g_db* db, hipStream_t stream) {
-    HIP_TRY(hipEventRecord(db->last_use, stream));
+    DeviceCtx* cx = device_ctx(db->device);
+    HIP_TRY(hipEventRecord(cx->last_use, stream));
     return S4G_OK;
 }
 
@@ -796,7 +835,8 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
                           uint32_t* strip_rows, uint64_t* workspace_bytes) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     DeviceGuard guard(db->device);
-    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
     ensure_bounds(q, scorer);
     Plan p;
     int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
@@ -823,7 +863,8 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (!d_scores) return fail(S4G_ERR_INVALID, "d_scores is NULL");
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
-    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
     ensure_bounds(q, scorer);
     Plan p;
     rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
@@ -841,26 +882,26 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         for (const Tile& t : db->tiles)
             if ((uint64_t)t.max_len4 * 4 > kLongSeq) need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
         if (need) {
-            if (!db->side_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&db->side_stream, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&db->side_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&db->side_join, hipEventDisableTiming));
+            if (!cx->side_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
             }
-            if (db->ws_side_bytes < need) {
-                if (db->d_ws_side) HIP_TRY(hipFree(db->d_ws_side));
-                db->d_ws_side = nullptr; db->ws_side_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&db->d_ws_side, need));
-                db->ws_side_bytes = need;
+            if (cx->ws_side_bytes < need) {
+                if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
+                cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&cx->d_ws_side, need));
+                cx->ws_side_bytes = need;
             }
-            HIP_TRY(hipEventRecord(db->side_fork, stream));                 // after the uploads of this call
-            HIP_TRY(hipStreamWaitEvent(db->side_stream, db->side_fork, 0));
+            HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
+            HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
             for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
                 const Tile& t = db->tiles[ti];
                 if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
-                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, db->side_stream, true);
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true);
                 if (rc) return rc;
             }
-            HIP_TRY(hipEventRecord(db->side_join, db->side_stream));
+            HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
             forked = true;
         }
     }
@@ -870,7 +911,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
         if (rc) return rc;
     }
-    if (forked) HIP_TRY(hipStreamWaitEvent(stream, db->side_join, 0));
+    if (forked) HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
     return scratch_release(db, stream);
 }
 
@@ -1114,7 +1155,8 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     if (!d_ids || !d_top_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
-    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
     rc = scratch_acquire(db, stream);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)q_count * k * 4, stream));
@@ -1125,13 +1167,13 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     const uint64_t cols = db->max_tile_seqs;
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
     const uint64_t need = (uint64_t)batch * cols * 4 + (uint64_t)batch * k * 8 + (uint64_t)batch * 4;
-    if (db->tile_scores_bytes < need) {
-        if (db->d_tile_scores) HIP_TRY(hipFree(db->d_tile_scores));
-        db->d_tile_scores = nullptr; db->tile_scores_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&db->d_tile_scores, need));
-        db->tile_scores_bytes = need;
+    if (cx->tile_scores_bytes < need) {
+        if (cx->d_tile_scores) HIP_TRY(hipFree(cx->d_tile_scores));
+        cx->d_tile_scores = nullptr; cx->tile_scores_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_tile_scores, need));
+        cx->tile_scores_bytes = need;
     }
-    int32_t* d_buf = db->d_tile_scores;
+    int32_t* d_buf = cx->d_tile_scores;
     uint32_t* c_ids = reinterpret_cast<uint32_t*>(d_buf + (uint64_t)batch * cols);
     int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + (uint64_t)batch * k);
     uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + (uint64_t)batch * k);
@@ -1197,7 +1239,8 @@ S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g
             return fail(S4G_ERR_INVALID, "pair %u: path capacity must be at least query length + target length", i);
     }
     DeviceGuard guard(db->device);
-    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
     hipStream_t stream = nullptr;
 
     // items: pairs grouped by query, sorted by target length inside a query, 64 lanes per item
@@ -1217,13 +1260,16 @@ S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g
         items.push_back({pair_q[idx[i]], len4, i, j - i, (uint64_t)nstrips * len4 * kTraceR * 64});
         i = j;
     }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, db->device));
-    DevBuf<int8_t> d_mat;
-    HIP_TRY(d_mat.alloc(1024));
-    HIP_TRY(hipMemcpy(d_mat.p, scorer->mat32, 1024, hipMemcpyHostToDevice));
-    DevBuf<unsigned> d_counter;
-    HIP_TRY(d_counter.alloc(4));
+    {
+        int rc = device_props(cx);
+        if (rc) return rc;
+    }
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));      // a scan on another stream may still read d_mat
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    struct { int8_t* p; } d_mat = {cx->d_mat};
+    struct { unsigned* p; } d_counter = {cx->d_counter + 16};
 
     const uint64_t dir_budget = (8ull << 30) / 4;       // dwords of direction bytes per batch
     std::vector<int32_t> out5;
@@ -1264,38 +1310,58 @@ S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g
             for (uint32_t l = it.count; l < 64; ++l) lane_res[(size_t)k * 64 + l] = lane_res[(size_t)k * 64];   // valid address, length 0
         }
         const uint32_t np = (uint32_t)slot_of_pair.size();
-        DevBuf<uint64_t> d_lane_res, d_dir_off, d_poff;
-        DevBuf<uint32_t> d_lane_len, d_item_q, d_item_len4, d_dirs, d_end, d_slot;
-        DevBuf<int32_t> d_lane_score, d_best, d_ws, d_out;
-        DevBuf<uint8_t> d_paths;
-        HIP_TRY(d_lane_res.upload(lane_res)); HIP_TRY(d_dir_off.upload(dir_off)); HIP_TRY(d_poff.upload(poff));
-        HIP_TRY(d_lane_len.upload(lane_len)); HIP_TRY(d_item_q.upload(item_q)); HIP_TRY(d_item_len4.upload(item_len4));
-        HIP_TRY(d_slot.upload(slot_of_pair)); HIP_TRY(d_lane_score.upload(lane_score));
-        HIP_TRY(d_dirs.alloc(off)); HIP_TRY(d_end.alloc((size_t)ni * 64)); HIP_TRY(d_best.alloc((size_t)ni * 64));
-        HIP_TRY(d_out.alloc((size_t)np * 5)); HIP_TRY(d_paths.alloc(poff.back()));
-        const uint32_t grid = std::max(1u, std::min<uint32_t>((ni + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)prop.multiProcessorCount * 2));
+        const uint32_t grid = std::max(1u, std::min<uint32_t>((ni + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)cx->prop.multiProcessorCount * 2));
         const uint64_t ws_slot = 2ull * std::max(1u, max_len4) * 64 * 4;
-        HIP_TRY(d_ws.alloc(ws_slot * grid * kWavesPerBlock));
+        // every temporary of this batch is carved from the device's grow-only arena (no hipMalloc/hipFree per call);
+        // only direction blocks beyond 256 MB get an allocation of their own
+        const bool big_dirs = off * 4 > (256ull << 20);
+        DevBuf<uint32_t> d_dirs_big;
+        if (big_dirs) HIP_TRY(d_dirs_big.alloc(off));
+        uint64_t need = 0;
+        auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
+        const uint64_t o_lane_res = reserve((uint64_t)ni * 64 * 8), o_dir_off = reserve((uint64_t)ni * 8), o_poff = reserve((uint64_t)(np + 1) * 8);
+        const uint64_t o_lane_len = reserve((uint64_t)ni * 64 * 4), o_item_q = reserve((uint64_t)ni * 4), o_item_len4 = reserve((uint64_t)ni * 4);
+        const uint64_t o_slot = reserve((uint64_t)np * 4), o_lane_score = reserve((uint64_t)ni * 64 * 4);
+        const uint64_t o_end = reserve((uint64_t)ni * 64 * 4), o_best = reserve((uint64_t)ni * 64 * 4), o_out = reserve((uint64_t)np * 5 * 4);
+        const uint64_t o_paths = reserve(poff.back()), o_ws = reserve(ws_slot * 4 * grid * kWavesPerBlock);
+        const uint64_t o_dirs = big_dirs ? 0 : reserve(off * 4);
+        if (cx->arena_bytes < need) {
+            if (cx->arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->arena)); }
+            cx->arena = nullptr; cx->arena_bytes = 0;
+            const uint64_t want = std::max<uint64_t>(need + need / 4, 16ull << 20);
+            HIP_TRY(hipMalloc((void**)&cx->arena, want));
+            cx->arena_bytes = want;
+        }
+        char* A = cx->arena;
+        auto put = [&](uint64_t at, const void* src, uint64_t bytes) { return bytes ? hipMemcpyAsync(A + at, src, bytes, hipMemcpyHostToDevice, stream) : hipSuccess; };
+        HIP_TRY(put(o_lane_res, lane_res.data(), lane_res.size() * 8)); HIP_TRY(put(o_dir_off, dir_off.data(), dir_off.size() * 8));
+        HIP_TRY(put(o_poff, poff.data(), poff.size() * 8)); HIP_TRY(put(o_lane_len, lane_len.data(), lane_len.size() * 4));
+        HIP_TRY(put(o_item_q, item_q.data(), item_q.size() * 4)); HIP_TRY(put(o_item_len4, item_len4.data(), item_len4.size() * 4));
+        HIP_TRY(put(o_slot, slot_of_pair.data(), slot_of_pair.size() * 4)); HIP_TRY(put(o_lane_score, lane_score.data(), lane_score.size() * 4));
+        uint32_t* d_dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint32_t*>(A + o_dirs);
         HIP_TRY(hipMemsetAsync(d_counter.p, 0, 4, stream));
         TraceArgs a;
-        a.lane_res = d_lane_res.p; a.lane_len = d_lane_len.p; a.lane_score = d_lane_score.p; a.item_q = d_item_q.p;
-        a.item_len4 = d_item_len4.p; a.item_dir_off = d_dir_off.p;
+        a.lane_res = reinterpret_cast<const uint64_t*>(A + o_lane_res); a.lane_len = reinterpret_cast<const uint32_t*>(A + o_lane_len);
+        a.lane_score = reinterpret_cast<const int32_t*>(A + o_lane_score); a.item_q = reinterpret_cast<const uint32_t*>(A + o_item_q);
+        a.item_len4 = reinterpret_cast<const uint32_t*>(A + o_item_len4); a.item_dir_off = reinterpret_cast<const uint64_t*>(A + o_dir_off);
         a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = d_mat.p;
-        a.dirs = d_dirs.p; a.ws = d_ws.p; a.ws_slot = ws_slot; a.counter = d_counter.p; a.n_items = ni;
-        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.end_key = d_end.p; a.best = d_best.p;
+        a.dirs = d_dirs; a.ws = reinterpret_cast<int32_t*>(A + o_ws); a.ws_slot = ws_slot; a.counter = d_counter.p; a.n_items = ni;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        a.end_key = reinterpret_cast<uint32_t*>(A + o_end); a.best = reinterpret_cast<int32_t*>(A + o_best);
         hipLaunchKernelGGL(sw_trace_fill, dim3(grid), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
         WalkArgs w;
-        w.dirs = d_dirs.p; w.item_dir_off = d_dir_off.p; w.item_len4 = d_item_len4.p; w.end_key = d_end.p;
-        w.slot_of_pair = d_slot.p; w.path_off = d_poff.p; w.paths = d_paths.p; w.out = d_out.p; w.n_pairs = np;
+        w.dirs = d_dirs; w.item_dir_off = a.item_dir_off; w.item_len4 = a.item_len4; w.end_key = a.end_key;
+        w.slot_of_pair = reinterpret_cast<const uint32_t*>(A + o_slot); w.path_off = reinterpret_cast<const uint64_t*>(A + o_poff);
+        w.paths = reinterpret_cast<uint8_t*>(A + o_paths); w.out = reinterpret_cast<int32_t*>(A + o_out); w.n_pairs = np;
         hipLaunchKernelGGL(sw_trace_walk, dim3((np + 63) / 64), dim3(64), 0, stream, w);
         HIP_TRY(hipGetLastError());
         out5.resize((size_t)np * 5);
         std::vector<uint8_t> paths(poff.back() ? poff.back() : 1);
         std::vector<int32_t> best((size_t)ni * 64);
-        HIP_TRY(hipMemcpy(out5.data(), d_out.p, out5.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(paths.data(), d_paths.p, poff.back(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(best.data(), d_best.p, best.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out5.data(), A + o_out, out5.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(paths.data(), A + o_paths, poff.back(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(best.data(), A + o_best, best.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t x = 0; x < np; ++x) {
             const uint32_t pi = pair_ids[x];
             if (best[slot_of_pair[x]] != pair_score[pi])

@@ -11,7 +11,28 @@
 #include "impl.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+
+// S4G_PROFILE=1: cumulative wall time per phase of the host API, printed at exit (diagnostic only)
+namespace {
+struct PhaseClock {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool on = getenv("S4G_PROFILE") != NULL;
+    ~PhaseClock() {
+        if (!on) return;
+        static const char* names[8] = {"chainDatabaseCreate", "queries to device", "scan + download", "values/selection", "device traceback",
+                                       "build DbAlignments", "chainDatabaseDelete", ""};
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "[s4g profile] %-22s %8.3f s  (%ld calls)\n", names[i], t[i], n[i]);
+    }
+} g_clock;
+struct Phase {
+    int id; std::chrono::steady_clock::time_point t0;
+    explicit Phase(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+    ~Phase() { if (g_clock.on) { g_clock.t[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_clock.n[id]++; } }
+};
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ traceback
 namespace swimpl {
@@ -105,6 +126,7 @@ static void flatten(Chain** chains, int n, std::vector<uint8_t>& codes, std::vec
 
 SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, int databaseLen, int* cards, int cardsLen) {
     SW_ASSERT(database != NULL && databaseStart >= 0 && databaseLen >= 0, "chainDatabaseCreate: invalid arguments");
+    Phase ph(0);
     ChainDatabase* db = new ChainDatabase();
     db->chains = database + databaseStart;
     db->length = databaseLen;
@@ -121,6 +143,7 @@ SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, i
 
 SW_API void chainDatabaseDelete(ChainDatabase* db) {
     if (!db) return;
+    Phase ph(6);
     s4g_db_destroy(db->dev);
     delete db;
 }
@@ -278,8 +301,11 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
     std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
     flatten(queries, queriesLen, qcodes, qoff);
     s4g_queries* dq = NULL;
-    if (s4g_queries_create(&dq, cdb->device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
-        SW_FATAL("cannot place the queries on MI355X device %d: %s", cdb->device, s4g_last_error());
+    {
+        Phase ph(1);
+        if (s4g_queries_create(&dq, cdb->device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
+            SW_FATAL("cannot place the queries on MI355X device %d: %s", cdb->device, s4g_last_error());
+    }
 
     // targets to consider: all, or the caller's subset
     std::vector<int> subset;
@@ -312,8 +338,12 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
 
     for (uint32_t b = 0; b < (uint32_t)queriesLen; b += batch) {
         const uint32_t cnt = std::min<uint32_t>(batch, (uint32_t)queriesLen - b);
-        if (s4g_scan_host(cdb->dev, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
-            SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        {
+            Phase ph(2);
+            if (s4g_scan_host(cdb->dev, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
+                SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        }
+        Phase* ph_sel = new Phase(3);
         // steps 2-3 on the host, one pool task per query (the value callback is the caller's double-precision code)
         std::vector<SelectJob> sel(cnt);
         std::vector<ThreadPoolTask*> tasks(cnt);
@@ -336,13 +366,18 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
                 path_off.push_back(path_off.back() + (uint64_t)chainGetLength(queries[b + i]) + (uint64_t)chainGetLength(cdb->chains[tidx]));
             }
         }
+        delete ph_sel;
         // step 4 on the device: one batched traceback of every survivor of this query batch
         const uint32_t np = (uint32_t)pair_q.size();
         std::vector<int32_t> out5((size_t)np * 5);
         std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
-        if (np && s4g_traceback_host(cdb->dev, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
-                                     path_off.data(), paths.data()) != S4G_OK)
-            SW_FATAL("traceback failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        {
+            Phase ph(4);
+            if (np && s4g_traceback_host(cdb->dev, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
+                                         path_off.data(), paths.data()) != S4G_OK)
+                SW_FATAL("traceback failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+        }
+        Phase ph_build(5);
         uint32_t x = 0;
         for (uint32_t i = 0; i < cnt; ++i) {
             const int n = (int)sel[i].keep.size();
