@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libs4g_hip.so")
+LIB_PATH = os.environ.get("S4G_LIB") or os.path.join(_HERE, "lib", "libs4g_hip.so")   # S4G_LIB: A/B builds of the same ABI
 
 S4G_OK = 0
 S4G_ERR_NO_DEVICE = -1

@@ -496,9 +496,10 @@ __device__ __forceinline__ void pkd_rows8(int (&H)[R], int (&E)[R], int row0, co
     }
 }
 
-template <int R, int RR>
+template <int R, int RR, bool FIRST>
 __device__ __forceinline__ void pkd_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
-                                          bool first, bool last, int& best, int eo, int e2, int zrow0) {
+                                          bool last, int& best, int eo, int e2, int zrow0) {
+    constexpr bool first = FIRST;
     constexpr int NB = RR / 8;
     // zrow0 = packed z(i0, 0) = B + i0*e for the strip's first row i0
     int H[R];
@@ -526,11 +527,15 @@ __device__ __forceinline__ void pkd_strip(const uint32_t* res, unsigned len4, co
             int diag = hdiag;
             int F = first ? zcol : fb[cc];           // first strip: F~(0,j) = z(0,j) (F = 0)
             int zcur = zcol;
+            // (LLVM hoists the R per-row constants r*e out of the chunk loop into SGPRs; a few of them spill to VGPR lanes and
+            // come back by v_readlane.  Forcing a single running SGPR instead -- asm s_add, or an opaque e per column -- removes
+            // those reloads but serialises the rows behind SALU->VALU dependencies and measured 1 % SLOWER, A/B on one device.)
+            const int e2c = e2;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 v4i sc[2] = {sc_n[0], sc_n[1]};
                 if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
-                pkd_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, zcur, e2);
+                pkd_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, zcur, e2c);
             }
             hdiag = first ? zcol - e2 : hb[cc];      // first strip: H~(-1, j) = z(0,j) - e
             zcol += e2;
@@ -612,11 +617,18 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
             bool done = false;
 #define S4G_LAST_STRIP(RR_)                                                                                  \
             if constexpr (R > RR_) {                                                                         \
-                if (!done && rr == RR_) { pkd_strip<R, RR_>(res, len4, prof, wsH, wsF, lane, first, last, best, eo, e2, zrow0); done = true; } \
+                if (!done && rr == RR_) {                                                                    \
+                    if (first) pkd_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0); \
+                    else pkd_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);    \
+                    done = true;                                                                             \
+                }                                                                                            \
             }
             S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
 #undef S4G_LAST_STRIP
-            if (!done) pkd_strip<R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, eo, e2, zrow0);
+            if (!done) {
+                if (first) pkd_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
+                else pkd_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
+            }
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) {
