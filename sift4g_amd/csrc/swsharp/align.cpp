@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <thread>
 
 // S4G_PROFILE=1: cumulative wall time per phase of the host API, printed at exit (diagnostic only)
 namespace {
@@ -132,19 +133,27 @@ SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, i
     db->length = databaseLen;
     db->device = pick_device(cards, cardsLen);
     db->dev = NULL;
+    if (cards && cardsLen > 0) db->cards.assign(cards, cards + cardsLen); else db->cards.assign(1, 0);
     std::vector<uint8_t> codes; std::vector<uint64_t> off;
     flatten(db->chains, databaseLen, codes, off);
     db->residues = (long long)off[databaseLen];
-    int rc = s4g_db_create(&db->dev, db->device, codes.data(), off.data(), (uint32_t)databaseLen);
-    if (rc != S4G_OK)
-        SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->device, s4g_last_error());
+    // one resident replica per card: queries are split across the cards (the reference hands its `cards` list through
+    // chainDatabaseCreate and alignDatabase for the same purpose, database_alignment.cpp:80-86)
+    for (int card : db->cards) {
+        s4g_db* rep = NULL;
+        int rc = s4g_db_create(&rep, card, codes.data(), off.data(), (uint32_t)databaseLen);
+        if (rc != S4G_OK)
+            SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", card, s4g_last_error());
+        db->replicas.push_back(rep);
+    }
+    db->dev = db->replicas[0];
     return db;
 }
 
 SW_API void chainDatabaseDelete(ChainDatabase* db) {
     if (!db) return;
     Phase ph(6);
-    s4g_db_destroy(db->dev);
+    for (s4g_db* rep : db->replicas) s4g_db_destroy(rep);
     delete db;
 }
 
@@ -288,25 +297,29 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
 }
 
 // ------------------------------------------------------------------------------------------------ step 1 + glue
-SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
-                            ChainDatabase* cdb, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
-                            void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
-                            int* cards, int cardsLen, Thread* thread) {
-    (void)cards; (void)cardsLen; (void)thread;   // the ChainDatabase already lives on its device
-    SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0, "shotgunDatabase: invalid arguments");
-    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
-    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
-    if (queriesLen == 0 || cdb->length == 0) return;
+// Steps 1-4 for queries [q0, q1) on one card (its own replica of the database); results go to out/outLens[q0..q1).
+static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Chain** all_queries, int q0, int q1, ChainDatabase* cdb,
+                            int card_slot, Scorer* scorer, int maxAlignments, ValueFunction valueFunction, void* valueFunctionParam,
+                            double valueThreshold, int* indexes, int indexesLen) {
+    (void)type;
+    Chain** queries = all_queries + q0;
+    const int queriesLen = q1 - q0;
+    DbAlignment*** dbAlignments_base = out_all + q0;
+    int* dbAlignmentsLens_base = out_lens + q0;
+    DbAlignment**** dbAlignments = &dbAlignments_base;
+    int** dbAlignmentsLens = &dbAlignmentsLens_base;
+    const int device = cdb->cards[card_slot];
+    s4g_db* ddb = cdb->replicas[card_slot];
+    if (queriesLen == 0) return;
 
     std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
     flatten(queries, queriesLen, qcodes, qoff);
     s4g_queries* dq = NULL;
     {
         Phase ph(1);
-        if (s4g_queries_create(&dq, cdb->device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
-            SW_FATAL("cannot place the queries on MI355X device %d: %s", cdb->device, s4g_last_error());
+        if (s4g_queries_create(&dq, device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
+            SW_FATAL("cannot place the queries on MI355X device %d: %s", device, s4g_last_error());
     }
-
     // targets to consider: all, or the caller's subset
     std::vector<int> subset;
     std::vector<Chain*> sub_chains;
@@ -340,8 +353,8 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
         const uint32_t cnt = std::min<uint32_t>(batch, (uint32_t)queriesLen - b);
         {
             Phase ph(2);
-            if (s4g_scan_host(cdb->dev, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
-                SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+            if (s4g_scan_host(ddb, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
+                SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", device, s4g_last_error());
         }
         Phase* ph_sel = new Phase(3);
         // steps 2-3 on the host, one pool task per query (the value callback is the caller's double-precision code)
@@ -373,9 +386,9 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
         std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
         {
             Phase ph(4);
-            if (np && s4g_traceback_host(cdb->dev, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
+            if (np && s4g_traceback_host(ddb, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
                                          path_off.data(), paths.data()) != S4G_OK)
-                SW_FATAL("traceback failed on MI355X device %d: %s", cdb->device, s4g_last_error());
+                SW_FATAL("traceback failed on MI355X device %d: %s", device, s4g_last_error());
         }
         Phase ph_build(5);
         uint32_t x = 0;
@@ -385,7 +398,7 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
             for (int k = 0; k < n; ++k, ++x) {
                 const Survivor& sv = sel[i].keep[k];
                 DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
-                a->query = queries[b + i]; a->query_idx = (int)(b + i);
+                a->query = queries[b + i]; a->query_idx = q0 + (int)(b + i);
                 a->target = cdb->chains[pair_t[x]]; a->target_idx = (int)pair_t[x];
                 a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
                 a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
@@ -400,6 +413,40 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
         }
     }
     s4g_queries_destroy(dq);
+}
+
+
+SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                            ChainDatabase* cdb, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
+                            void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
+                            int* cards, int cardsLen, Thread* thread) {
+    (void)cards; (void)cardsLen; (void)thread;   // the ChainDatabase already lives on its cards
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0, "shotgunDatabase: invalid arguments");
+    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    if (queriesLen == 0 || cdb->length == 0) return;
+    // query-shard over the cards, balanced in query residues; one host thread per card (upstream's multi-GPU model)
+    const int n_cards = std::min<int>((int)cdb->cards.size(), queriesLen);
+    std::vector<int> cut(n_cards + 1, 0);
+    long long total = 0, acc = 0;
+    for (int i = 0; i < queriesLen; ++i) total += chainGetLength(queries[i]);
+    for (int i = 0, c = 1; i < queriesLen && c < n_cards; ++i) {
+        acc += chainGetLength(queries[i]);
+        while (c < n_cards && acc * n_cards >= total * c) cut[c++] = i + 1;
+    }
+    cut[n_cards] = queriesLen;
+    for (int c = 1; c <= n_cards; ++c) cut[c] = std::max(cut[c], cut[c - 1]);
+    if (n_cards == 1) {
+        shotgun_on_card(*dbAlignments, *dbAlignmentsLens, type, queries, 0, queriesLen, cdb, 0, scorer, maxAlignments, valueFunction,
+                        valueFunctionParam, valueThreshold, indexes, indexesLen);
+        return;
+    }
+    std::vector<std::thread> workers;
+    for (int c = 0; c < n_cards; ++c)
+        workers.emplace_back(shotgun_on_card, *dbAlignments, *dbAlignmentsLens, type, queries, cut[c], cut[c + 1], cdb, c, scorer,
+                             maxAlignments, valueFunction, valueFunctionParam, valueThreshold, indexes, indexesLen);
+    for (std::thread& w : workers) w.join();
 }
 
 SW_API void alignDatabase(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,

@@ -47,9 +47,11 @@ struct Scorer {
 struct ChainDatabase {
     Chain** chains;          // borrowed: database + databaseStart
     int length;
-    int device;
-    s4g_db* dev;
+    int device;              // first card
+    s4g_db* dev;             // replica on the first card
     long long residues;
+    std::vector<int> cards;          // every card the database was created for (--cards 0123...; main.cpp:254-262)
+    std::vector<s4g_db*> replicas;   // one resident copy per card; replicas[0] == dev
 };
 
 struct DbAlignment {

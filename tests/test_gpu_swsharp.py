@@ -60,23 +60,29 @@ def test_shotgun_database_batch(oracle_mod, blosum62):
     tch = [sw.chain(f"t{i}", t) for i, t in enumerate(ts)]
     qch = [sw.chain(f"q{i}", q) for i, q in enumerate(qs)]
     tarr, qarr = sw.chain_array(tch), sw.chain_array(qch)
-    cdb = L.chainDatabaseCreate(tarr, 0, len(tch), None, 0)       # zero cards: device 0
     cells = int(sum(len(t) for t in ts))
     ev = L.createEValueParams(cells, s)
     cb = sw.evalue_callback()
-    outs, lens = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
-    L.shotgunDatabase(ctypes.byref(outs), ctypes.byref(lens), 0, qarr, len(qch), cdb, s, 10, cb, ev, 1e-3, None, 0, None, 0, None)
-    total = 0
-    for i in range(len(qs)):
-        ref, nr = pvp(), ci()
-        sc = (ci * len(ts))(*[int(x) for x in exp[i]])
-        L.dbAlignmentsFromScores(ctypes.byref(ref), ctypes.byref(nr), 0, qch[i], tarr, len(tch), sc, s, 10, cb, ev, 1e-3)
-        assert lens[i] == nr.value
-        assert _hits(outs[i], lens[i]) == _hits(ref, nr.value)
-        total += lens[i]
-    assert total >= 40
-    L.deleteShotgunDatabase(outs, lens, len(qs))
-    L.deleteEValueParams(ev); L.chainDatabaseDelete(cdb); L.scorerDelete(s)
+    # zero cards (device 0), and a multi-card list: "--cards 000" = three workers, each with its own replica of the database and
+    # a third of the queries on its own host thread (all on the one GPU of the test box)
+    for cards in (None, (0, 0, 0)):
+        carr = (ci * len(cards))(*cards) if cards else None
+        cdb = L.chainDatabaseCreate(tarr, 0, len(tch), carr, len(cards) if cards else 0)
+        outs, lens = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
+        L.shotgunDatabase(ctypes.byref(outs), ctypes.byref(lens), 0, qarr, len(qch), cdb, s, 10, cb, ev, 1e-3, None, 0, carr,
+                          len(cards) if cards else 0, None)
+        total = 0
+        for i in range(len(qs)):
+            ref, nr = pvp(), ci()
+            sc = (ci * len(ts))(*[int(x) for x in exp[i]])
+            L.dbAlignmentsFromScores(ctypes.byref(ref), ctypes.byref(nr), 0, qch[i], tarr, len(tch), sc, s, 10, cb, ev, 1e-3)
+            assert lens[i] == nr.value
+            assert _hits(outs[i], lens[i]) == _hits(ref, nr.value)
+            total += lens[i]
+        assert total >= 40
+        L.deleteShotgunDatabase(outs, lens, len(qs))
+        L.chainDatabaseDelete(cdb)
+    L.deleteEValueParams(ev); L.scorerDelete(s)
 
 
 DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
