@@ -36,7 +36,7 @@
  *       createFilteredDatabase, database_alignment.cpp:136-162)
  *   s4g_traceback_host
  *       step 4 of swsharp alignDatabase: traceback of the survivors
- *   s4g_topk / s4g_topk_host / s4g_scan_topk
+ *   s4g_topk / s4g_topk_host / s4g_scan_topk / s4g_scan_topk_host
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
  *       and the merge semantics of dbAlignmentsMerge (:101-102)
@@ -157,6 +157,11 @@ int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32
 int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   uint32_t k, int32_t min_score, uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts,
                   void* stream, uint32_t flags);
+/* s4g_scan_topk with one score cut per query (h_min_scores[q_count] in host memory, NULL = 1 for all) and results in
+ * host memory: a conservative integer score cut per query on the device, exact e-values on the survivors on the host. */
+int s4g_scan_topk_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                       uint32_t k, const int32_t* h_min_scores, uint32_t* h_ids, int32_t* h_top_scores, uint32_t* h_counts,
+                       uint32_t flags);
 int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
                   uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream);
 

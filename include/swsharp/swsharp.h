@@ -97,6 +97,16 @@ void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int t
                      void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
                      int* cards, int cardsLen, Thread* thread);
 
+/* shotgunDatabase for the case sift4g actually runs -- valueFunction = eValues (database_alignment.cpp:129-134): the same
+ * alignments, but the library knows the value function, so only the per-query top hits ever leave the device (a
+ * conservative integer score cut per query + exact streaming top-k on the GPU, exact double e-values on the host with an
+ * exactness check against everything that was cut).  This is the form that scales to databases whose Q x N score matrix
+ * cannot be materialised.  Declared in swsharp.h so that evalue.h keeps its reference shape. */
+struct EValueParams;
+void shotgunDatabaseEValues(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                            ChainDatabase* chainDatabase, Scorer* scorer, int maxAlignments, struct EValueParams* eValueParams,
+                            double maxEvalue, int* cards, int cardsLen, Thread* thread);
+
 /* Post-scoring half of alignDatabase (steps 2-4) on scores that are already known: host logic only.
  * database[i] / scores[i], i in [0, databaseLen). */
 void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,

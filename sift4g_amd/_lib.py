@@ -60,6 +60,8 @@ SIGNATURES = {
     "s4g_scan_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
                                      ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_uint32]),
+    "s4g_scan_topk_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                          ctypes.c_uint32, c_i32p, c_u32p, c_i32p, c_u32p, ctypes.c_uint32]),
     "s4g_topk_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                      c_u32p, c_i32p, c_u32p, ctypes.c_void_p]),
     "s4g_traceback_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,

@@ -998,13 +998,15 @@ __device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned
 __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k, uint32_t kpad,
                                                         int32_t min_score, uint32_t* __restrict__ out_ids,
                                                         int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                        const uint32_t* __restrict__ col_ids) {
+                                                        const uint32_t* __restrict__ col_ids,
+                                                        const int32_t* __restrict__ row_min_scores) {
     __shared__ unsigned hist[kBins];
     __shared__ unsigned long long keys[kTopkMax];
     __shared__ int s_hi, s_cut;
     __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
     const int tid = threadIdx.x;
     const int32_t* row = scores + (uint64_t)blockIdx.x * n;
+    if (row_min_scores) min_score = row_min_scores[blockIdx.x];       // per-query cut (e-value driven)
     if (min_score < 0) min_score = 0;
 
     // ---- level 1: high 12 bits ----
@@ -1136,7 +1138,7 @@ S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count
     uint32_t kpad = 2;
     while (kpad < k) kpad <<= 1;
     hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, k, kpad,
-                       min_score, d_ids, d_top_scores, d_counts, (const uint32_t*)nullptr);
+                       min_score, d_ids, d_top_scores, d_counts, (const uint32_t*)nullptr, (const int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return S4G_OK;
 }
@@ -1145,9 +1147,42 @@ S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count
 // database tile: scan into a [batch][tile columns] buffer, exact tile top-k (ids translated to original ids), merge
 // into the running per-query lists.  Tile columns are ordered by original id, so ties break by id exactly as in
 // s4g_topk on the full matrix.  This is the path for databases whose Q x N scores do not fit (BASELINE configs[3]).
+static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, const int32_t* d_min_scores, uint32_t* d_ids, int32_t* d_top_scores,
+                          uint32_t* d_counts, void* stream_, uint32_t flags);
+
 S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                           uint32_t k, int32_t min_score, uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts,
                           void* stream_, uint32_t flags) {
+    return scan_topk_impl(db, q, q_begin, q_count, scorer, k, min_score, nullptr, d_ids, d_top_scores, d_counts, stream_, flags);
+}
+
+// Same with one score cut per query (h_min_scores[q_count], host memory) and host outputs: the form the e-value driven
+// selection uses (a conservative integer score cut per query on the device, exact e-values on the survivors on the host).
+S4G_API int s4g_scan_topk_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                               uint32_t k, const int32_t* h_min_scores, uint32_t* h_ids, int32_t* h_top_scores, uint32_t* h_counts,
+                               uint32_t flags) {
+    if (!db || !q || !scorer || !h_ids || !h_top_scores || !h_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q_count == 0) return S4G_OK;
+    DeviceGuard guard(db->device);
+    DevBuf<uint32_t> d_ids, d_cnt;
+    DevBuf<int32_t> d_sc, d_min;
+    HIP_TRY(d_ids.alloc((size_t)q_count * k)); HIP_TRY(d_sc.alloc((size_t)q_count * k)); HIP_TRY(d_cnt.alloc(q_count));
+    if (h_min_scores) {
+        HIP_TRY(d_min.alloc(q_count));
+        HIP_TRY(hipMemcpy(d_min.p, h_min_scores, (size_t)q_count * 4, hipMemcpyHostToDevice));
+    }
+    int rc = scan_topk_impl(db, q, q_begin, q_count, scorer, k, 1, h_min_scores ? d_min.p : nullptr, d_ids.p, d_sc.p, d_cnt.p, nullptr, flags);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h_counts, d_cnt.p, (size_t)q_count * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_ids, d_ids.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_top_scores, d_sc.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost));
+    return S4G_OK;
+}
+
+static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, const int32_t* d_min_scores, uint32_t* d_ids, int32_t* d_top_scores,
+                          uint32_t* d_counts, void* stream_, uint32_t flags) {
     int rc = check_scan_args(db, q, scorer, q_begin, q_count);
     if (rc) return rc;
     if (k == 0 || k > (uint32_t)kTopkMax) return fail(S4G_ERR_INVALID, "k must be in 1..%d (got %u)", kTopkMax, k);
@@ -1193,7 +1228,7 @@ S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
             if (rc) return rc;
             hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
-                               c_sc, c_cnt, (const uint32_t*)t.d_col_ids);
+                               c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
             hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
                                d_top_scores + (uint64_t)b * k, d_counts + b, c_ids, c_sc, c_cnt, k, kpad2);
             HIP_TRY(hipGetLastError());

@@ -297,6 +297,53 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
 }
 
 // ------------------------------------------------------------------------------------------------ step 1 + glue
+// Step 4 for a batch of queries: one device traceback of every survivor (keep[i][k].idx indexes cdb->chains), then the
+// DbAlignment objects.  `local0` = index of the batch's first query inside the device query set dq.
+static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** queries, int query_idx0, uint32_t local0, uint32_t cnt,
+                            const std::vector<std::vector<Survivor>>& keep, ChainDatabase* cdb, s4g_db* ddb, s4g_queries* dq, int device,
+                            Scorer* scorer) {
+    std::vector<uint32_t> pair_q, pair_t;
+    std::vector<int32_t> pair_score;
+    std::vector<uint64_t> path_off(1, 0);
+    for (uint32_t i = 0; i < cnt; ++i)
+        for (const Survivor& sv : keep[i]) {
+            pair_q.push_back(local0 + i);
+            pair_t.push_back((uint32_t)sv.idx);
+            pair_score.push_back(sv.score);
+            path_off.push_back(path_off.back() + (uint64_t)chainGetLength(queries[i]) + (uint64_t)chainGetLength(cdb->chains[sv.idx]));
+        }
+    const uint32_t np = (uint32_t)pair_q.size();
+    std::vector<int32_t> out5((size_t)np * 5);
+    std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
+    {
+        Phase ph(4);
+        if (np && s4g_traceback_host(ddb, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
+                                     path_off.data(), paths.data()) != S4G_OK)
+            SW_FATAL("traceback failed on MI355X device %d: %s", device, s4g_last_error());
+    }
+    Phase ph_build(5);
+    uint32_t x = 0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const int n = (int)keep[i].size();
+        DbAlignment** out = n ? (DbAlignment**)malloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
+        for (int k = 0; k < n; ++k, ++x) {
+            const Survivor& sv = keep[i][k];
+            DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
+            a->query = queries[i]; a->query_idx = query_idx0 + (int)i;
+            a->target = cdb->chains[sv.idx]; a->target_idx = sv.idx;
+            a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
+            a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
+            a->score = sv.score; a->value = sv.value; a->scorer = scorer;
+            a->path_len = out5[(size_t)x * 5 + 4];
+            a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+            memcpy(a->path, paths.data() + path_off[x], a->path_len);
+            out[k] = a;
+        }
+        out_lists[i] = out;
+        out_lens[i] = n;
+    }
+}
+
 // Steps 1-4 for queries [q0, q1) on one card (its own replica of the database); results go to out/outLens[q0..q1).
 static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Chain** all_queries, int q0, int q1, ChainDatabase* cdb,
                             int card_slot, Scorer* scorer, int maxAlignments, ValueFunction valueFunction, void* valueFunctionParam,
@@ -365,52 +412,15 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
                       valueFunction, valueFunctionParam, valueThreshold, {}};
             tasks[i] = threadPoolSubmit(select_task, &sel[i]);
         }
-        std::vector<uint32_t> pair_q, pair_t;
-        std::vector<int32_t> pair_score;
-        std::vector<uint64_t> path_off(1, 0);
+        std::vector<std::vector<Survivor>> keep(cnt);
         for (uint32_t i = 0; i < cnt; ++i) {
             threadPoolTaskWait(tasks[i]);
             threadPoolTaskDelete(tasks[i]);
-            for (const Survivor& sv : sel[i].keep) {
-                const int tidx = subset.empty() ? sv.idx : subset[sv.idx];
-                pair_q.push_back(b + i);
-                pair_t.push_back((uint32_t)tidx);
-                pair_score.push_back(sv.score);
-                path_off.push_back(path_off.back() + (uint64_t)chainGetLength(queries[b + i]) + (uint64_t)chainGetLength(cdb->chains[tidx]));
-            }
+            keep[i].swap(sel[i].keep);
+            if (!subset.empty()) for (Survivor& sv : keep[i]) sv.idx = subset[sv.idx];     // index into the ChainDatabase
         }
         delete ph_sel;
-        // step 4 on the device: one batched traceback of every survivor of this query batch
-        const uint32_t np = (uint32_t)pair_q.size();
-        std::vector<int32_t> out5((size_t)np * 5);
-        std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
-        {
-            Phase ph(4);
-            if (np && s4g_traceback_host(ddb, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), out5.data(),
-                                         path_off.data(), paths.data()) != S4G_OK)
-                SW_FATAL("traceback failed on MI355X device %d: %s", device, s4g_last_error());
-        }
-        Phase ph_build(5);
-        uint32_t x = 0;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const int n = (int)sel[i].keep.size();
-            DbAlignment** out = n ? (DbAlignment**)malloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
-            for (int k = 0; k < n; ++k, ++x) {
-                const Survivor& sv = sel[i].keep[k];
-                DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
-                a->query = queries[b + i]; a->query_idx = q0 + (int)(b + i);
-                a->target = cdb->chains[pair_t[x]]; a->target_idx = (int)pair_t[x];
-                a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
-                a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
-                a->score = sv.score; a->value = sv.value; a->scorer = scorer;
-                a->path_len = out5[(size_t)x * 5 + 4];
-                a->path = (char*)malloc(a->path_len ? a->path_len : 1);
-                memcpy(a->path, paths.data() + path_off[x], a->path_len);
-                out[k] = a;
-            }
-            (*dbAlignments)[b + i] = out;
-            (*dbAlignmentsLens)[b + i] = n;
-        }
+        trace_and_build(*dbAlignments + b, *dbAlignmentsLens + b, queries + b, q0 + (int)b, b, cnt, keep, cdb, ddb, dq, device, scorer);
     }
     s4g_queries_destroy(dq);
 }
@@ -446,6 +456,149 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
     for (int c = 0; c < n_cards; ++c)
         workers.emplace_back(shotgun_on_card, *dbAlignments, *dbAlignmentsLens, type, queries, cut[c], cut[c + 1], cdb, c, scorer,
                              maxAlignments, valueFunction, valueFunctionParam, valueThreshold, indexes, indexesLen);
+    for (std::thread& w : workers) w.join();
+}
+
+// ------------------------------------------------------------------------------------------------ e-value driven selection
+// shotgunDatabaseEValues: the same result as shotgunDatabase(..., valueFunction = eValues, param = eValueParams, ...), but
+// the library knows the value function, so nothing of size Q x N ever leaves the device:
+//   * per query a CONSERVATIVE integer score cut: the smallest score that can reach maxEvalue for ANY target length
+//     present in the database (e-values fall monotonically with the score);
+//   * streaming scan + exact device top-k' (k' > maxAlignments) above that cut (s4g_scan_topk_host);
+//   * exact double-precision e-values, threshold and final order on the host, on the <= k' survivors only;
+//   * exactness check: everything that was left out scores <= the list's lowest score, so its e-value is at least
+//     Emin(that score) = the best e-value that score can have for any length in the database.  If that is not strictly
+//     worse than the last kept alignment (or than maxEvalue when fewer than maxAlignments were kept), k' is raised and,
+//     as a last resort, the query falls back to the full-row path.
+namespace {
+
+struct EvJob { Chain* query; int m; };
+
+double emin_over_lengths(int score, Chain* query, const std::vector<Chain*>& length_reps, EValueParams* ev) {
+    std::vector<double> v(length_reps.size());
+    std::vector<int> sc(length_reps.size(), score);
+    eValues(v.data(), sc.data(), query, const_cast<Chain**>(length_reps.data()), (int)length_reps.size(), NULL, 0, ev);
+    double best = v[0];
+    for (double x : v) best = std::min(best, x);
+    return best;
+}
+
+}  // namespace
+
+static void shotgun_evalues_on_card(DbAlignment*** out_all, int* out_lens, Chain** all_queries, int q0, int q1, ChainDatabase* cdb,
+                                    int card_slot, Scorer* scorer, int maxAlignments, EValueParams* ev, double maxEvalue,
+                                    const std::vector<Chain*>* length_reps) {
+    Chain** queries = all_queries + q0;
+    const int nq = q1 - q0;
+    if (nq == 0) return;
+    const int device = cdb->cards[card_slot];
+    s4g_db* ddb = cdb->replicas[card_slot];
+    std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
+    flatten(queries, nq, qcodes, qoff);
+    s4g_queries* dq = NULL;
+    if (s4g_queries_create(&dq, device, qcodes.data(), qoff.data(), (uint32_t)nq) != S4G_OK)
+        SW_FATAL("cannot place the queries on MI355X device %d: %s", device, s4g_last_error());
+
+    // conservative score cut per query (cached per query length: the e-value depends on the query only through it)
+    std::vector<int32_t> min_score(nq);
+    {
+        Phase ph(3);
+        std::vector<std::pair<int, int>> cache;
+        for (int i = 0; i < nq; ++i) {
+            const int m = chainGetLength(queries[i]);
+            int found = -1;
+            for (auto& c : cache) if (c.first == m) found = c.second;
+            if (found < 0) {
+                int lo = 1, hi = std::max(2, scorerGetMaxScore(scorer) * std::max(m, 1) + 1);      // E(hi) is astronomically small
+                if (emin_over_lengths(hi, queries[i], *length_reps, ev) > maxEvalue) lo = hi;       // nothing can pass
+                while (lo < hi) {
+                    const int mid = lo + (hi - lo) / 2;
+                    if (emin_over_lengths(mid, queries[i], *length_reps, ev) <= maxEvalue) hi = mid; else lo = mid + 1;
+                }
+                found = lo;
+                cache.push_back({m, found});
+            }
+            min_score[i] = found;
+        }
+    }
+    const int kmax = 4096;
+    int k = std::min(kmax, std::max(4 * std::max(maxAlignments, 1), maxAlignments + 256));
+    if (maxAlignments < 0) k = kmax;
+    std::vector<uint32_t> ids((size_t)nq * k), cnt(nq);
+    std::vector<int32_t> sc((size_t)nq * k);
+    {
+        Phase ph(2);
+        if (s4g_scan_topk_host(ddb, dq, 0, (uint32_t)nq, scorer->dev, (uint32_t)k, min_score.data(), ids.data(), sc.data(), cnt.data(), 0) != S4G_OK)
+            SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", device, s4g_last_error());
+    }
+    std::vector<std::vector<Survivor>> keep(nq);
+    std::vector<int> redo;
+    {
+        Phase ph(3);
+        std::vector<Chain*> cand; std::vector<int> csc; std::vector<double> val;
+        for (int i = 0; i < nq; ++i) {
+            const uint32_t c = cnt[i];
+            cand.resize(c); csc.resize(c); val.resize(c);
+            for (uint32_t x = 0; x < c; ++x) { cand[x] = cdb->chains[ids[(size_t)i * k + x]]; csc[x] = sc[(size_t)i * k + x]; }
+            if (c) eValues(val.data(), csc.data(), queries[i], cand.data(), (int)c, NULL, 0, ev);
+            std::vector<Survivor>& kp = keep[i];
+            for (uint32_t x = 0; x < c; ++x)
+                if (val[x] <= maxEvalue) kp.push_back({(int)ids[(size_t)i * k + x], csc[x], val[x]});
+            std::sort(kp.begin(), kp.end(), [](const Survivor& a, const Survivor& b) {
+                if (a.value != b.value) return a.value < b.value;
+                if (a.score != b.score) return a.score > b.score;
+                return a.idx < b.idx;
+            });
+            if (maxAlignments >= 0 && (int)kp.size() > maxAlignments) kp.resize(maxAlignments);
+            if ((int)c == k) {        // the device list was cut: prove that nothing left out could have made it
+                const double bar = (maxAlignments >= 0 && (int)kp.size() == maxAlignments && !kp.empty()) ? kp.back().value : maxEvalue;
+                if (!(emin_over_lengths(csc[c - 1], queries[i], *length_reps, ev) > bar)) redo.push_back(i);
+            }
+        }
+    }
+    // rare: a query with more near-threshold hits than k' -- full row, the generic path
+    for (int i : redo) {
+        std::vector<int32_t> row(cdb->length);
+        if (s4g_scan_host(ddb, dq, (uint32_t)i, 1, scorer->dev, row.data()) != S4G_OK)
+            SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", device, s4g_last_error());
+        struct P { EValueParams* ev; } prm = {ev};
+        auto vf = [](double* values, int* scores, Chain* query, Chain** database, int n, int* cards, int cardsLen, void* param) {
+            eValues(values, scores, query, database, n, cards, cardsLen, ((P*)param)->ev);
+        };
+        select_survivors(keep[i], queries[i], cdb->chains, cdb->length, row.data(), maxAlignments, vf, &prm, maxEvalue);
+    }
+    trace_and_build(out_all + q0, out_lens + q0, queries, q0, 0, (uint32_t)nq, keep, cdb, ddb, dq, device, scorer);
+    s4g_queries_destroy(dq);
+}
+
+SW_API void shotgunDatabaseEValues(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                                   ChainDatabase* cdb, Scorer* scorer, int maxAlignments, EValueParams* eValueParams, double maxEvalue,
+                                   int* cards, int cardsLen, Thread* thread) {
+    (void)cards; (void)cardsLen; (void)thread;
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0 && eValueParams != NULL, "shotgunDatabaseEValues: invalid arguments");
+    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    if (queriesLen == 0 || cdb->length == 0) return;
+    // one representative chain per distinct target length (the e-value depends on a target only through its length)
+    std::vector<Chain*> reps;
+    {
+        std::vector<std::pair<int, int>> byLen(cdb->length);
+        for (int i = 0; i < cdb->length; ++i) byLen[i] = {chainGetLength(cdb->chains[i]), i};
+        std::sort(byLen.begin(), byLen.end());
+        for (int i = 0; i < cdb->length; ++i)
+            if (i == 0 || byLen[i].first != byLen[i - 1].first) reps.push_back(cdb->chains[byLen[i].second]);
+    }
+    const int n_cards = std::min<int>((int)cdb->cards.size(), queriesLen);
+    std::vector<std::thread> workers;
+    for (int c = 0; c < n_cards; ++c) {
+        const int a = (int)((long long)queriesLen * c / n_cards), b = (int)((long long)queriesLen * (c + 1) / n_cards);
+        if (n_cards == 1)
+            shotgun_evalues_on_card(*dbAlignments, *dbAlignmentsLens, queries, a, b, cdb, c, scorer, maxAlignments, eValueParams, maxEvalue, &reps);
+        else
+            workers.emplace_back(shotgun_evalues_on_card, *dbAlignments, *dbAlignmentsLens, queries, a, b, cdb, c, scorer, maxAlignments,
+                                 eValueParams, maxEvalue, &reps);
+    }
     for (std::thread& w : workers) w.join();
 }
 

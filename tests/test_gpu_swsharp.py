@@ -85,6 +85,43 @@ def test_shotgun_database_batch(oracle_mod, blosum62):
     L.deleteEValueParams(ev); L.scorerDelete(s)
 
 
+def test_evalue_driven_selection_equals_callback_path(oracle_mod, blosum62):
+    """shotgunDatabaseEValues (score cut + streaming device top-k + exact host e-values + exactness check) returns exactly
+    what shotgunDatabase returns with the reference's e-value callback -- including queries with more significant hits than
+    maxAlignments, more than the device list k' (forces the full-row fallback), and none at all."""
+    rng = np.random.default_rng(35)
+    qs = rand_seqs(rng, 9, 80, 260)
+    ts = rand_seqs(rng, 1500, 30, 320)
+    for k in range(700):                                  # query 0: 700 homologs of graded similarity (> k' = 260 at max 1)
+        m = qs[0].copy(); idx = rng.choice(len(m), size=int(rng.integers(1, len(m) // 2)), replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]; ts[k] = m
+    for k in range(700, 760):                             # queries 1..3: 20 homologs each
+        src = qs[1 + (k % 3)]; m = src.copy(); idx = rng.choice(len(m), size=len(m) // 4, replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]; ts[k] = m
+    s = sw.scorer(10, 1)
+    tch = [sw.chain(f"t{i}", t) for i, t in enumerate(ts)]
+    qch = [sw.chain(f"q{i}", q) for i, q in enumerate(qs)]
+    tarr, qarr = sw.chain_array(tch), sw.chain_array(qch)
+    cells = int(sum(len(t) for t in ts))
+    ev = L.createEValueParams(cells, s)
+    cb = sw.evalue_callback()
+    for cards in (None, (0, 0)):
+        carr = (ci * len(cards))(*cards) if cards else None
+        cdb = L.chainDatabaseCreate(tarr, 0, len(tch), carr, len(cards) if cards else 0)
+        for max_al, thr in ((400, 1e-4), (25, 1e-4), (1, 10.0), (5, 1e-30)):
+            a, la = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
+            b, lb = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
+            L.shotgunDatabase(ctypes.byref(a), ctypes.byref(la), 0, qarr, len(qch), cdb, s, max_al, cb, ev, thr, None, 0, None, 0, None)
+            L.shotgunDatabaseEValues(ctypes.byref(b), ctypes.byref(lb), 0, qarr, len(qch), cdb, s, max_al, ev, thr, None, 0, None)
+            for i in range(len(qs)):
+                assert la[i] == lb[i], (max_al, thr, i, la[i], lb[i])
+                assert _hits(a[i], la[i]) == _hits(b[i], lb[i]), (max_al, thr, i)
+            assert la[0] == min(max_al, la[0]) and la[0] >= 1
+            L.deleteShotgunDatabase(a, la, len(qs)); L.deleteShotgunDatabase(b, lb, len(qs))
+        L.chainDatabaseDelete(cdb)
+    L.deleteEValueParams(ev); L.scorerDelete(s)
+
+
 DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
 
 
