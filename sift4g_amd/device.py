@@ -233,7 +233,9 @@ def traceback(db, queries, scorer, pair_q, pair_t, pair_score):
     pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
     pair_score = np.ascontiguousarray(pair_score, dtype=np.int32)
     n = len(pair_q)
-    cap = queries.lengths[pair_q].astype(np.uint64) + db.lengths[pair_t].astype(np.uint64)
+    # (out-of-range ids are reported by the library, not by numpy: clip only for sizing the path buffers)
+    cap = (np.take(queries.lengths, pair_q, mode="clip").astype(np.uint64) +
+           np.take(db.lengths, pair_t, mode="clip").astype(np.uint64)) if n else np.zeros(0, np.uint64)
     off = np.zeros(n + 1, dtype=np.uint64)
     off[1:] = np.cumsum(cap)
     out = np.zeros((max(n, 1), 5), dtype=np.int32)

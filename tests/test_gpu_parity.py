@@ -455,3 +455,67 @@ def test_randomized_configurations(s4g, oracle_mod):
             assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (it, a, b)
             if o["score"]:
                 assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+
+
+def test_concurrent_host_threads_and_streams(s4g, oracle_mod, blosum62, scorer):
+    """the per-device scratch (workspace, counters, query lists) is shared by every database on the device: scans issued
+    from several host threads, on different databases and different streams, must serialise correctly."""
+    import threading
+    import torch
+    rng = np.random.default_rng(36)
+    qs = rand_seqs(rng, 6, 40, 220)
+    sets = [rand_seqs(rng, 150 + 37 * i, 5, 260) for i in range(3)]
+    exps = [oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8) for ts in sets]
+    dbs = [s4g.Database(ts) for ts in sets]
+    q = s4g.QuerySet(qs)
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            for rep in range(6):
+                with torch.cuda.stream(st):
+                    out = torch.empty((len(qs), dbs[i].n), dtype=torch.int32, device="cuda:0")
+                    s4g.scan(dbs[i], q, scorer, out, force_i32=bool(rep & 1))
+                    ids, sc, cnt = s4g.scan_topk(dbs[i], q, scorer, 7, 1)
+                st.synchronize()
+                if not np.array_equal(out.cpu().numpy(), exps[i]):
+                    errors.append((i, rep, "scan"))
+                want = [sorted(range(dbs[i].n), key=lambda j: (-exps[i][r, j], j))[:7] for r in range(len(qs))]
+                if ids.cpu().tolist() != want:
+                    errors.append((i, rep, "topk"))
+        except Exception as e:          # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_argument_errors_are_reported(s4g, scorer):
+    """bad arguments come back as error codes with text (never a crash, never a silent fallback)."""
+    import torch
+    from sift4g_amd._lib import S4GError
+    rng = np.random.default_rng(37)
+    db = s4g.Database(rand_seqs(rng, 70, 5, 60))
+    q = s4g.QuerySet(rand_seqs(rng, 3, 20, 50))
+    out = torch.empty((3, db.n), dtype=torch.int32, device="cuda:0")
+    with pytest.raises(S4GError, match="out of bounds"):
+        s4g.scan(db, q, scorer, torch.empty((5, db.n), dtype=torch.int32, device="cuda:0"), q_begin=2, q_count=5)
+    with pytest.raises(S4GError, match="k must be"):
+        s4g.scan_topk(db, q, scorer, 5000)
+    with pytest.raises(S4GError, match="k must be"):
+        s4g.topk(db, out, 0)
+    with pytest.raises(S4GError, match="out of range"):
+        s4g.Database([np.array([3, 26, 1], dtype=np.uint8)])
+    with pytest.raises(S4GError, match="out of range"):
+        s4g.QuerySet([np.array([31], dtype=np.uint8)])
+    with pytest.raises(S4GError, match="out of range"):
+        s4g.traceback(db, q, scorer, [0], [db.n], [5])
+    with pytest.raises(S4GError, match="device"):
+        s4g.Database(rand_seqs(rng, 2, 5, 9), device=63)
+    with pytest.raises(ValueError):
+        s4g.scan(db, q, scorer, out.to(torch.int64))
