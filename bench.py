@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E column model, 2 int32 loads + 2 stores per cell
 TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
+VALU_PEAK_T = 39.3             # T lane-ops/s: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (integer / packed VALU issue, measured 4 clk per wave64 op)
+VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75, "sw_scan_pk<ArithF16,32>": 3.75,
+                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5}   # algorithmic vector ops per DP cell
 
 
 def cpu_baseline(cfg, n_threads, target_seconds=12.0):
@@ -197,7 +200,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL,
-                         "note": "register-tiled kernel moves ~17/R B per cell, so frac may exceed 1; the binding limit is VALU issue"},
+                         "note": "register-tiled kernel moves ~8/R B per cell, so frac exceeds 1 by construction; the binding limit is VALU issue",
+                         # the limit that actually binds: vector-ALU issue.  algorithmic ops per cell of the dispatched kernel x cells/s
+                         # against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (tools/valu_rates.hip, profiles/r01_valu_rates.txt)
+                         "valu": {"ops_per_cell": VALU_OPS_PER_CELL.get(plan["kernel"]), "peak_T_lane_ops_per_s": VALU_PEAK_T,
+                                  "achieved_T_lane_ops_per_s": round(kern_gcups * VALU_OPS_PER_CELL.get(plan["kernel"], 0) / 1e3, 2),
+                                  "frac": round(kern_gcups * VALU_OPS_PER_CELL.get(plan["kernel"], 0) / 1e3 / VALU_PEAK_T, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)

@@ -573,6 +573,7 @@ struct TileWork {
     uint32_t off_m3 = 0, n_m3 = 0;
     uint32_t off_pk = 0, n_pk = 0;
     uint32_t off_wide = 0, n_wide = 0;     // single ids
+    uint32_t prio_cost[3] = {0, 0, 0};     // per packed tier: rows * len4 at or above which an item runs at raised wave priority
 };
 
 struct Plan {
@@ -706,6 +707,16 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             }
         }
         TileWork w;
+        // critical-path items: larger than a quarter of the per-wave share of their launch (only then can unfair issue
+        // arbitration between co-resident waves stretch the launch)
+        for (int tier = 0; tier < 3; ++tier) {
+            if (ids[tier].empty()) continue;
+            double rows_sum = 0;
+            for (uint32_t id : ids[tier]) rows_sum += q->len[id];
+            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double share = 0.5 * rows_sum * ((double)t.padded_residues / 256.0) / waves;       // (rows * len4) per wave
+            w.prio_cost[tier] = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, share / 4.0));
+        }
         add_pairs(ids[0], &w.off_drift, &w.n_drift);
         add_pairs(ids[1], &w.off_m3, &w.n_m3);
         add_pairs(ids[2], &w.off_pk, &w.n_pk);
@@ -767,13 +778,13 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     a.n_groups = t.n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     if (w.n_drift) {
-        a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3;
+        a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
         a.floor_bits = p.bias | (p.bias << 16);
         hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)t.n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
-        a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2;
+        a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2; a.prio_cost = w.prio_cost[1];
         const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)t.n_groups * w.n_m3);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
@@ -785,7 +796,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         HIP_TRY(hipGetLastError());
     }
     if (w.n_pk) {
-        a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters;
+        a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
         a.floor_bits = 0;
         hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)t.n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());

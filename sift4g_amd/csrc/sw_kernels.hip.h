@@ -237,6 +237,7 @@ struct ScanArgs16 {
     uint32_t n_groups, n_pairs, q_begin;
     uint32_t open, ext;                      // each < 2^15
     uint32_t floor_bits;                     // packed floor of the arithmetic policy (see Arith*)
+    uint32_t prio_cost;                      // items with rows * len4 >= prio_cost run at raised wave priority (0 = never)
 };
 
 __device__ __forceinline__ v2s as_s(v2us x) { return __builtin_bit_cast(v2s, x); }
@@ -421,6 +422,9 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
+        // An item that is large against the per-wave share of the launch sits on the critical path: the SIMD arbitrates
+        // vector issue by priority, then age, so without this a big item on a "young" wave gets the leftovers.
+        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
         int best = fl;
 
         for (unsigned s = 0; s < nstrips; ++s) {
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
+        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);   // see sw_scan_pk
         int best = 0;
 
         for (unsigned s = 0; s < nstrips; ++s) {
