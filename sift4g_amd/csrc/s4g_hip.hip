@@ -890,8 +890,14 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     const uint32_t full = std::max(std::max(p.grid_i32, p.grid_i16), std::max(p.grid_m3, p.grid_drift));
     if (db->tiles.size() > 1) {
         uint64_t need = 0;
-        for (const Tile& t : db->tiles)
-            if ((uint64_t)t.max_len4 * 4 > kLongSeq) need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * tile_grid(t, full));
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
+            const TileWork& w = p.tiles[ti];
+            const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+            const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+            need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
+        }
         if (need) {
             if (!cx->side_stream) {
                 HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
