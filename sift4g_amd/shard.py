@@ -30,6 +30,17 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
+def _all_gather(out, inp, group):
+    """all_gather_into_tensor; with the gloo backend (CPU tests, or two test ranks sharing one GPU) device tensors are
+    staged through host memory -- with nccl (= RCCL) they stay on the device."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def gather_query_shards(ids, scores, counts, n_queries_total, group=None):
     """query-shard mode: rank r holds the hit lists of queries [b_r, b_{r+1}).  Returns the full
     (ids [Q,K], scores [Q,K], counts [Q]) on every rank.  One all-gather of (2K+1) int32 per query."""
@@ -46,7 +57,7 @@ def gather_query_shards(ids, scores, counts, n_queries_total, group=None):
     packed[:q, k:2 * k] = scores
     packed[:q, 2 * k] = counts
     out = torch.empty((world * per, 2 * k + 1), dtype=torch.int32, device=ids.device)   # concatenated along dim 0
-    dist.all_gather_into_tensor(out, packed, group=group)
+    _all_gather(out, packed, group)
     out = out.view(world, per, 2 * k + 1)
     rows = torch.cat([out[r, : bounds[r + 1] - bounds[r]] for r in range(world)], dim=0)
     return rows[:, :k].contiguous(), rows[:, k:2 * k].contiguous(), rows[:, 2 * k].contiguous()
@@ -81,7 +92,7 @@ def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None):
     q, kk = gid.shape
     packed = torch.cat([gid, scores], dim=1).contiguous()
     out = torch.empty((world * q, 2 * kk), dtype=torch.int32, device=gid.device)        # concatenated along dim 0
-    dist.all_gather_into_tensor(out, packed, group=group)
+    _all_gather(out, packed, group)
     out = out.view(world, q, 2 * kk)
     all_ids = out[:, :, :kk].permute(1, 0, 2).reshape(q, world * kk)
     all_sc = out[:, :, kk:].permute(1, 0, 2).reshape(q, world * kk)

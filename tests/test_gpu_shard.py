@@ -1,0 +1,72 @@
+"""Two ranks on the one GPU of the test box (gloo rendezvous, both ranks on cuda:0): the real multi-rank jobs of
+sift4g_amd/shard.py -- query-shard and DB-shard, HIP scans + device top-k + gather/merge -- against a single-process scan."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cfg, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sift4g_amd as s4g
+        from sift4g_amd import shard
+        torch.cuda.set_device(0)
+        scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+        queries = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+        # query-shard: DB replicated, queries split
+        db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+        a = [t.cpu().numpy() for t in shard.scan_query_shard(db, queries, scorer, k)]
+        # DB-shard: length-balanced slices of the DB, all queries on every rank, streaming top-k + merge
+        lengths = np.diff(cfg["t_off"].astype(np.int64))
+        mine = shard.balanced_db_shards(lengths, world)[rank].numpy()
+        off = np.zeros(len(mine) + 1, dtype=np.uint64); off[1:] = np.cumsum(lengths[mine]).astype(np.uint64)
+        codes = np.concatenate([cfg["t_codes"][int(cfg["t_off"][i]):int(cfg["t_off"][i + 1])] for i in mine])
+        part = s4g.Database(codes=codes, offsets=off, tile_seqs=256)
+        b = [t.cpu().numpy() for t in shard.scan_db_shard(part, mine.astype(np.int64), queries, scorer, k)]
+        q.put((rank, a, b))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_process():
+    import sift4g_amd as s4g
+    from sift4g_amd import synth
+    cfg = synth.make_config(2, n_queries=9, n_targets=1200, homologs_per_query=12)
+    cfg = {k: cfg[k] for k in ("q_codes", "q_off", "t_codes", "t_off")}
+    k = 40
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    queries = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    full = torch.empty((queries.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, queries, scorer, full)
+    ids, sc, cnt = s4g.topk(db, full, k, 1)
+    want = (ids.astype(np.int64), sc, cnt.astype(np.int64))
+    ctx = mp.get_context("spawn")
+    qu = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, k, qu)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [qu.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, a, b in res:
+        for got in (a, b):
+            gi = np.where(got[0] < 0, 0xFFFFFFFF, got[0]).astype(np.int64)
+            assert np.array_equal(gi, want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2].astype(np.int64), want[2])
