@@ -31,30 +31,35 @@ VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75,
 
 
 def cpu_baseline(cfg, n_threads, target_seconds=12.0):
-    """The scalar oracle (kind "port": a restatement, NOT swsharp's SSE code) timed on this host's cores on a
-    bounded sample of the same workload."""
+    """The CPU port of the same recurrence timed on this host's cores on a bounded sample of the same workload
+    (kind "port": a restatement, NOT swsharp's own SSE code, which is an absent submodule).  Uses the AVX2
+    inter-sequence port (oracle/sw_simd.c, 16 targets per vector -- the class of code the reference's CPU scorer is) and
+    falls back to the scalar oracle on CPUs without AVX2."""
     import oracle
     M = oracle.blosum62()
     q_off, t_off = cfg["q_off"], cfg["t_off"]
-
-    nq = min(16, len(q_off) - 1)
+    simd = oracle.simd_available()
+    scan = oracle.scan_simd_flat if simd else oracle.scan_flat
+    nq = min(128 if simd else 16, len(q_off) - 1)
     qo = q_off[:nq + 1].copy()
     n_t = len(t_off) - 1
-    chunk = max(64, min(n_t, 16 * n_threads))
+    chunk = max(256, min(n_t, 64 * n_threads))
     cells, dt, nt = 0.0, 0.0, 0
     while nt < n_t and dt < target_seconds:           # time-boxed: whole chunks of targets until ~target_seconds
         hi = min(n_t, nt + chunk)
         to = (t_off[nt:hi + 1] - t_off[nt]).copy()
         tc = cfg["t_codes"][int(t_off[nt]):int(t_off[hi])]
         t0 = time.perf_counter()
-        oracle.scan_flat(cfg["q_codes"], qo, np.ascontiguousarray(tc), to, M, 10, 1, n_threads)
+        scan(cfg["q_codes"], qo, np.ascontiguousarray(tc), to, M, 10, 1, n_threads)
         dt += time.perf_counter() - t0
         cells += float(qo[nq]) * float(to[-1])
         nt = hi
-        chunk = min(chunk * 2, 65536)
+        chunk = min(chunk * 2, 1 << 18)
+    impl = ("AVX2 inter-sequence port (oracle/sw_simd.c, 16 int16 lanes, scalar recheck on saturation)" if simd
+            else "scalar C oracle (oracle/sw_oracle.c)")
     return dict(value=round(cells / dt / 1e9, 3), unit="GCUPS", cores=n_threads, kind="port",
                 sample=f"first {nq} queries x first {nt} targets of the same workload, {cells:.3e} cells in {dt:.1f} s, "
-                       f"scalar C oracle (oracle/sw_oracle.c), {n_threads} pthreads")
+                       f"{impl}, {n_threads} pthreads")
 
 
 def main():
@@ -208,7 +213,8 @@ def main():
                                   "frac": round(kern_gcups * VALU_OPS_PER_CELL.get(plan["kernel"], 0) / 1e3 / VALU_PEAK_T, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
+            n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

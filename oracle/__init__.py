@@ -45,6 +45,11 @@ def lib():
                                        _u32p, _u32p, ctypes.c_uint64,
                                        _i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p]
         L.s4g_oracle_pairs.restype = None
+        L.s4g_oracle_simd_available.argtypes = []
+        L.s4g_oracle_simd_available.restype = ctypes.c_int
+        L.s4g_oracle_scan_simd.argtypes = [_u8p, _u64p, ctypes.c_uint32, _u8p, _u64p, ctypes.c_uint32,
+                                           _i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p]
+        L.s4g_oracle_scan_simd.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -102,6 +107,20 @@ def scan_flat(qcodes, qoff, tcodes, toff, M, gap_open=10, gap_extend=1, threads=
         lib().s4g_oracle_scan(_p(qcodes, _u8p), _p(qoff, _u64p), nq, _p(tcodes, _u8p), _p(toff, _u64p), nt,
                               _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p))
     return out
+
+
+def simd_available():
+    return bool(lib().s4g_oracle_simd_available())
+
+
+def scan_simd_flat(qcodes, qoff, tcodes, toff, M, gap_open=10, gap_extend=1, threads=1):
+    """AVX2 inter-sequence port (oracle/sw_simd.c): the timed CPU baseline.  Returns None without AVX2."""
+    nq, nt = len(qoff) - 1, len(toff) - 1
+    out = np.zeros((nq, nt), dtype=np.int32)
+    M = np.ascontiguousarray(M, dtype=np.int32)
+    rc = lib().s4g_oracle_scan_simd(_p(qcodes, _u8p), _p(qoff, _u64p), nq, _p(tcodes, _u8p), _p(toff, _u64p), nt,
+                                    _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p))
+    return out if rc == 0 else None
 
 
 def scan(queries, targets, M, gap_open=10, gap_extend=1, threads=1):

@@ -135,6 +135,7 @@ static int sw_score_work(const uint8_t* q, int lq, const uint8_t* t, int lt,
     return best;
 }
 
+int s4g_oracle_sw_score(const uint8_t* q, int lq, const uint8_t* t, int lt, const int32_t* M, int open, int ext);
 S4G_ORACLE_API int s4g_oracle_sw_score(const uint8_t* q, int lq, const uint8_t* t, int lt,
                                        const int32_t* M, int open, int ext) {
     if (lq <= 0 || lt <= 0) return 0;

@@ -135,3 +135,21 @@ def test_pairs_and_scan_agree(oracle_mod, blosum62):
     pq = np.array([4, 0, 2], dtype=np.uint32); pt = np.array([8, 3, 3], dtype=np.uint32)
     got = oracle_mod.pairs_flat(qc, qo, tc, to, pq, pt, blosum62, 10, 1, threads=2)
     assert got.tolist() == [full[4, 8], full[0, 3], full[2, 3]]
+
+
+def test_simd_port_equals_scalar_oracle(oracle_mod, blosum62):
+    """oracle/sw_simd.c (the timed CPU baseline) against the scalar restatement: every letter code, empty and ragged
+    inputs, target counts that are not a multiple of the vector width, and scores beyond int16 (scalar recheck)."""
+    if not oracle_mod.simd_available():
+        pytest.skip("no AVX2 on this CPU")
+    from oracle import _flat
+    rng = np.random.default_rng(51)
+    W = ord("W") - 65
+    qs = rand_seqs(rng, 7, 0, 300, 26) + [np.full(3100, W, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    ts = rand_seqs(rng, 83, 0, 400, 26) + [np.full(3300, W, dtype=np.uint8), np.zeros(0, dtype=np.uint8), qs[0][5:].copy()]
+    qc, qo = _flat(qs); tc, to = _flat(ts)
+    for go, ge in ((10, 1), (5, 5), (14, 0)):
+        a = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, go, ge, threads=4)
+        b = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, go, ge, threads=3)
+        assert np.array_equal(a, b), (go, ge, np.argwhere(a != b)[:5])
+    assert a[7, 83] == 3100 * 11          # > 32767: went through the scalar recheck
