@@ -28,7 +28,7 @@
  *   s4g_queries_create / s4g_queries_destroy
  *       the `Chain* query` argument of alignDatabase
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
- *   s4g_scan / s4g_scan_flags / s4g_scan_host / s4g_scan_host_flags / s4g_score_lists_host
+ *   s4g_scan / s4g_scan_flags / s4g_scan_host / s4g_scan_host_flags / s4g_score_lists_host / s4g_score_pairs_host
  *       step 1 of swsharp alignDatabase(...): the optimal local affine-gap
  *       score of the query against every target of the ChainDatabase
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
@@ -124,6 +124,7 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 #define S4G_SCAN_FORCE_I32 1u
 #define S4G_SCAN_NO_F16    2u   /* skip the v_pk_maximum3_f16 tier (those queries then run in the plain packed int16 kernel) */
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */
+#define S4G_SCAN_NO_PAIRS  16u  /* never take the one-wave-per-pair latency route (sw_pair_scan); any other flag implies this */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
@@ -140,6 +141,18 @@ int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin
  * h_scores[cand_offsets[n_queries]] receives the scores in list order. */
 int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t* cand_offsets,
                          const uint32_t* cand_ids, const s4g_scorer* scorer, int32_t* h_scores);
+
+/* The same for an explicit pair list: h_scores[i] = score(query pair_q[i], target pair_t[i]).
+ * This is the latency path of the per-query alignDatabase call
+ * (/root/reference/sift4g/src/database_alignment.cpp:83-86 with `indexes` = that query's candidates):
+ * every pair gets a wave of its own (anti-diagonal sweep, sw_pair.hip.h) instead of sharing a wave with 63
+ * length-sorted neighbours, so a call is bounded by ~0.7 cycles per cell of its longest pair rather than ~26.
+ * Queries longer than 1024 residues, and candidate lists that approach the whole database, are served exactly by
+ * scanning the resident database and picking the columns; flags force one route (tests, measurements). */
+#define S4G_PAIRS_FORCE_WAVE 1u  /* one wave per pair; error if a query exceeds 1024 residues */
+#define S4G_PAIRS_FORCE_SCAN 2u  /* full scan + column pick */
+int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint64_t n_pairs,
+                         const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, uint32_t flags);
 
 /* Per-query top-k of a device score matrix [q_count][n_seqs] (as written by
  * s4g_scan): the k highest scores with score >= min_score, ordered by score

@@ -1,7 +1,7 @@
 """ctypes face of oracle/libsw_oracle.so -- TEST INFRASTRUCTURE ONLY.
 
 Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
-Nothing under sift4g_amd/ imports this package (tests/test_layout.py enforces it).
+Nothing under sift4g_amd/ imports this package (tests/test_abi.py::test_product_never_touches_the_oracle enforces it).
 The oracle is "parity unpinned": see the header of oracle/sw_oracle.c.
 """
 import ctypes

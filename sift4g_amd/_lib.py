@@ -19,6 +19,7 @@ S4G_SCAN_FORCE_I32 = 1
 S4G_SCAN_NO_F16 = 2
 S4G_SCAN_F16_ARITH = 4
 S4G_SCAN_NO_DRIFT = 8
+S4G_SCAN_NO_PAIRS = 16
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -55,6 +56,8 @@ SIGNATURES = {
     "s4g_scan_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_void_p, c_i32p]),
     "s4g_score_lists_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u32p, ctypes.c_void_p, c_i32p]),
+    "s4g_score_pairs_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, c_u32p, c_u32p, c_i32p,
+                                            ctypes.c_uint32]),
     "s4g_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "s4g_scan_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,

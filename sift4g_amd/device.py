@@ -141,12 +141,14 @@ def scan_plan(db, queries, scorer):
                 workspace_bytes=w.value)
 
 
-def _flags(force_i32=False, no_f16=False, f16_arith=False, no_drift=False):
+def _flags(force_i32=False, no_f16=False, f16_arith=False, no_drift=False, no_pairs=False):
     return ((_lib.S4G_SCAN_FORCE_I32 if force_i32 else 0) | (_lib.S4G_SCAN_NO_F16 if no_f16 else 0) |
-            (_lib.S4G_SCAN_F16_ARITH if f16_arith else 0) | (_lib.S4G_SCAN_NO_DRIFT if no_drift else 0))
+            (_lib.S4G_SCAN_F16_ARITH if f16_arith else 0) | (_lib.S4G_SCAN_NO_DRIFT if no_drift else 0) |
+            (_lib.S4G_SCAN_NO_PAIRS if no_pairs else 0))
 
 
-def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False):
+def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False,
+         no_pairs=False):
     """Asynchronous scan into a device tensor `out` (torch int32 [q_count, n_seqs], on db.device).
 
     stream: a torch.cuda.Stream (default: torch's current stream on that device)."""
@@ -157,16 +159,17 @@ def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i
     if stream is None:
         stream = torch.cuda.current_stream(out.device)
     check(lib.s4g_scan_flags(db._h, queries._h, q_begin, q_count, scorer._h, ctypes.c_void_p(out.data_ptr()),
-                             ctypes.c_void_p(stream.cuda_stream), _flags(force_i32, no_f16, f16_arith, no_drift)), "s4g_scan_flags")
+                             ctypes.c_void_p(stream.cuda_stream), _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs)), "s4g_scan_flags")
     return out
 
 
-def scan_host(db, queries, scorer, q_begin=0, q_count=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False):
+def scan_host(db, queries, scorer, q_begin=0, q_count=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False,
+              no_pairs=False):
     """Synchronous scan -> numpy int32 [q_count, n_seqs]."""
     q_count = queries.n - q_begin if q_count is None else q_count
     out = np.zeros((q_count, db.n), dtype=np.int32)
     check(lib.s4g_scan_host_flags(db._h, queries._h, q_begin, q_count, scorer._h, _ptr(out, c_i32p),
-                                  _flags(force_i32, no_f16, f16_arith, no_drift)), "s4g_scan_host_flags")
+                                  _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs)), "s4g_scan_host_flags")
     return out
 
 
@@ -177,6 +180,19 @@ def score_lists(db, queries, scorer, cand_offsets, cand_ids):
     check(lib.s4g_score_lists_host(db._h, queries._h, _ptr(cand_offsets, c_u64p), _ptr(cand_ids, c_u32p), scorer._h,
                                    _ptr(out, c_i32p)), "s4g_score_lists_host")
     return out[: int(cand_offsets[-1])]
+
+
+def score_pairs(db, queries, scorer, pair_q, pair_t, route=None):
+    """scores of explicit (query, target) pairs; route = None (cost model) | "wave" (one wave per pair) | "scan"."""
+    pair_q = np.ascontiguousarray(pair_q, dtype=np.uint32)
+    pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
+    if pair_q.shape != pair_t.shape or pair_q.ndim != 1:
+        raise ValueError("pair_q and pair_t must be 1-D arrays of the same length")
+    out = np.zeros(max(len(pair_q), 1), dtype=np.int32)
+    flags = {None: 0, "wave": 1, "scan": 2}[route]
+    check(lib.s4g_score_pairs_host(db._h, queries._h, scorer._h, len(pair_q), _ptr(pair_q, c_u32p), _ptr(pair_t, c_u32p),
+                                   _ptr(out, c_i32p), flags), "s4g_score_pairs_host")
+    return out[: len(pair_q)]
 
 
 def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False,

@@ -25,7 +25,8 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     exp = oracle_mod.scan(queries, targets, M, go, ge, threads=threads)
     # default plan (fastest exact kernel per query: drifting-frame int16 / maximum3-int16 / plain packed int16 / int32),
     # without the drift kernel, the f16-arithmetic form of the maximum3 tier, no maximum3 at all, int32 alone
-    for mode in (dict(), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+    # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
+    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
@@ -36,15 +37,17 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
 def test_micro_known_answers(s4g, oracle_mod, micro, scorer):
     qs = [oracle_mod.encode(c["q"]) for c in micro["cases"]]
     ts = [oracle_mod.encode(c["t"]) for c in micro["cases"]]
-    got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), scorer)
-    for i, c in enumerate(micro["cases"]):
-        assert got[i, i] == c["score"], (c["name"], int(got[i, i]), c["score"])
+    for mode in (dict(), dict(no_pairs=True)):
+        got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), scorer, **mode)
+        for i, c in enumerate(micro["cases"]):
+            assert got[i, i] == c["score"], (mode, c["name"], int(got[i, i]), c["score"])
 
 
 def test_cfg1_reference_fixture(s4g, cfg1, scorer):
     """BASELINE.json configs[0]: test_files/query.fasta x sample_protein_database.fa vs the golden 2 x 9 matrix."""
-    got = s4g.scan_host(s4g.Database([c for _, c in cfg1["targets"]]), s4g.QuerySet([c for _, c in cfg1["queries"]]), scorer)
-    assert np.array_equal(got, cfg1["scores"])
+    db, q = s4g.Database([c for _, c in cfg1["targets"]]), s4g.QuerySet([c for _, c in cfg1["queries"]])
+    assert np.array_equal(s4g.scan_host(db, q, scorer), cfg1["scores"])                    # latency route (pairs)
+    assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), cfg1["scores"])     # scan kernels
 
 
 def test_random_standard_alphabet(s4g, oracle_mod, blosum62, scorer):
@@ -327,7 +330,8 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         assert sum(tiles) == len(ts)
         if tile_seqs == 64:
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 12288-residue sequences form their own tile (side stream)
-        for mode in (dict(), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+        # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
+    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
@@ -519,3 +523,76 @@ def test_argument_errors_are_reported(s4g, scorer):
         s4g.Database(rand_seqs(rng, 2, 5, 9), device=63)
     with pytest.raises(ValueError):
         s4g.scan(db, q, scorer, out.to(torch.int64))
+
+
+# ---------------------------------------------------------------------------------------------- pair lists (sw_pair.hip.h)
+def _pairs_check(s4g, oracle_mod, M, qs, ts, pq, pt, sc, go=10, ge=1, routes=("wave", None, "scan")):
+    qc, qo = oracle_mod._flat(qs)
+    tc, to = oracle_mod._flat(ts)
+    want = oracle_mod.pairs_flat(qc, qo, tc, to, pq, pt, M, go, ge, threads=8)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    for route in routes:
+        got = s4g.score_pairs(db, q, sc, pq, pt, route=route)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, (f"route {route}: {len(bad)} mismatches, first pairs {bad[:5].tolist()} "
+                               f"(lq {len(qs[pq[bad[0]]])}, lt {len(ts[pt[bad[0]]])}) got {got[bad[0]]} want {want[bad[0]]}")
+
+
+def test_pairs_every_row_block_class(s4g, oracle_mod, blosum62, scorer):
+    """one wave per pair: query lengths on both sides of every rows-per-lane class (64 x {2,4,6,8,12,16} rows) and
+    target lengths around the 4-column dword and the 64-lane skew."""
+    rng = np.random.default_rng(31)
+    qlens = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 767, 768, 769, 1023, 1024]
+    tlens = [1, 2, 3, 4, 5, 62, 63, 64, 65, 66, 127, 129, 300, 777]
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
+    ts = [rand_seqs(rng, 1, l, l)[0] for l in tlens]
+    pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), scorer)
+
+
+def test_pairs_random_lists_all_codes(s4g, oracle_mod, blosum62, scorer):
+    """scattered candidate lists (with repeats) over a database with all 26 codes, homologs planted."""
+    rng = np.random.default_rng(32)
+    qs = rand_seqs(rng, 12, 30, 700, 26)
+    ts = rand_seqs(rng, 900, 1, 900, 26)
+    for i in range(0, 900, 37):                              # high-scoring pairs: a mutated copy of some query
+        src = qs[i % len(qs)].copy()
+        src[rng.integers(0, len(src), size=max(1, len(src) // 10))] = rng.integers(0, 20, size=max(1, len(src) // 10))
+        ts[i] = np.delete(src, rng.integers(0, len(src), size=3))
+    n = 4000
+    pq = rng.integers(0, len(qs), size=n)
+    pt = rng.integers(0, len(ts), size=n)
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq, pt, scorer)
+
+
+def test_pairs_target_windows_and_long_queries(s4g, oracle_mod, blosum62, scorer):
+    """targets longer than the 4096-column LDS window (several windows, odd step counts); queries beyond 1024 residues
+    take the scan route inside the same call."""
+    rng = np.random.default_rng(33)
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in (97, 350, 640, 1024, 1025, 2300)]
+    ts = [rand_seqs(rng, 1, l, l)[0] for l in (4095, 4096, 4097, 8191, 8200, 12289, 13001, 40, 1)]
+    ts[4][100:450] = qs[1]                                   # a real hit deep inside the second window
+    ts[6][8100:8740] = qs[2]
+    pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), scorer, routes=(None, "scan"))
+    short = pq.ravel() < 4
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel()[short], pt.ravel()[short], scorer, routes=("wave",))
+    with pytest.raises(RuntimeError):
+        s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [5], [0], route="wave")
+
+
+def test_pairs_empty_sequences_and_other_scorers(s4g, oracle_mod, blosum62, scorer):
+    rng = np.random.default_rng(34)
+    e = np.zeros(0, dtype=np.uint8)
+    qs = [e, rand_seqs(rng, 1, 90, 90)[0], rand_seqs(rng, 1, 300, 300)[0]]
+    ts = [rand_seqs(rng, 1, 120, 120)[0], e, rand_seqs(rng, 1, 1000, 1000)[0]]
+    pq, pt = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), scorer)
+    assert len(s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [], [])) == 0
+    for go, ge in ((1, 1), (12, 3), (40, 40)):
+        _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), s4g.Scorer("BLOSUM_62", go, ge), go, ge)
+    M = rng.integers(-30, 60, size=(26, 26)).astype(np.int32)     # large, asymmetric scores: int32 range is exercised
+    M[:, 3] = 55
+    _pairs_check(s4g, oracle_mod, M, qs, ts, pq.ravel(), pt.ravel(), s4g.Scorer(M, 7, 2), 7, 2)
+    with pytest.raises(RuntimeError):
+        s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [3], [0])
