@@ -20,7 +20,7 @@ build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	@mkdir -p build
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
-$(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h $(CSRC)/sw_trace.hip.h $(CSRC)/matrices.h include/s4g_hip.h
+$(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(wildcard $(CSRC)/*.h) include/s4g_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/s4g_hip.hip
 
@@ -38,7 +38,7 @@ dropin: $(LIBDIR)/libswsharp.so
 oracle:
 	$(MAKE) -s -C oracle
 
-isa: $(CSRC)/s4g_hip.hip $(CSRC)/sw_kernels.hip.h
+isa: $(CSRC)/s4g_hip.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p build/isa
 	cd build/isa && $(HIPCC) $(HIPFLAGS) -c -save-temps -Rpass-analysis=kernel-resource-usage ../../$(CSRC)/s4g_hip.hip -o s4g_hip.o
 

@@ -69,6 +69,8 @@ SIGNATURES = {
                                      c_u32p, c_i32p, c_u32p, ctypes.c_void_p]),
     "s4g_traceback_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,
                                           c_i32p, c_i32p, c_u64p, c_u8p]),
+    "s4g_traceback_host_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,
+                                          c_i32p, c_i32p, c_u64p, c_u8p, ctypes.c_uint32]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_u64p]),
 }

@@ -123,6 +123,7 @@ struct DeviceCtx {
     uint64_t tile_scores_bytes = 0;
     uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
     uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
     // pair lists: pinned staging for the items of the current call, their device copy (+ host-route scores behind it)
     s4g::PairItem* h_items = nullptr;
     s4g::PairItem* d_items = nullptr;
@@ -1554,13 +1555,141 @@ S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_
 
 // ---------------------------------------------------------------------------
 // Traceback of the survivors on the device (step 4 of alignDatabase).
-S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
-                               const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
-                               int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+namespace {
+
+template <int RPL>
+int launch_pair_trace(DeviceCtx* cx, PairTraceArgs a, uint32_t* grid_cache, hipStream_t stream) {
+    if (*grid_cache == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace<RPL>, 64, 0));
+        *grid_cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(*grid_cache, a.n_pairs));
+    hipLaunchKernelGGL(sw_pair_trace<RPL>, dim3(grid), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// Traceback with one wave per pair (sw_pair_trace): `sel` = indices of the pairs whose query has <= kPairMaxRows residues.
+int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                    const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    hipStream_t stream = nullptr;
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    // class-major, longest target first (32-residue granularity), as in score_pairs_device
+    const uint32_t n = (uint32_t)sel.size();
+    constexpr uint32_t kBuckets = 2048;
+    std::vector<uint32_t> count((size_t)kPairClasses * kBuckets + 1, 0), order(n);
+    auto key_of = [&](uint32_t pi) {
+        const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
+        return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
+    };
+    for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
+    for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+    uint32_t cls_begin[kPairClasses + 1];
+    for (int c = 0; c <= kPairClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    for (uint32_t i = 0; i < n; ++i) order[count[key_of(sel[i])]++] = sel[i];
+    auto dir_bytes = [&](uint32_t pi) {
+        const int c = pair_class(q->len[pair_q[pi]]);
+        const uint32_t rpl = (uint32_t)kPairRpl[c], nw = rpl <= 4 ? 1 : (rpl <= 8 ? 2 : 4);
+        const uint64_t steps = (uint64_t)db->len[pair_t[pi]] + (q->len[pair_q[pi]] + rpl - 1) / rpl - 1;
+        return ((steps + 1) & ~1ull) * 64 * nw * 4;
+    };
+    const uint64_t dir_budget = 8ull << 30;
+    std::vector<PairTraceItem> items;
+    std::vector<int32_t> out5, best;
+    std::vector<uint8_t> paths;
+    for (uint32_t b0 = 0; b0 < n;) {
+        // a batch: consecutive pairs of ONE class whose direction blocks fit the budget
+        int c = 0;
+        while (cls_begin[c + 1] <= b0) ++c;
+        uint32_t b1 = b0;
+        uint64_t dir_total = 0, path_total = 0;
+        items.clear();
+        while (b1 < cls_begin[c + 1] && (b1 == b0 || dir_total + dir_bytes(order[b1]) <= dir_budget)) {
+            const uint32_t pi = order[b1];
+            const uint64_t cap = (uint64_t)q->len[pair_q[pi]] + db->len[pair_t[pi]];
+            path_total += cap;
+            items.push_back({pair_q[pi], pair_t[pi], pair_score[pi], b1 - b0, dir_total, path_total});
+            dir_total += dir_bytes(pi);
+            ++b1;
+        }
+        const uint32_t ni = b1 - b0;
+        const bool big_dirs = dir_total > (256ull << 20);
+        DevBuf<uint8_t> d_dirs_big;
+        if (big_dirs) HIP_TRY(d_dirs_big.alloc(dir_total));
+        uint64_t need = 0;
+        auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
+        const uint64_t o_items = reserve((uint64_t)ni * sizeof(PairTraceItem)), o_out = reserve((uint64_t)ni * 20), o_best = reserve((uint64_t)ni * 4);
+        const uint64_t o_paths = reserve(path_total), o_dirs = big_dirs ? 0 : reserve(dir_total);
+        if (cx->arena_bytes < need) {
+            if (cx->arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->arena)); }
+            cx->arena = nullptr; cx->arena_bytes = 0;
+            const uint64_t want = std::max<uint64_t>(need + need / 4, 16ull << 20);
+            HIP_TRY(hipMalloc((void**)&cx->arena, want));
+            cx->arena_bytes = want;
+        }
+        char* A = cx->arena;
+        HIP_TRY(hipMemcpyAsync(A + o_items, items.data(), (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(cx->d_counter + 32, 0, 4, stream));
+        PairTraceArgs a;
+        a.items = reinterpret_cast<const PairTraceItem*>(A + o_items); a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+        a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
+        a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
+        a.counter = cx->d_counter + 32; a.n_pairs = ni; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        switch (c) {
+            case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
+            case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
+            case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
+            case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
+            case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
+            default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
+        }
+        if (rc) return rc;
+        out5.resize((size_t)ni * 5); best.resize(ni); paths.resize(path_total ? path_total : 1);
+        HIP_TRY(hipMemcpyAsync(out5.data(), A + o_out, (size_t)ni * 20, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(best.data(), A + o_best, (size_t)ni * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(paths.data(), A + o_paths, path_total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (uint32_t x = 0; x < ni; ++x) {
+            const uint32_t pi = order[b0 + x];
+            const int32_t want = pair_score[pi] > 0 && q->len[pair_q[pi]] && db->len[pair_t[pi]] ? pair_score[pi] : 0;
+            if (best[x] != want && !(pair_score[pi] <= 0 && best[x] == 0))
+                return fail(S4G_ERR_INVALID, "pair %u: score %d passed in, traceback kernel computed %d", pi, pair_score[pi], best[x]);
+            memcpy(h_out + (size_t)pi * 5, out5.data() + (size_t)x * 5, 20);
+            const uint32_t len = (uint32_t)out5[(size_t)x * 5 + 4];
+            memcpy(h_paths + path_off[pi], paths.data() + items[x].path_end - len, len);
+        }
+        b0 = b1;
+    }
+    return S4G_OK;
+}
+
+int traceback_groups(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);
+
+}  // namespace
+
+S4G_API int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths, uint32_t flags) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (n_pairs == 0) return S4G_OK;
     if (!pair_q || !pair_t || !pair_score || !h_out || !path_off || !h_paths) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if ((flags & S4G_PAIRS_FORCE_SCAN) && (flags & S4G_PAIRS_FORCE_WAVE)) return fail(S4G_ERR_INVALID, "contradictory flags");
     for (uint32_t i = 0; i < n_pairs; ++i) {
         if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %u out of range", i);
         if (q->len[pair_q[i]] >= 65535 || db->len[pair_t[i]] >= 65535)
@@ -1568,6 +1697,52 @@ S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g
         if (path_off[i + 1] - path_off[i] < (uint64_t)q->len[pair_q[i]] + db->len[pair_t[i]])
             return fail(S4G_ERR_INVALID, "pair %u: path capacity must be at least query length + target length", i);
     }
+    // one wave per pair (sw_pair_trace) for queries of up to kPairMaxRows residues; the 64-pairs-per-wave strip kernels
+    // (sw_trace_fill + sw_trace_walk) for the rest
+    std::vector<uint32_t> wave_sel, group_sel;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const bool wave = !(flags & S4G_PAIRS_FORCE_SCAN) && q->len[pair_q[i]] <= (uint32_t)kPairMaxRows;
+        if (!wave && (flags & S4G_PAIRS_FORCE_WAVE))
+            return fail(S4G_ERR_INVALID, "pair %u: query of %u residues; the pair kernel takes at most %d", i, q->len[pair_q[i]], kPairMaxRows);
+        (wave ? wave_sel : group_sel).push_back(i);
+    }
+    if (!wave_sel.empty()) {
+        int rc = traceback_pairs(db, q, scorer, wave_sel, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
+        if (rc) return rc;
+    }
+    if (group_sel.empty()) return S4G_OK;
+    if (group_sel.size() == n_pairs) return traceback_groups(db, q, scorer, n_pairs, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
+    // mixed call: compact the remaining pairs, run them, scatter the results
+    const uint32_t m = (uint32_t)group_sel.size();
+    std::vector<uint32_t> gq(m), gt(m);
+    std::vector<int32_t> gs(m), gout((size_t)m * 5);
+    std::vector<uint64_t> goff(m + 1, 0);
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t i = group_sel[k];
+        gq[k] = pair_q[i]; gt[k] = pair_t[i]; gs[k] = pair_score[i];
+        goff[k + 1] = goff[k] + (path_off[i + 1] - path_off[i]);
+    }
+    std::vector<uint8_t> gpaths(goff[m] ? goff[m] : 1);
+    int rc = traceback_groups(db, q, scorer, m, gq.data(), gt.data(), gs.data(), gout.data(), goff.data(), gpaths.data());
+    if (rc) return rc;
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t i = group_sel[k];
+        memcpy(h_out + (size_t)i * 5, gout.data() + (size_t)k * 5, 20);
+        memcpy(h_paths + path_off[i], gpaths.data() + goff[k], (size_t)gout[(size_t)k * 5 + 4]);
+    }
+    return S4G_OK;
+}
+
+S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                               const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                               int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+    return s4g_traceback_host_flags(db, q, scorer, n_pairs, pair_q, pair_t, pair_score, h_out, path_off, h_paths, 0);
+}
+
+namespace {
+int traceback_groups(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
@@ -1703,3 +1878,4 @@ S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g
     }
     return S4G_OK;
 }
+}  // namespace

@@ -41,37 +41,70 @@ __device__ __forceinline__ int wave_shr1(int v) {     // lane l <- lane l-1, lan
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
 }
 
-// LDS reads issued by hand: the result registers are only valid after the matching lds_wait*, which also pins the
-// consumers behind the wait (the value is an in/out operand of the s_waitcnt statement).
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ void lds_u8(unsigned& dst, unsigned addr) { asm volatile("ds_read_u8 %0, %1" : "=v"(dst) : "v"(addr)); }
-__device__ __forceinline__ void lds_wait(unsigned& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
-struct alignas(4) Pack1 { int w[1]; };
-struct alignas(8) Pack2 { int w[2]; };
-struct alignas(16) Pack4 { int w[4]; };
-__device__ __forceinline__ void lds_pack(Pack1& d, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d.w[0]) : "v"(addr)); }
-__device__ __forceinline__ void lds_pack(Pack2& d, unsigned addr) {
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    v2i x;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(x) : "v"(addr));
-    d.w[0] = x[0]; d.w[1] = x[1];
-}
-__device__ __forceinline__ void lds_pack(Pack4& d, unsigned addr) {
-    v4i x;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr));
-    d.w[0] = x[0]; d.w[1] = x[1]; d.w[2] = x[2]; d.w[3] = x[3];
-}
-__device__ __forceinline__ void lds_wait_pack(Pack1& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d.w[0])); }
-__device__ __forceinline__ void lds_wait_pack(Pack2& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d.w[0]), "+v"(d.w[1])); }
-__device__ __forceinline__ void lds_wait_pack(Pack4& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d.w[0]), "+v"(d.w[1]), "+v"(d.w[2]), "+v"(d.w[3]));
-}
+// Software pipelining of the two dependent LDS reads of a step (target residue -> packed scores).  The reads are plain
+// loads the compiler tracks; `pin` is an empty statement that makes a value opaque at a chosen point, which (a) keeps
+// the compiler from rotating the loop back into load -> wait -> use (that exposes two LDS round trips per step) and
+// (b) puts the s_waitcnt where the statement stands, i.e. after the step that ran underneath the loads.
+// (An earlier version issued the ds_reads through asm statements with a separate s_waitcnt statement; the compiler
+// then copied a register between the two statements -- before the data had arrived -- in one instantiation.  Memory
+// operations the compiler cannot see are not worth that risk, so the loads stay ordinary loads.)
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin(unsigned& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(v2i& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(v4i& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ int pk_get(int v, int) { return v; }
+template <typename V> __device__ __forceinline__ int pk_get(const V& v, int i) { return v[i]; }
+__device__ __forceinline__ void pk_set(int& v, int, int x) { v = x; }
+template <typename V> __device__ __forceinline__ void pk_set(V& v, int i, int x) { v[i] = x; }
 template <int NW> struct PackOf;
-template <> struct PackOf<1> { typedef Pack1 type; };
-template <> struct PackOf<2> { typedef Pack2 type; };
-template <> struct PackOf<4> { typedef Pack4 type; };
+template <> struct PackOf<1> { typedef int type; };
+template <> struct PackOf<2> { typedef v2i type; };
+template <> struct PackOf<4> { typedef v4i type; };
+
+// lane profile: prof[(t*64 + lane)*NW + w] byte b = M[q_{lane*RPL + 4w + b}][t]  (rows beyond the query: pad code)
+template <int RPL, int NW>
+__device__ __forceinline__ void pair_build_profile(char* prof, const int* lmat4, const uint8_t* qc, unsigned lq, int lane) {
+    typedef typename PackOf<NW>::type vnw;
+    __builtin_amdgcn_wave_barrier();
+    int rows[RPL][8];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const unsigned i = (unsigned)lane * RPL + r;
+        const unsigned code = i < lq ? qc[i] : (unsigned)kPadCode;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) rows[r][d] = lmat4[code * 8 + d];
+    }
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        vnw pk;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            unsigned x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (4 * w + b < RPL) x |= (((unsigned)rows[4 * w + b][t >> 2] >> (8 * (t & 3))) & 0xFFu) << (8 * b);
+            pk_set(pk, w, (int)x);
+        }
+        *reinterpret_cast<vnw*>(prof + ((t * 64 + lane) * NW) * 4) = pk;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stage target columns [w0 - 64, kend + 8) as bytes (index = column - w0 + 64); pad outside [0, lt)
+typedef const __attribute__((address_space(1))) uint32_t* global_u32_ptr;      // global_load instead of flat_load
+__device__ __forceinline__ void pair_stage_window(char* stage, const uint32_t* res, int len4, unsigned w0, unsigned kend, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    global_u32_ptr gres = (global_u32_ptr)res;
+    const int e_end = (int)((kend - w0 + 64 + 8 + 3) / 4);
+    for (int e = lane; e < e_end; e += 64) {
+        const int c = (int)(w0 / 4) - 16 + e;
+        unsigned v = 0x1F1F1F1Fu;
+        if (c >= 0 && c < len4) v = gres[(uint64_t)c * 64];
+        reinterpret_cast<unsigned*>(stage)[e] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int RPL>
 __global__ __launch_bounds__(64) void sw_pair_scan(const PairArgs a) {
@@ -105,32 +138,9 @@ __global__ __launch_bounds__(64) void sw_pair_scan(const PairArgs a) {
         const uint32_t* res = reinterpret_cast<const uint32_t*>(a.seq_addr[tid]);
         const int len4 = (int)((lt + 3) / 4);
 
-        if (q != have_q) {      // lane profile: prof[(t*64 + lane)*NW + w] byte b = M[q_{lane*RPL + 4w + b}][t]
+        if (q != have_q) {
             have_q = q;
-            const uint8_t* qc = a.q_codes + a.q_off[q];
-            __builtin_amdgcn_wave_barrier();
-            int rows[RPL][8];
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const unsigned i = (unsigned)lane * RPL + r;
-                const unsigned code = i < lq ? qc[i] : (unsigned)kPadCode;
-#pragma unroll
-                for (int d = 0; d < 8; ++d) rows[r][d] = lmat4[code * 8 + d];
-            }
-#pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                vnw out;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    unsigned x = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (4 * w + b < RPL) x |= (((unsigned)rows[4 * w + b][t >> 2] >> (8 * (t & 3))) & 0xFFu) << (8 * b);
-                    out.w[w] = (int)x;
-                }
-                *reinterpret_cast<vnw*>(prof + ((t * 64 + lane) * NW) * 4) = out;
-            }
-            __builtin_amdgcn_wave_barrier();
+            pair_build_profile<RPL, NW>(prof, lmat4, a.q_codes + a.q_off[q], lq, lane);
         }
 
         const unsigned lanes_used = (lq + RPL - 1) / RPL;
@@ -142,15 +152,14 @@ __global__ __launch_bounds__(64) void sw_pair_scan(const PairArgs a) {
         int hu_prev = 0;            // H(row above the block, previous column)
         unsigned f_out = 0;         // F handed to the block below, for this lane's current column
         int best = 0;
-        const unsigned prof_addr = lds_addr(prof) + lane * (NW * 4);
-        const unsigned stage_addr = lds_addr(stage);
+        const char* prof_lane = prof + lane * (NW * 4);
         auto step = [&](const vnw& sc) {
             const int hu = wave_shr1(H[RPL - 1]);       // H(row above the block, this column)
             unsigned F = (unsigned)wave_shr1((int)f_out);
             int d[RPL];
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                const int w = sc.w[r / 4];
+                const int w = pk_get(sc, r / 4);
                 const int s = (int)(signed char)(w >> (8 * (r % 4)));
                 d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
             }
@@ -171,50 +180,231 @@ __global__ __launch_bounds__(64) void sw_pair_scan(const PairArgs a) {
 
         for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
             const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
-            // stage columns [w0 - 64, kend + 8) as bytes; pad outside [0, lt)
-            __builtin_amdgcn_wave_barrier();
-            const int e_end = (int)((kend - w0 + 64 + 8 + 3) / 4);
-            for (int e = lane; e < e_end; e += 64) {
-                const int c = (int)(w0 / 4) - 16 + e;
-                unsigned v = 0x1F1F1F1Fu;
-                if (c >= 0 && c < len4) v = res[(uint64_t)c * 64];
-                reinterpret_cast<unsigned*>(stage)[e] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // Software pipeline, two steps per iteration.  The LDS reads are issued by hand (the compiler otherwise
-            // rotates the loop into load -> wait -> use and exposes two LDS round trips per step): while a step runs
-            // on scA, the scores of the next step (scB) and the residue of the one after (tC) are in flight.
-            unsigned sa = stage_addr + 64 - lane;       // LDS address of column k - lane, k = w0
-            unsigned tB;
-            vnw scA, scB;
-            lds_u8(tB, sa);
-            lds_wait(tB);
-            lds_pack(scA, prof_addr + tB * (64 * NW * 4));
-            lds_u8(tB, sa + 1);
-            lds_wait(tB);
-            lds_wait_pack(scA);
+            pair_stage_window(stage, res, len4, w0, kend, lane);
+            // two steps per iteration; while a step runs on scA, the scores of the next step (scB) and the residue of
+            // the one after (tC) are in flight
+            const unsigned char* sa = reinterpret_cast<const unsigned char*>(stage) + 64 - lane;    // column k - lane, k = w0
+            unsigned tB = sa[0];
+            vnw scA = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+            tB = sa[1];
+            pin(tB);
+            pin(scA);
             for (unsigned k = w0; k < kend; k += 2) {       // an odd tail runs one harmless extra step (pad columns)
-                unsigned tC;
-                lds_pack(scB, prof_addr + tB * (64 * NW * 4));
-                lds_u8(tC, sa + 2);
+                vnw scB = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));     // scores of step k + 1
+                unsigned tC = sa[2];                                                          // residue of step k + 2
                 __builtin_amdgcn_sched_barrier(0);
                 step(scA);
                 __builtin_amdgcn_sched_barrier(0);
-                lds_wait(tC);
-                lds_wait_pack(scB);
-                lds_pack(scA, prof_addr + tC * (64 * NW * 4));
-                lds_u8(tB, sa + 3);
+                pin(tC);
+                pin(scB);
+                scA = *reinterpret_cast<const vnw*>(prof_lane + tC * (64 * NW * 4));         // step k + 2
+                tB = sa[3];                                                                   // step k + 3
                 sa += 2;
                 __builtin_amdgcn_sched_barrier(0);
                 step(scB);
                 __builtin_amdgcn_sched_barrier(0);
-                lds_wait(tB);
-                lds_wait_pack(scA);
+                pin(tB);
+                pin(scA);
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) best = imax(best, __shfl_xor(best, off, 64));
         if (lane == 0) a.scores[out] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Traceback of a pair (step 4 of alignDatabase for the survivors), same sweep: every cell also emits the 4-bit
+// direction code of sw_trace.hip.h (TB_*: source of H, "E opened here", "F opened here"), stored per step as one
+// lane-contiguous line (byte r of lane l at step k = row l*RPL + r, column k - l), and the wave tracks the first cell
+// in row-major order whose H equals the known score.  Lane 0 then walks the codes back (they were just written by this
+// wave: L2 hits) and writes the moves from the END of the pair's path region backwards, so no reversal is needed:
+// the path is the last out[4] bytes of the region.  Tie rules are those of sw_trace_fill / the oracle.
+struct PairTraceItem {
+    uint32_t q, t;          // query id, target id
+    int32_t score;          // known optimal score (from the scan)
+    uint32_t slot;          // index of the pair in out5 / best
+    uint64_t dir_off;       // byte offset of the pair's direction block: (steps rounded up to even) * 64 * NW*4 bytes
+    uint64_t path_end;      // byte offset one past the pair's path region (capacity >= lq + lt)
+};
+
+struct PairTraceArgs {
+    const PairTraceItem* __restrict__ items;
+    const uint64_t* __restrict__ seq_addr;
+    const uint32_t* __restrict__ seq_len;
+    const uint8_t* __restrict__ q_codes;
+    const uint64_t* __restrict__ q_off;
+    const uint32_t* __restrict__ q_len;
+    const int8_t* __restrict__ mat;
+    uint8_t* __restrict__ dirs;
+    uint8_t* __restrict__ paths;
+    int32_t* __restrict__ out5;     // [slot][5]: q_start, q_end, t_start, t_end, path_len   (-1,-1,-1,-1,0 if score <= 0)
+    int32_t* __restrict__ best;     // [slot] recomputed optimal score (cross-check against `score`)
+    unsigned* counter;
+    uint32_t n_pairs;
+    uint32_t open, ext;
+};
+
+template <int RPL>
+__global__ __launch_bounds__(64) void sw_pair_trace(const PairTraceArgs a) {
+    constexpr int NW = RPL <= 4 ? 1 : (RPL <= 8 ? 2 : 4);
+    constexpr int W = kPairWindow;
+    typedef typename PackOf<NW>::type vnw;
+    __shared__ __attribute__((aligned(16))) char lds[1024 + 32 * 64 * NW * 4 + W + 192];
+    const int lane = threadIdx.x;
+    const int* lmat4 = reinterpret_cast<const int*>(lds);
+    char* prof = lds + 1024;
+    char* stage = prof + 32 * 64 * NW * 4;
+    for (int i = lane; i < 256; i += 64) reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __builtin_amdgcn_wave_barrier();
+    const unsigned open = a.open, ext = a.ext;
+    unsigned have_q = 0xFFFFFFFFu;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= a.n_pairs) break;
+        const PairTraceItem it = a.items[item];
+        const unsigned q = it.q;
+        const unsigned lq = a.q_len[q];
+        const unsigned lt = a.seq_len[it.t];
+        const int want = it.score;
+        int32_t* out = a.out5 + (uint64_t)it.slot * 5;
+        if (lq == 0 || lt == 0 || want <= 0) {
+            if (lane == 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; a.best[it.slot] = 0; }
+            continue;
+        }
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(a.seq_addr[it.t]);
+        const int len4 = (int)((lt + 3) / 4);
+        if (q != have_q) {
+            have_q = q;
+            pair_build_profile<RPL, NW>(prof, lmat4, a.q_codes + a.q_off[q], lq, lane);
+        }
+        const unsigned lanes_used = (lq + RPL - 1) / RPL;
+        const unsigned nsteps = lt + lanes_used - 1;
+        int H[RPL];
+        unsigned E[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
+        int hu_prev = 0;
+        unsigned f_out = 0;         // F for the block below | "F opened here" << 31
+        unsigned eopen = 0;         // bit r: E(row r, current column) was opened from H(row r, previous column)
+        int best = 0;
+        unsigned key = 0xFFFFFFFFu;
+        const char* prof_lane = prof + lane * (NW * 4);
+        vnw* dst = reinterpret_cast<vnw*>(a.dirs + it.dir_off) + lane;     // step k writes dst[k * 64]
+        unsigned cell0 = ((unsigned)(lane * RPL) << 16) - (unsigned)lane;  // + k = (row of r = 0) << 16 | column
+        auto step = [&](const vnw& sc) {
+            const int hu = wave_shr1(H[RPL - 1]);
+            const unsigned fin = (unsigned)wave_shr1((int)f_out);
+            unsigned F = fin & 0x7FFFFFFFu;
+            unsigned fopen = fin >> 31;
+            int d[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int w = pk_get(sc, r / 4);
+                const int s = (int)(signed char)(w >> (8 * (r % 4)));
+                d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
+            }
+            int D[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) D[w] = 0;
+            unsigned eopen_next = 0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int h = imax(imax(d[r], (int)E[r]), (int)F);
+                const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (h == (int)F ? 2u : 3u));
+                D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
+                if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
+                best = imax(best, h);
+                const unsigned hm = usub_sat((unsigned)h, open);
+                const unsigned En = umax_s(usub_sat(E[r], ext), hm);
+                const unsigned Fn = umax_s(usub_sat(F, ext), hm);
+                eopen_next |= (En == hm ? 1u : 0u) << r;
+                fopen = (Fn == hm) ? 1u : 0u;
+                E[r] = En;
+                F = Fn;
+                H[r] = h;
+            }
+            eopen = eopen_next;
+            f_out = F | (fopen << 31);
+            hu_prev = hu;
+            vnw Dv;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
+            *dst = Dv;
+            dst += 64;
+            ++cell0;
+        };
+
+        for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
+            const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
+            pair_stage_window(stage, res, len4, w0, kend, lane);
+            const unsigned char* sa = reinterpret_cast<const unsigned char*>(stage) + 64 - lane;    // column k - lane, k = w0
+            unsigned tB = sa[0];
+            vnw scA = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+            tB = sa[1];
+            pin(tB);
+            pin(scA);
+            for (unsigned k = w0; k < kend; k += 2) {       // an odd tail runs one harmless extra step (pad columns)
+                vnw scB = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));     // scores of step k + 1
+                unsigned tC = sa[2];                                                          // residue of step k + 2
+                __builtin_amdgcn_sched_barrier(0);
+                step(scA);
+                __builtin_amdgcn_sched_barrier(0);
+                pin(tC);
+                pin(scB);
+                scA = *reinterpret_cast<const vnw*>(prof_lane + tC * (64 * NW * 4));         // step k + 2
+                tB = sa[3];                                                                   // step k + 3
+                sa += 2;
+                __builtin_amdgcn_sched_barrier(0);
+                step(scB);
+                __builtin_amdgcn_sched_barrier(0);
+                pin(tB);
+                pin(scA);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            best = imax(best, __shfl_xor(best, off, 64));
+            const unsigned other = (unsigned)__shfl_xor((int)key, off, 64);
+            key = other < key ? other : key;
+        }
+        // the codes were written by all lanes of this wave; make them visible to lane 0's loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) {
+            a.best[it.slot] = best;
+            if (key == 0xFFFFFFFFu) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; }
+            else {
+                const uint8_t* dirs = a.dirs + it.dir_off;
+                uint8_t* pe = a.paths + it.path_end;
+                int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
+                const int ei = i, ej = j;
+                unsigned n = 0, state = 0;
+                const unsigned cap = lq + lt;
+                while (i >= 0 && j >= 0 && n < cap) {
+                    const unsigned l = (unsigned)i / RPL, r = (unsigned)i % RPL;
+                    const unsigned b = dirs[((uint64_t)((unsigned)j + l) * 64 + l) * (NW * 4) + r];
+                    if (state == 0) {
+                        const unsigned src = b & 3u;
+                        if (src == 0u) break;
+                        if (src == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }      // MOVE_DIAG
+                        else state = (src == 2u) ? 2u : 1u;
+                    } else if (state == 1) {
+                        *(pe - 1 - n) = 2; ++n;                                      // MOVE_LEFT
+                        if (b & 4u) state = 0;
+                        --j;
+                    } else {
+                        *(pe - 1 - n) = 3; ++n;                                      // MOVE_UP
+                        if (b & 8u) state = 0;
+                        --i;
+                    }
+                }
+                out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n;
+            }
+        }
     }
 }
 

@@ -386,29 +386,39 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
     };
     auto select_task = [](void* p) -> void* {
         SelectJob* jb = (SelectJob*)p;
-        if (jb->subset->empty()) {
-            select_survivors(jb->keep, jb->query, jb->targets, jb->n, jb->row, jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
-        } else {
-            std::vector<int> picked(jb->subset->size());
-            for (size_t k = 0; k < picked.size(); ++k) picked[k] = jb->row[(*jb->subset)[k]];
-            select_survivors(jb->keep, jb->query, jb->targets, jb->n, picked.data(), jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
-        }
+        select_survivors(jb->keep, jb->query, jb->targets, jb->n, jb->row, jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
         return NULL;
     };
 
+    // with a subset the library scores just those (query, target) pairs (one wave per pair, or a scan + column pick when
+    // the subset approaches the whole database: s4g_score_pairs_host decides); rows are then `subset`-indexed
+    std::vector<uint32_t> sub_q, sub_t;
+    if (!subset.empty()) {
+        sub_t.resize((size_t)batch * subset.size());
+        sub_q.resize(sub_t.size());
+        for (uint32_t i = 0; i < batch; ++i)
+            for (size_t k = 0; k < subset.size(); ++k) sub_t[(size_t)i * subset.size() + k] = (uint32_t)subset[k];
+    }
+    const size_t row_len = subset.empty() ? (size_t)cdb->length : subset.size();
     for (uint32_t b = 0; b < (uint32_t)queriesLen; b += batch) {
         const uint32_t cnt = std::min<uint32_t>(batch, (uint32_t)queriesLen - b);
         {
             Phase ph(2);
-            if (s4g_scan_host(ddb, dq, b, cnt, scorer->dev, scores.data()) != S4G_OK)
-                SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", device, s4g_last_error());
+            int rc;
+            if (subset.empty()) rc = s4g_scan_host(ddb, dq, b, cnt, scorer->dev, scores.data());
+            else {
+                for (uint32_t i = 0; i < cnt; ++i)
+                    for (size_t k = 0; k < subset.size(); ++k) sub_q[(size_t)i * subset.size() + k] = b + i;
+                rc = s4g_score_pairs_host(ddb, dq, scorer->dev, (uint64_t)cnt * subset.size(), sub_q.data(), sub_t.data(), scores.data(), 0);
+            }
+            if (rc != S4G_OK) SW_FATAL("Smith-Waterman scan failed on MI355X device %d: %s", device, s4g_last_error());
         }
         Phase* ph_sel = new Phase(3);
         // steps 2-3 on the host, one pool task per query (the value callback is the caller's double-precision code)
         std::vector<SelectJob> sel(cnt);
         std::vector<ThreadPoolTask*> tasks(cnt);
         for (uint32_t i = 0; i < cnt; ++i) {
-            sel[i] = {queries[b + i], targets, n_targets, scores.data() + (size_t)i * cdb->length, &subset, maxAlignments,
+            sel[i] = {queries[b + i], targets, n_targets, scores.data() + (size_t)i * row_len, &subset, maxAlignments,
                       valueFunction, valueFunctionParam, valueThreshold, {}};
             tasks[i] = threadPoolSubmit(select_task, &sel[i]);
         }

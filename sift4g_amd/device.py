@@ -242,9 +242,10 @@ def topk(db, scores, k, min_score=1, stream=None):
     return ids, sc, cnt
 
 
-def traceback(db, queries, scorer, pair_q, pair_t, pair_score):
+def traceback(db, queries, scorer, pair_q, pair_t, pair_score, route=None):
     """Device traceback of (query, target) pairs with known scores -> list of dicts(score, q_start, q_end, t_start, t_end, path)
-    (path: uint8 array of swsharp move codes 1 DIAG / 2 LEFT / 3 UP, start to end)."""
+    (path: uint8 array of swsharp move codes 1 DIAG / 2 LEFT / 3 UP, start to end).
+    route = None (one wave per pair for queries up to 1024 residues, strip kernels beyond) | "wave" | "scan" (strip kernels)."""
     pair_q = np.ascontiguousarray(pair_q, dtype=np.uint32)
     pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
     pair_score = np.ascontiguousarray(pair_score, dtype=np.int32)
@@ -256,8 +257,8 @@ def traceback(db, queries, scorer, pair_q, pair_t, pair_score):
     off[1:] = np.cumsum(cap)
     out = np.zeros((max(n, 1), 5), dtype=np.int32)
     paths = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
-    check(lib.s4g_traceback_host(db._h, queries._h, scorer._h, n, _ptr(pair_q, c_u32p), _ptr(pair_t, c_u32p),
-                                 _ptr(pair_score, c_i32p), _ptr(out, c_i32p), _ptr(off, c_u64p), _ptr(paths, c_u8p)),
-          "s4g_traceback_host")
+    check(lib.s4g_traceback_host_flags(db._h, queries._h, scorer._h, n, _ptr(pair_q, c_u32p), _ptr(pair_t, c_u32p),
+                                       _ptr(pair_score, c_i32p), _ptr(out, c_i32p), _ptr(off, c_u64p), _ptr(paths, c_u8p),
+                                       {None: 0, "wave": 1, "scan": 2}[route]), "s4g_traceback_host")
     return [dict(score=int(pair_score[i]), q_start=int(out[i, 0]), q_end=int(out[i, 1]), t_start=int(out[i, 2]),
                  t_end=int(out[i, 3]), path=paths[int(off[i]):int(off[i]) + int(out[i, 4])].copy()) for i in range(n)]

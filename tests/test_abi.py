@@ -79,3 +79,4 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"\bimport oracle\b|\bfrom oracle\b|sw_oracle|libsw_oracle|s4g_oracle_", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+

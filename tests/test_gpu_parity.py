@@ -386,18 +386,21 @@ def test_device_traceback_equals_oracle(s4g, oracle_mod, blosum62, scorer):
         pq, pt = pq.ravel(), pt.ravel()
         perm = rng.permutation(len(pq))                    # arbitrary pair order, > 64 survivors per query -> several items
         pq, pt = pq[perm], pt[perm]
-        res = s4g.traceback(db, q, scorer, pq, pt, scores[pq, pt])
-        n_pos = 0
-        for a, b, r in zip(pq, pt, res):
-            o = oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1)
-            assert o["score"] == r["score"]
-            if o["score"] == 0:
-                assert len(r["path"]) == 0 and r["q_start"] == -1
-                continue
-            n_pos += 1
-            assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"]), (a, b)
-            assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (a, b)
-        assert n_pos > 1000
+        want = [oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1) for a, b in zip(pq, pt)]
+        # both device routes: one wave per pair (sw_pair_trace, the default for these query lengths) and the
+        # 64-pairs-per-wave strip kernels (sw_trace_fill + sw_trace_walk)
+        for route in (None, "wave", "scan"):
+            res = s4g.traceback(db, q, scorer, pq, pt, scores[pq, pt], route=route)
+            n_pos = 0
+            for a, b, r, o in zip(pq, pt, res, want):
+                assert o["score"] == r["score"]
+                if o["score"] == 0:
+                    assert len(r["path"]) == 0 and r["q_start"] == -1
+                    continue
+                n_pos += 1
+                assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"]), (route, a, b)
+                assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (route, a, b)
+            assert n_pos > 1000
     with pytest.raises(Exception):                         # a wrong score is detected, not silently traced
         s4g.traceback(db, q, scorer, [0], [0], [int(scores[0, 0]) + 1])
 
@@ -596,3 +599,51 @@ def test_pairs_empty_sequences_and_other_scorers(s4g, oracle_mod, blosum62, scor
     _pairs_check(s4g, oracle_mod, M, qs, ts, pq.ravel(), pt.ravel(), s4g.Scorer(M, 7, 2), 7, 2)
     with pytest.raises(RuntimeError):
         s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [3], [0])
+
+
+def test_pair_traceback_row_block_classes_windows_and_mixed_routes(s4g, oracle_mod, blosum62, scorer):
+    """sw_pair_trace over every rows-per-lane class, targets beyond one 4096-column window, gap-rich alignments; queries
+    beyond 1024 residues in the same call fall to the strip kernels."""
+    rng = np.random.default_rng(35)
+    qlens = [1, 2, 64, 65, 128, 129, 200, 256, 257, 384, 385, 512, 513, 700, 768, 769, 1024, 1025, 1500]
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
+    ts = []
+    for k, src in enumerate(qs):                              # two gapped homologs per query + noise
+        if len(src) > 20:
+            cut = len(src) // 2
+            ts.append(np.concatenate([rand_seqs(rng, 1, 30, 30)[0], src[:cut], rand_seqs(rng, 1, 7, 7)[0], src[cut:]]))
+            ts.append(np.concatenate([src[:cut], src[cut + 5:], rand_seqs(rng, 1, 11, 11)[0]]))
+        else:
+            ts.append(src.copy())
+    ts += rand_seqs(rng, 10, 1, 500)
+    long_t = rand_seqs(rng, 1, 9000, 9000)[0]
+    long_t[4000:4700] = qs[13]                                 # hit straddling the first window boundary (4096)
+    long_t[8100:8484] = qs[9]
+    ts.append(long_t)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    scores = s4g.scan_host(db, q, scorer)
+    pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    pq, pt = pq.ravel(), pt.ravel()
+    MOVE = {0: 1, 1: 2, 2: 3}
+    res = s4g.traceback(db, q, scorer, pq, pt, scores[pq, pt])
+    n_pos = 0
+    for a, b, r in zip(pq, pt, res):
+        o = oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1)
+        assert o["score"] == r["score"], (a, b)
+        if o["score"] == 0:
+            assert len(r["path"]) == 0 and r["q_start"] == -1
+            continue
+        n_pos += 1
+        assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"]), (a, b)
+        assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (a, b)
+    assert n_pos > 500
+    with pytest.raises(RuntimeError):
+        s4g.traceback(db, q, scorer, [len(qs) - 1], [0], [int(scores[-1, 0])], route="wave")
+    for go, ge in ((1, 1), (0, 0), (5, 5)):                  # cheap gaps: long gap runs and many ties
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        sub = rng.choice(len(pq), size=150, replace=False)
+        got_scores = s4g.score_pairs(db, q, sc, pq[sub], pt[sub])
+        for a, b, r in zip(pq[sub], pt[sub], s4g.traceback(db, q, sc, pq[sub], pt[sub], got_scores)):
+            o = oracle_mod.sw_align(qs[a], ts[b], blosum62, go, ge)
+            assert o["score"] == r["score"], (go, ge, a, b)
+            assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (go, ge, a, b)
