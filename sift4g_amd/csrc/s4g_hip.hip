@@ -22,6 +22,19 @@
 #include <thread>
 #include <vector>
 
+// S4G_PROFILE=1: cumulative host time of the database-creation phases, printed at exit (diagnostic only)
+namespace {
+struct CreateClock {
+    double t[4] = {0, 0, 0, 0};
+    long n = 0;
+    bool on = getenv("S4G_PROFILE") != nullptr;
+    ~CreateClock() {
+        if (on && n) fprintf(stderr, "[s4g profile] s4g_db_create x%ld: lengths+sort %.3f s, pack %.3f s, upload %.3f s\n", n, t[0], t[1], t[2]);
+    }
+} g_create_clock;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 using namespace s4g;
 
 #define S4G_API extern "C" __attribute__((visibility("default")))
@@ -86,6 +99,8 @@ struct Tile {
     uint32_t* d_perm_local = nullptr;   // [G*64] column in the tile's own score buffer = rank of the id inside the tile
     uint32_t* d_col_ids = nullptr;      // [n_seqs] tile column -> original target id (ascending)
     std::vector<uint64_t> h_grp_off;    // host copy (traceback addresses lanes of arbitrary targets)
+    char* d_block = nullptr;            // small tiles: every array above lives in this one allocation (recycled through
+    uint64_t block_bytes = 0;           // DeviceCtx::block_cache: sift4g creates a candidate database per query)
     uint64_t pos0 = 0;                  // position of the tile's first sequence in the global length-sorted order
 };
 
@@ -101,6 +116,7 @@ struct s4g_db {
     mutable uint64_t* d_seq_addr = nullptr;     // [n_seqs] device address of the sequence's first residue dword
     mutable uint32_t* d_seq_len = nullptr;      // [n_seqs]
     mutable std::vector<uint32_t> id_of_pos;    // position in the length-sorted order -> original index
+    bool seq_tables_in_block = false;           // d_seq_addr / d_seq_len are part of tiles[0].d_block
 };
 
 // Per-device scratch shared by every database on that device: strip-boundary workspace, work-queue counters, query
@@ -136,6 +152,7 @@ struct DeviceCtx {
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     int32_t* d_ws_side = nullptr;
     uint64_t ws_side_bytes = 0;
+    std::vector<std::pair<char*, uint64_t>> block_cache;    // freed small-tile blocks, reused by the next s4g_db_create
     char* arena = nullptr;              // traceback temporaries
     uint64_t arena_bytes = 0;
 };
@@ -230,9 +247,18 @@ constexpr uint64_t kTileMaxResidues = 1ull << 30;      // padded residues per ti
 constexpr uint32_t kLongSeq = 12288;                   // sequences longer than this get tiles of their own: beyond ~16k residues
                                                        // the per-wave strip-boundary workspace no longer fits the budget at full grid
 
-void free_tile(Tile& t) {
-    (void)hipFree(t.d_res); (void)hipFree(t.d_grp_off); (void)hipFree(t.d_grp_len4);
-    (void)hipFree(t.d_perm_global); (void)hipFree(t.d_perm_local); (void)hipFree(t.d_col_ids);
+constexpr uint64_t kBlockMax = 64ull << 20;      // tiles up to this size are one allocation
+constexpr size_t kBlockCacheEntries = 8;
+
+void free_tile(Tile& t, DeviceCtx* cx) {
+    if (t.d_block) {
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (cx->block_cache.size() < kBlockCacheEntries) cx->block_cache.emplace_back(t.d_block, t.block_bytes);
+        else (void)hipFree(t.d_block);
+    } else {
+        (void)hipFree(t.d_res); (void)hipFree(t.d_grp_off); (void)hipFree(t.d_grp_len4);
+        (void)hipFree(t.d_perm_global); (void)hipFree(t.d_perm_local); (void)hipFree(t.d_col_ids);
+    }
     t = Tile();
 }
 
@@ -250,7 +276,8 @@ struct DevBuf {          // scoped device allocation for the non-hot paths
 
 // Packs order[p0, p1) (length-sorted, longest first) into one tile and uploads it.
 hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, size_t p0, size_t p1,
-                      const uint8_t* codes, const uint64_t* offsets, std::string* err) {
+                      const uint8_t* codes, const uint64_t* offsets, std::string* err, uint64_t extra_bytes = 0,
+                      uint64_t* extra_off = nullptr) {
     const uint32_t n = (uint32_t)(p1 - p0);
     const uint32_t G = (n + 63) / 64;
     t.n_seqs = n; t.n_groups = G;
@@ -267,28 +294,44 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
     t.padded_residues = dwords * 4;
     // tile column of a sequence = rank of its original id inside the tile (ties in top-k break by id)
     std::vector<uint32_t> col_ids(order.begin() + p0, order.begin() + p1);
-    std::sort(col_ids.begin(), col_ids.end());
+    const bool whole = (n == db->n_seqs);           // single tile: the ids are 0..n-1 and the rank of an id is the id
+    if (whole) std::iota(col_ids.begin(), col_ids.end(), 0u);
+    else std::sort(col_ids.begin(), col_ids.end());
     std::vector<uint32_t> perm_g((size_t)G * 64, 0xFFFFFFFFu), perm_l((size_t)G * 64, 0xFFFFFFFFu);
     std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
     std::atomic<bool> bad{false};
     auto pack = [&](uint32_t g0, uint32_t g1) {
         for (uint32_t g = g0; g < g1; ++g) {
-            uint8_t* base = reinterpret_cast<uint8_t*>(res.data() + grp_off[g]);
+            uint32_t* base = res.data() + grp_off[g];
             const uint32_t lanes = std::min<uint32_t>(64, n - g * 64);
             for (uint32_t lane = 0; lane < lanes; ++lane) {
                 const uint32_t id = order[p0 + (size_t)g * 64 + lane];
                 perm_g[(size_t)g * 64 + lane] = id;
-                perm_l[(size_t)g * 64 + lane] = (uint32_t)(std::lower_bound(col_ids.begin(), col_ids.end(), id) - col_ids.begin());
+                perm_l[(size_t)g * 64 + lane] = whole ? id : (uint32_t)(std::lower_bound(col_ids.begin(), col_ids.end(), id) - col_ids.begin());
                 const uint8_t* src = codes + offsets[id];
                 const uint32_t l = db->len[id];
-                for (uint32_t j = 0; j < l; ++j) {
-                    const uint8_t c = src[j];
-                    if (c >= 26) { bad = true; return; }
-                    base[((size_t)(j >> 2) * 64 + lane) * 4 + (j & 3)] = c;
+                // four residues per dword; a byte >= 26 anywhere is an error (SWAR test: bit 7 of b | ((b & 0x7F) + 102))
+                uint32_t c4 = 0, any_bad = 0;
+                for (; c4 + 1 <= l / 4; ++c4) {
+                    uint32_t w;
+                    memcpy(&w, src + 4 * (size_t)c4, 4);
+                    any_bad |= (w | ((w & 0x7F7F7F7Fu) + 0x66666666u)) & 0x80808080u;
+                    base[(size_t)c4 * 64 + lane] = w;
                 }
+                if (l & 3) {
+                    uint32_t w = 0x1F1F1F1Fu;
+                    for (uint32_t j = 4 * c4; j < l; ++j) {
+                        const uint32_t c = src[j];
+                        if (c >= 26) any_bad = 1;
+                        w = (w & ~(0xFFu << (8 * (j & 3)))) | (c << (8 * (j & 3)));
+                    }
+                    base[(size_t)c4 * 64 + lane] = w;
+                }
+                if (any_bad) { bad = true; return; }
             }
         }
     };
+    const double t_pack = now_s();
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const unsigned nthreads = dwords > (1u << 22) ? hw : 1;
     if (nthreads == 1) pack(0, G);
@@ -299,6 +342,9 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
     }
     if (bad) { *err = "residue code out of range (codes must be letter - 'A', 0..25)"; return hipErrorInvalidValue; }
     for (size_t p = p0; p < p1; ++p) t.residues += db->len[order[p]];
+    const double t_up = now_s();
+    g_create_clock.t[1] += t_up - t_pack;
+    struct UpTimer { double t0; ~UpTimer() { g_create_clock.t[2] += now_s() - t0; } } up_timer{t_up};
     auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
         if (e != hipSuccess) return e;
@@ -306,6 +352,45 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
         return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     hipError_t e;
+    {   // small tile: one allocation (taken from the per-device cache when one fits) instead of six
+        uint64_t need = 0;
+        auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
+        const uint64_t o_res = reserve(dwords * 4), o_off = reserve((uint64_t)G * 8), o_len4 = reserve((uint64_t)G * 4);
+        const uint64_t o_pg = reserve((uint64_t)G * 256), o_pl = reserve((uint64_t)G * 256), o_col = reserve((uint64_t)n * 4);
+        const uint64_t o_extra = reserve(extra_bytes);
+        if (need <= kBlockMax) {
+            DeviceCtx* cx = device_ctx(db->device);
+            char* blk = nullptr;
+            uint64_t blk_bytes = 0;
+            {
+                std::lock_guard<std::mutex> lk(cx->mu);
+                for (size_t k = 0; k < cx->block_cache.size(); ++k)
+                    if (cx->block_cache[k].second >= need && cx->block_cache[k].second <= 4 * need + (1u << 20)) {
+                        blk = cx->block_cache[k].first; blk_bytes = cx->block_cache[k].second;
+                        cx->block_cache.erase(cx->block_cache.begin() + k);
+                        break;
+                    }
+            }
+            if (!blk) {
+                blk_bytes = need + need / 4;          // a little slack so the next, slightly larger database still fits
+                if ((e = hipMalloc((void**)&blk, blk_bytes)) != hipSuccess) return e;
+            }
+            t.d_block = blk; t.block_bytes = blk_bytes;
+            db->hbm_bytes += blk_bytes;
+            t.d_res = reinterpret_cast<uint32_t*>(blk + o_res); t.d_grp_off = reinterpret_cast<uint64_t*>(blk + o_off);
+            t.d_grp_len4 = reinterpret_cast<uint32_t*>(blk + o_len4); t.d_perm_global = reinterpret_cast<uint32_t*>(blk + o_pg);
+            t.d_perm_local = reinterpret_cast<uint32_t*>(blk + o_pl); t.d_col_ids = reinterpret_cast<uint32_t*>(blk + o_col);
+            if (extra_off) *extra_off = o_extra;
+            auto cp = [&](void* d, const void* h, size_t bytes) { return bytes ? hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+            if ((e = cp(t.d_res, res.data(), dwords * 4)) != hipSuccess || (e = cp(t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess ||
+                (e = cp(t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess || (e = cp(t.d_perm_global, perm_g.data(), (size_t)G * 256)) != hipSuccess ||
+                (e = cp(t.d_perm_local, perm_l.data(), (size_t)G * 256)) != hipSuccess || (e = cp(t.d_col_ids, col_ids.data(), (size_t)n * 4)) != hipSuccess)
+                return e;
+            t.h_grp_off.swap(grp_off);
+            t.pos0 = p0;
+            return hipSuccess;
+        }
+    }
     if ((e = up((void**)&t.d_res, res.data(), dwords * 4)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess) return e;
@@ -333,6 +418,7 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
     db->device = device;
     db->n_seqs = n_seqs;
     db->len.resize(n_seqs);
+    const double t_begin = now_s();
     for (uint32_t i = 0; i < n_seqs; ++i) {
         uint64_t l = offsets[i + 1] - offsets[i];
         if (offsets[i + 1] < offsets[i] || l > 0x7FFFFFF0ull) { delete db; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
@@ -346,6 +432,7 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
 
     db->pos_of_id.resize(n_seqs);
     for (uint32_t pp = 0; pp < n_seqs; ++pp) db->pos_of_id[order[pp]] = pp;
+    g_create_clock.t[0] += now_s() - t_begin; g_create_clock.n++;
     // cut the sorted order into tiles: by count, by padded residues, and at the long-sequence threshold
     size_t p = 0;
     while (p < n_seqs) {
@@ -364,7 +451,22 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
         }
         db->tiles.emplace_back();
         std::string err;
-        hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err);
+        // a database that is one small tile also carries the per-sequence tables of the pair kernels in its block
+        const bool whole = (p == 0 && q == n_seqs);
+        uint64_t tab_off = 0;
+        hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off);
+        if (e == hipSuccess && whole && db->tiles.back().d_block && n_seqs) {
+            const Tile& t0 = db->tiles.back();
+            std::vector<uint64_t> addr(n_seqs);
+            for (uint32_t pos = 0; pos < n_seqs; ++pos)
+                addr[order[pos]] = (uint64_t)(uintptr_t)(t0.d_res + t0.h_grp_off[pos >> 6] + (pos & 63));
+            db->d_seq_addr = reinterpret_cast<uint64_t*>(t0.d_block + tab_off);
+            db->d_seq_len = reinterpret_cast<uint32_t*>(t0.d_block + tab_off + (((uint64_t)n_seqs * 8 + 255) / 256 * 256));
+            db->seq_tables_in_block = true;
+            db->id_of_pos = order;
+            if ((e = hipMemcpy(db->d_seq_addr, addr.data(), (size_t)n_seqs * 8, hipMemcpyHostToDevice)) == hipSuccess)
+                e = hipMemcpy(db->d_seq_len, db->len.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             std::string msg = err.empty() ? std::string(hipGetErrorString(e)) : err;
             s4g_db_destroy(db);
@@ -392,8 +494,8 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
         std::lock_guard<std::mutex> lk(cx->mu);
         if (cx->last_use) (void)hipEventSynchronize(cx->last_use);
     }
-    for (Tile& t : db->tiles) free_tile(t);
-    (void)hipFree(db->d_seq_addr); (void)hipFree(db->d_seq_len);
+    for (Tile& t : db->tiles) free_tile(t, device_ctx(db->device));
+    if (!db->seq_tables_in_block) { (void)hipFree(db->d_seq_addr); (void)hipFree(db->d_seq_len); }
     delete db;
     return S4G_OK;
 }
