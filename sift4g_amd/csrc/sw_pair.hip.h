@@ -18,7 +18,7 @@
 
 namespace s4g {
 
-constexpr int kPairWindow = 4096;      // target columns staged per window
+constexpr int kPairWindow = 2048;      // target columns staged per window
 constexpr int kPairMaxRows = 64 * 16;  // longest query this path takes
 
 struct PairItem { uint32_t q, t, out; };   // query id, target id (original index), index into scores

@@ -569,11 +569,11 @@ def test_pairs_random_lists_all_codes(s4g, oracle_mod, blosum62, scorer):
 
 
 def test_pairs_target_windows_and_long_queries(s4g, oracle_mod, blosum62, scorer):
-    """targets longer than the 4096-column LDS window (several windows, odd step counts); queries beyond 1024 residues
-    take the scan route inside the same call."""
+    """targets longer than the LDS window of the pair kernels (kPairWindow columns: several windows, lengths on both sides
+    of the boundaries, odd step counts); queries beyond 1024 residues take the scan route inside the same call."""
     rng = np.random.default_rng(33)
     qs = [rand_seqs(rng, 1, l, l)[0] for l in (97, 350, 640, 1024, 1025, 2300)]
-    ts = [rand_seqs(rng, 1, l, l)[0] for l in (4095, 4096, 4097, 8191, 8200, 12289, 13001, 40, 1)]
+    ts = [rand_seqs(rng, 1, l, l)[0] for l in (4095, 4096, 4097, 8191, 8200, 12289, 13001, 40, 1, 1985, 2047, 2048, 2049, 2112)]
     ts[4][100:450] = qs[1]                                   # a real hit deep inside the second window
     ts[6][8100:8740] = qs[2]
     pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
@@ -647,3 +647,43 @@ def test_pair_traceback_row_block_classes_windows_and_mixed_routes(s4g, oracle_m
             o = oracle_mod.sw_align(qs[a], ts[b], blosum62, go, ge)
             assert o["score"] == r["score"], (go, ge, a, b)
             assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (go, ge, a, b)
+
+
+def test_pair_kernels_fuzz(s4g, oracle_mod, blosum62):
+    """random pair lists over the whole (query length <= 1024) x (target length <= 6000) rectangle and three scorers:
+    scores of sw_pair_scan and alignments of sw_pair_trace against the oracle."""
+    rng = np.random.default_rng(36)
+    MOVE = {0: 1, 1: 2, 2: 3}
+    for go, ge in ((10, 1), (3, 3), (25, 2)):
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        qlens = rng.integers(1, 1025, size=40)
+        tlens = np.concatenate([rng.integers(1, 700, size=300), rng.integers(700, 6001, size=40)])
+        qs = [rand_seqs(rng, 1, int(l), int(l), 26)[0] for l in qlens]
+        ts = [rand_seqs(rng, 1, int(l), int(l), 26)[0] for l in tlens]
+        for k in range(0, len(ts), 5):                       # related pairs: a window of some query, mutated, inside noise
+            src = qs[k % len(qs)]
+            a = int(rng.integers(0, max(1, len(src) // 2)))
+            piece = src[a:a + max(1, len(ts[k]) // 2)].copy()
+            if len(piece) > 8:
+                piece[rng.integers(0, len(piece), size=len(piece) // 8)] = rng.integers(0, 20, size=len(piece) // 8)
+            at = int(rng.integers(0, max(1, len(ts[k]) - len(piece) + 1)))
+            ts[k][at:at + len(piece)] = piece[:len(ts[k]) - at]
+        db, q = s4g.Database(ts, tile_seqs=int(rng.choice([0, 64]))), s4g.QuerySet(qs)
+        n = 3000
+        pq = rng.integers(0, len(qs), size=n)
+        pt = rng.integers(0, len(ts), size=n)
+        pq[:len(ts)] = np.arange(len(ts)) % len(qs); pt[:len(ts)] = np.arange(len(ts))      # every target at least once
+        qc, qo = oracle_mod._flat(qs)
+        tc, to = oracle_mod._flat(ts)
+        want = oracle_mod.pairs_flat(qc, qo, tc, to, pq, pt, blosum62, go, ge, threads=8)
+        got = s4g.score_pairs(db, q, sc, pq, pt, route="wave")
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, (go, ge, bad[:5].tolist(), got[bad[:5]].tolist(), want[bad[:5]].tolist())
+        sub = np.concatenate([np.arange(len(ts))[::3], rng.choice(n, size=200, replace=False)])
+        res = s4g.traceback(db, q, sc, pq[sub], pt[sub], want[sub], route="wave")
+        for a, b, r in zip(pq[sub], pt[sub], res):
+            o = oracle_mod.sw_align(qs[a], ts[b], blosum62, go, ge)
+            assert o["score"] == r["score"]
+            assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (go, ge, int(a), int(b))
+            if o["score"]:
+                assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
