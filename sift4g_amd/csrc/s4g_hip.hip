@@ -8,6 +8,7 @@
 #include "sw_kernels.hip.h"
 #include "sw_trace.hip.h"
 #include "sw_pair.hip.h"
+#include "sw_pack.hip.h"
 #include "matrices.h"
 
 #include <algorithm>
@@ -29,7 +30,7 @@ struct CreateClock {
     long n = 0;
     bool on = getenv("S4G_PROFILE") != nullptr;
     ~CreateClock() {
-        if (on && n) fprintf(stderr, "[s4g profile] s4g_db_create x%ld: lengths+sort %.3f s, pack %.3f s, upload %.3f s\n", n, t[0], t[1], t[2]);
+        if (on && n) fprintf(stderr, "[s4g profile] s4g_db_create x%ld: lengths+sort %.3f s, host pack %.3f s, tile upload (+ device pack) %.3f s, raw codes upload %.3f s\n", n, t[0], t[1], t[2], t[3]);
     }
 } g_create_clock;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -275,9 +276,11 @@ struct DevBuf {          // scoped device allocation for the non-hot paths
 };
 
 // Packs order[p0, p1) (length-sorted, longest first) into one tile and uploads it.
+// d_raw != nullptr: the raw codes are already on the device and the transposition runs there (sw_pack_tile); d_bad
+// collects its validity flag (checked by the caller after the last tile).
 hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, size_t p0, size_t p1,
                       const uint8_t* codes, const uint64_t* offsets, std::string* err, uint64_t extra_bytes = 0,
-                      uint64_t* extra_off = nullptr) {
+                      uint64_t* extra_off = nullptr, const uint8_t* d_raw = nullptr, int* d_bad = nullptr) {
     const uint32_t n = (uint32_t)(p1 - p0);
     const uint32_t G = (n + 63) / 64;
     t.n_seqs = n; t.n_groups = G;
@@ -298,6 +301,48 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
     if (whole) std::iota(col_ids.begin(), col_ids.end(), 0u);
     else std::sort(col_ids.begin(), col_ids.end());
     std::vector<uint32_t> perm_g((size_t)G * 64, 0xFFFFFFFFu), perm_l((size_t)G * 64, 0xFFFFFFFFu);
+    if (d_raw) {
+        const double t_pack0 = now_s();
+        std::vector<uint64_t> src_off((size_t)G * 64, 0);
+        std::vector<uint32_t> src_len((size_t)G * 64, 0);
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t id = order[p0 + k];
+            perm_g[k] = id;
+            perm_l[k] = whole ? id : (uint32_t)(std::lower_bound(col_ids.begin(), col_ids.end(), id) - col_ids.begin());
+            src_off[k] = offsets[id];
+            src_len[k] = db->len[id];
+            t.residues += db->len[id];
+        }
+        const double t_up0 = now_s();
+        g_create_clock.t[1] += t_up0 - t_pack0;
+        struct UpTimer { double t0; ~UpTimer() { g_create_clock.t[2] += now_s() - t0; } } up_timer{t_up0};
+        hipError_t e;
+        auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+            hipError_t e2 = hipMalloc(d, bytes ? bytes : 4);
+            if (e2 != hipSuccess) return e2;
+            db->hbm_bytes += bytes;
+            return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+        };
+        if ((e = hipMalloc((void**)&t.d_res, dwords ? dwords * 4 : 4)) != hipSuccess) return e;
+        db->hbm_bytes += dwords * 4;
+        if ((e = up((void**)&t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess) return e;
+        if ((e = up((void**)&t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess) return e;
+        if ((e = up((void**)&t.d_perm_global, perm_g.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
+        if ((e = up((void**)&t.d_perm_local, perm_l.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
+        if ((e = up((void**)&t.d_col_ids, col_ids.data(), (size_t)n * 4)) != hipSuccess) return e;
+        DevBuf<uint64_t> d_src_off;
+        DevBuf<uint32_t> d_src_len;
+        if ((e = d_src_off.upload(src_off)) != hipSuccess || (e = d_src_len.upload(src_len)) != hipSuccess) return e;
+        PackArgs a;
+        a.raw = d_raw; a.src_off = d_src_off.p; a.src_len = d_src_len.p; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4;
+        a.res = t.d_res; a.bad = d_bad;
+        if (G) hipLaunchKernelGGL(sw_pack_tile, dim3(G), dim3(256), 0, nullptr, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return e;      // d_src_* go out of scope
+        t.h_grp_off.swap(grp_off);
+        t.pos0 = p0;
+        return hipSuccess;
+    }
     std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
     std::atomic<bool> bad{false};
     auto pack = [&](uint32_t g0, uint32_t g1) {
@@ -433,6 +478,21 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
     db->pos_of_id.resize(n_seqs);
     for (uint32_t pp = 0; pp < n_seqs; ++pp) db->pos_of_id[order[pp]] = pp;
     g_create_clock.t[0] += now_s() - t_begin; g_create_clock.n++;
+    // Databases from 8 MB to 16 GB of residues are transposed on the device: one upload of the raw codes, then one
+    // sw_pack_tile launch per tile.  Smaller ones are packed by the host (a launch and two allocations would cost more
+    // than they save); larger ones tile by tile on the host, so that the raw copy never doubles the footprint.
+    const uint64_t total_res = n_seqs ? offsets[n_seqs] : 0;
+    DevBuf<uint8_t> d_raw;
+    DevBuf<int> d_bad;
+    if (total_res >= (8ull << 20) && total_res <= (16ull << 30)) {
+        const double t_raw = now_s();
+        hipError_t e1 = d_raw.alloc(total_res);
+        if (e1 == hipSuccess) e1 = hipMemcpy(d_raw.p, codes, total_res, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess) e1 = d_bad.alloc(1);
+        if (e1 == hipSuccess) e1 = hipMemset(d_bad.p, 0, 4);
+        if (e1 != hipSuccess) { s4g_db_destroy(db); return fail(S4G_ERR_HIP, "database upload failed: %s", hipGetErrorString(e1)); }
+        g_create_clock.t[3] += now_s() - t_raw;
+    }
     // cut the sorted order into tiles: by count, by padded residues, and at the long-sequence threshold
     size_t p = 0;
     while (p < n_seqs) {
@@ -454,7 +514,8 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
         // a database that is one small tile also carries the per-sequence tables of the pair kernels in its block
         const bool whole = (p == 0 && q == n_seqs);
         uint64_t tab_off = 0;
-        hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off);
+        hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off,
+                                  d_raw.p, d_bad.p);
         if (e == hipSuccess && whole && db->tiles.back().d_block && n_seqs) {
             const Tile& t0 = db->tiles.back();
             std::vector<uint64_t> addr(n_seqs);
@@ -477,6 +538,15 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
         db->padded_residues += t.padded_residues;
         db->max_tile_seqs = std::max(db->max_tile_seqs, t.n_seqs);
         p = q;
+    }
+    if (d_bad.p) {
+        int h_bad = 0;
+        hipError_t e1 = hipMemcpy(&h_bad, d_bad.p, 4, hipMemcpyDeviceToHost);
+        if (e1 != hipSuccess || h_bad) {
+            s4g_db_destroy(db);
+            return e1 != hipSuccess ? fail(S4G_ERR_HIP, "database upload failed: %s", hipGetErrorString(e1))
+                                    : fail(S4G_ERR_INVALID, "database upload failed: residue code out of range (codes must be letter - 'A', 0..25)");
+        }
     }
     *out = db;
     return S4G_OK;

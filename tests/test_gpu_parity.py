@@ -687,3 +687,36 @@ def test_pair_kernels_fuzz(s4g, oracle_mod, blosum62):
             assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (go, ge, int(a), int(b))
             if o["score"]:
                 assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+
+
+def test_device_side_packing(s4g, oracle_mod, blosum62, scorer):
+    """databases of 8 MB of residues and more are transposed on the device (sw_pack_tile): same scores as the oracle,
+    single- and multi-tile, empty and 1-residue sequences, lengths around the dword; an invalid code is still refused."""
+    rng = np.random.default_rng(37)
+    lens = np.concatenate([rng.integers(0, 9, size=500), rng.integers(9, 700, size=33000), rng.integers(700, 2500, size=300)])
+    rng.shuffle(lens)
+    ts = [rand_seqs(rng, 1, int(l), int(l), 26)[0] if l else np.zeros(0, np.uint8) for l in lens]
+    assert sum(len(t) for t in ts) > (8 << 20)
+    qs = rand_seqs(rng, 3, 60, 420, 26)
+    ts[123] = qs[0][5:300].copy()
+    tc, to = oracle_mod._flat(ts)
+    qc, qo = oracle_mod._flat(qs)
+    exp = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, 10, 1, threads=8)
+    if exp is None:
+        exp = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, 10, 1, threads=8)
+    q = s4g.QuerySet(qs)
+    for tile_seqs in (0, 4096):
+        db = s4g.Database(ts, tile_seqs=tile_seqs)
+        for mode in (dict(no_pairs=True), dict(force_i32=True), dict()):
+            got = s4g.scan_host(db, q, scorer, **mode)
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (tile_seqs, mode, bad[:5].tolist())
+        pt = rng.integers(0, len(ts), size=300)
+        r = s4g.traceback(db, q, scorer, np.zeros(300, np.uint32), pt, exp[0, pt])
+        for b, x in zip(pt[:40], r[:40]):
+            o = oracle_mod.sw_align(qs[0], ts[b], blosum62, 10, 1)
+            assert o["score"] == x["score"] and len(o["path"]) == len(x["path"])
+    ts[77] = ts[77].copy() if len(ts[77]) else np.zeros(5, np.uint8)
+    ts[77][0] = 26
+    with pytest.raises(RuntimeError):
+        s4g.Database(ts)
