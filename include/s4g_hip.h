@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_create_tiled / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -93,6 +93,12 @@ int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t
  * the length-sorted order; tiles bound the strip-boundary workspace and the s4g_scan_topk score buffer. */
 int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
                         uint32_t max_tile_seqs);
+
+/* The same for residue codes and offsets that already live on `device` (a database generated, decompressed or
+ * received there): only the n_seqs+1 offsets come back to the host (length sort, tile cuts); the codes are
+ * transposed where they are.  d_codes / d_offsets stay the caller's and may be freed after the call. */
+int s4g_db_create_from_device(s4g_db** out, int device, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_seqs,
+                              uint32_t max_tile_seqs);
 int s4g_db_destroy(s4g_db* db);
 /* Packed on-disk format: the tiles exactly as they sit in HBM.  s4g_db_save writes a database created from
  * sequences; s4g_db_load places a saved one on `device` without parsing or packing. */

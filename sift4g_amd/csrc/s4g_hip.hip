@@ -449,9 +449,33 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
 
 }  // namespace
 
+namespace {
+// codes: host copy of the residues, or NULL when d_codes (device copy, caller-owned) is given
+int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t* d_codes, const uint64_t* offsets, uint32_t n_seqs,
+                   uint32_t max_tile_seqs);
+}
+
 S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
                                 uint32_t max_tile_seqs) {
     if (!out || !offsets || (!codes && n_seqs && offsets[n_seqs])) return fail(S4G_ERR_INVALID, "NULL argument");
+    return db_create_impl(out, device, codes, nullptr, offsets, n_seqs, max_tile_seqs);
+}
+
+S4G_API int s4g_db_create_from_device(s4g_db** out, int device, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_seqs,
+                                      uint32_t max_tile_seqs) {
+    if (!out || !d_offsets || (!d_codes && n_seqs)) return fail(S4G_ERR_INVALID, "NULL argument");
+    int have = device_count_raw();
+    if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
+    if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    DeviceGuard guard(device);
+    std::vector<uint64_t> offsets((size_t)n_seqs + 1);
+    HIP_TRY(hipMemcpy(offsets.data(), d_offsets, offsets.size() * 8, hipMemcpyDeviceToHost));    // only the lengths come to the host
+    return db_create_impl(out, device, nullptr, d_codes, offsets.data(), n_seqs, max_tile_seqs);
+}
+
+namespace {
+int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t* d_codes, const uint64_t* offsets, uint32_t n_seqs,
+                   uint32_t max_tile_seqs) {
     int have = device_count_raw();
     if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
     if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
@@ -484,10 +508,15 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
     const uint64_t total_res = n_seqs ? offsets[n_seqs] : 0;
     DevBuf<uint8_t> d_raw;
     DevBuf<int> d_bad;
-    if (total_res >= (8ull << 20) && total_res <= (16ull << 30)) {
+    const uint8_t* raw_dev = d_codes;       // codes that already live on the device are packed there whatever their size
+    if (d_codes || (total_res >= (8ull << 20) && total_res <= (16ull << 30))) {
         const double t_raw = now_s();
-        hipError_t e1 = d_raw.alloc(total_res);
-        if (e1 == hipSuccess) e1 = hipMemcpy(d_raw.p, codes, total_res, hipMemcpyHostToDevice);
+        hipError_t e1 = hipSuccess;
+        if (!d_codes) {
+            e1 = d_raw.alloc(total_res);
+            if (e1 == hipSuccess) e1 = hipMemcpy(d_raw.p, codes, total_res, hipMemcpyHostToDevice);
+            raw_dev = d_raw.p;
+        }
         if (e1 == hipSuccess) e1 = d_bad.alloc(1);
         if (e1 == hipSuccess) e1 = hipMemset(d_bad.p, 0, 4);
         if (e1 != hipSuccess) { s4g_db_destroy(db); return fail(S4G_ERR_HIP, "database upload failed: %s", hipGetErrorString(e1)); }
@@ -515,7 +544,7 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
         const bool whole = (p == 0 && q == n_seqs);
         uint64_t tab_off = 0;
         hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off,
-                                  d_raw.p, d_bad.p);
+                                  raw_dev, d_bad.p);
         if (e == hipSuccess && whole && db->tiles.back().d_block && n_seqs) {
             const Tile& t0 = db->tiles.back();
             std::vector<uint64_t> addr(n_seqs);
@@ -551,6 +580,7 @@ S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, 
     *out = db;
     return S4G_OK;
 }
+}  // namespace
 
 S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs) {
     return s4g_db_create_tiled(out, device, codes, offsets, n_seqs, 0);

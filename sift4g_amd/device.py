@@ -107,6 +107,27 @@ class Database(_SeqSet):
         self.lengths = None
         return self
 
+    @classmethod
+    def from_device(cls, codes, offsets, tile_seqs=0):
+        """codes: torch uint8 tensor on the GPU (one byte per residue, sequences back to back); offsets: torch int64 tensor
+        [n+1] on the same GPU.  Only the offsets travel to the host; the codes are packed where they are."""
+        import torch
+        if codes.dtype != torch.uint8 or offsets.dtype != torch.int64 or not codes.is_cuda or codes.device != offsets.device:
+            raise ValueError("codes must be a uint8 and offsets an int64 tensor on the same GPU")
+        codes, offsets = codes.contiguous(), offsets.contiguous()
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.device = codes.device.index or 0
+        torch.cuda.current_stream(codes.device).synchronize()          # the library reads the tensors on the null stream
+        check(lib.s4g_db_create_from_device(ctypes.byref(self._h), self.device, ctypes.c_void_p(codes.data_ptr()),
+                                            ctypes.c_void_p(offsets.data_ptr()), offsets.numel() - 1, int(tile_seqs)),
+              "s4g_db_create_from_device")
+        self.n = offsets.numel() - 1
+        self.codes = None
+        self.offsets = offsets.cpu().numpy().astype(np.uint64)
+        self.lengths = np.diff(self.offsets).astype(np.uint32)
+        return self
+
     def tiles(self):
         n = ctypes.c_uint32()
         check(lib.s4g_db_tiles(self._h, ctypes.byref(n), None, 0), "s4g_db_tiles")

@@ -720,3 +720,32 @@ def test_device_side_packing(s4g, oracle_mod, blosum62, scorer):
     ts[77][0] = 26
     with pytest.raises(RuntimeError):
         s4g.Database(ts)
+
+
+def test_database_from_device_resident_codes(s4g, oracle_mod, blosum62, scorer):
+    """s4g_db_create_from_device: codes generated / held on the GPU are packed there (only the offsets visit the host);
+    small and multi-tile databases, same scores and alignments as the host-created database."""
+    import torch
+    rng = np.random.default_rng(38)
+    qs = rand_seqs(rng, 5, 30, 300, 26)
+    for nt, tile_seqs in ((700, 0), (700, 128), (3, 0)):
+        ts = rand_seqs(rng, nt, 0, 400, 26)
+        ts[1] = qs[0][3:].copy()
+        tc, to = oracle_mod._flat(ts)
+        d_codes = torch.from_numpy(tc.copy()).to("cuda:0")
+        d_off = torch.from_numpy(to.astype(np.int64)).to("cuda:0")
+        db = s4g.Database.from_device(d_codes, d_off, tile_seqs=tile_seqs)
+        del d_codes, d_off                                     # the database keeps nothing of the caller's buffers
+        torch.cuda.empty_cache()
+        exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+        q = s4g.QuerySet(qs)
+        for mode in (dict(no_pairs=True), dict()):
+            assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp), (nt, tile_seqs, mode)
+        r = s4g.traceback(db, q, scorer, [0], [1], [int(exp[0, 1])])[0]
+        o = oracle_mod.sw_align(qs[0], ts[1], blosum62, 10, 1)
+        assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+    bad = torch.full((10,), 27, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        s4g.Database.from_device(bad, torch.tensor([0, 10], dtype=torch.int64, device="cuda:0"))
+    with pytest.raises(ValueError):
+        s4g.Database.from_device(bad.cpu(), torch.tensor([0, 10], dtype=torch.int64))
