@@ -20,9 +20,18 @@ build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	@mkdir -p build
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
-$(LIBDIR)/libs4g_hip.so: $(CSRC)/s4g_hip.hip $(wildcard $(CSRC)/*.h) include/s4g_hip.h
+# libs4g_hip.so: one object per translation unit (make -j builds them side by side), every unit depends on every header
+HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip
+HIPOBJ  := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIPSRC))
+HIPHDR  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/s4g_hip.h
+
+build/obj/%.o: $(CSRC)/%.hip $(HIPHDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIBDIR)/libs4g_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/s4g_hip.hip
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIPOBJ)
 
 $(LIBDIR)/libswsharp.so: $(SWSRC) $(CSRC)/swsharp/impl.hpp $(CSRC)/matrices.h include/swsharp/swsharp.h include/swsharp/evalue.h $(LIBDIR)/libs4g_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(SWSRC) -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN'
@@ -38,9 +47,9 @@ dropin: $(LIBDIR)/libswsharp.so
 oracle:
 	$(MAKE) -s -C oracle
 
-isa: $(CSRC)/s4g_hip.hip $(wildcard $(CSRC)/*.h)
+isa: $(HIPSRC) $(HIPHDR)
 	@mkdir -p build/isa
-	cd build/isa && $(HIPCC) $(HIPFLAGS) -c -save-temps -Rpass-analysis=kernel-resource-usage ../../$(CSRC)/s4g_hip.hip -o s4g_hip.o
+	cd build/isa && for f in $(HIPSRC); do $(HIPCC) $(HIPFLAGS) -c -save-temps -Rpass-analysis=kernel-resource-usage ../../$$f -o $$(basename $$f .hip).o || exit 1; done
 
 clean:
 	rm -rf build $(LIBDIR)/*.so

@@ -1,0 +1,165 @@
+// s4g_internal.hpp -- declarations shared by the translation units of libs4g_hip.so (nothing here is exported; the
+// C ABI is include/s4g_hip.h).  Files: s4g_core.hip (errors, scorer, database, queries), s4g_scan.hip (plan, scan
+// launches, top-k), s4g_pairs.hip (one wave per pair: scores and traceback), s4g_trace.hip (traceback entry points and
+// the 64-pairs-per-wave route).
+#pragma once
+#include "../../include/s4g_hip.h"
+#include "sw_kernels.hip.h"
+#include "sw_pair.hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace s4g;
+
+#define S4G_API extern "C" __attribute__((visibility("default")))
+
+// error reporting: every failure sets the thread's message (s4g_last_error) and returns a code
+int fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(S4G_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+int device_count_raw();
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct s4g_scorer {
+    int32_t table[26 * 26];
+    int8_t mat32[32 * 32];
+    int open, ext;
+    int max_score, min_score;
+    int row_max[32];        // max(0, max_b table[a][b]): per-row bound on what one DP row can add
+    uint64_t serial;        // identity for caches keyed on the scorer
+};
+
+// A tile = a slice of the length-sorted database that is scanned by one launch (per kernel).  Tiles keep the
+// strip-boundary workspace bounded (it scales with the tile's longest sequence) and let huge databases stream
+// through a bounded score buffer (s4g_scan_topk).  Small databases are a single tile.
+struct Tile {
+    uint32_t n_seqs = 0, n_groups = 0, max_len4 = 0;
+    uint64_t residues = 0, padded_residues = 0;
+    uint32_t* d_res = nullptr;          // lane-transposed residues
+    uint64_t* d_grp_off = nullptr;
+    uint32_t* d_grp_len4 = nullptr;
+    uint32_t* d_perm_global = nullptr;  // [G*64] original target id of (g, lane); ~0u = empty lane
+    uint32_t* d_perm_local = nullptr;   // [G*64] column in the tile's own score buffer = rank of the id inside the tile
+    uint32_t* d_col_ids = nullptr;      // [n_seqs] tile column -> original target id (ascending)
+    std::vector<uint64_t> h_grp_off;    // host copy (traceback addresses lanes of arbitrary targets)
+    char* d_block = nullptr;            // small tiles: every array above lives in this one allocation (recycled through
+    uint64_t block_bytes = 0;           // DeviceCtx::block_cache: sift4g creates a candidate database per query)
+    uint64_t pos0 = 0;                  // position of the tile's first sequence in the global length-sorted order
+};
+
+struct s4g_db {
+    int device = 0;
+    uint32_t n_seqs = 0;
+    uint64_t residues = 0, padded_residues = 0, hbm_bytes = 0;
+    uint32_t max_tile_seqs = 0;
+    std::vector<Tile> tiles;
+    std::vector<uint32_t> len;     // original index -> length
+    std::vector<uint32_t> pos_of_id;   // original index -> position in the global length-sorted order
+    // per-sequence tables for the pair kernels (built on first use, under the device mutex)
+    mutable uint64_t* d_seq_addr = nullptr;     // [n_seqs] device address of the sequence's first residue dword
+    mutable uint32_t* d_seq_len = nullptr;      // [n_seqs]
+    mutable std::vector<uint32_t> id_of_pos;    // position in the length-sorted order -> original index
+    bool seq_tables_in_block = false;           // d_seq_addr / d_seq_len are part of tiles[0].d_block
+};
+
+// Per-device scratch shared by every database on that device: strip-boundary workspace, work-queue counters, query
+// lists, the streaming score buffer, a grow-only arena for the traceback.  sift4g's wrapper creates and destroys one
+// ChainDatabase per (query, chunk) (database_alignment.cpp:80,92); keeping the scratch here instead of in s4g_db
+// removes a multi-hundred-MB hipMalloc/hipFree pair from every such call.  All launches on a device serialize on
+// `mu` at enqueue time and on `last_use` across streams.
+struct DeviceCtx {
+    std::mutex mu;
+    int device = 0;
+    bool have_prop = false;
+    hipDeviceProp_t prop;
+    int32_t* d_ws = nullptr;
+    uint64_t ws_bytes = 0;
+    unsigned* d_counter = nullptr;
+    int8_t* d_mat = nullptr;
+    uint32_t* d_qlist = nullptr;     // query-id lists of the current call (pairs for the packed tiers, singles for int32)
+    uint64_t qlist_cap = 0;
+    int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
+    uint64_t tile_scores_bytes = 0;
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
+    uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
+    // pair lists: pinned staging for the items of the current call, their device copy (+ host-route scores behind it)
+    s4g::PairItem* h_items = nullptr;
+    s4g::PairItem* d_items = nullptr;
+    uint64_t items_cap = 0;
+    hipEvent_t items_done = nullptr;    // the upload that last read h_items
+    hipEvent_t last_use = nullptr;      // orders launches that share the scratch buffers across streams
+    // long-sequence tiles have few, huge items: they run on a side stream (own workspace and counters) underneath the
+    // main tiles instead of as a tail-dominated launch of their own
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    int32_t* d_ws_side = nullptr;
+    uint64_t ws_side_bytes = 0;
+    std::vector<std::pair<char*, uint64_t>> block_cache;    // freed small-tile blocks, reused by the next s4g_db_create
+    char* arena = nullptr;              // traceback temporaries
+    uint64_t arena_bytes = 0;
+};
+
+DeviceCtx* device_ctx(int device);
+
+struct s4g_queries {
+    int device = 0;
+    uint32_t n = 0;
+    uint8_t* d_codes = nullptr;
+    uint64_t* d_off = nullptr;
+    uint32_t* d_len = nullptr;
+    std::vector<uint32_t> len;
+    std::vector<uint8_t> codes;              // host copy (unpadded) for per-scorer bounds
+    std::vector<uint64_t> off;
+    uint32_t max_len = 0;
+    mutable std::vector<uint64_t> score_bound;
+    mutable uint64_t bound_scorer = 0;
+};
+
+constexpr uint32_t kLongSeq = 12288;                   // sequences longer than this get tiles of their own: beyond ~16k residues
+                                                       // the per-wave strip-boundary workspace no longer fits the budget at full grid
+
+template <typename T>
+struct DevBuf {          // scoped device allocation for the non-hot paths
+    T* p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// s4g_scan.hip
+int device_props(DeviceCtx* cx);
+int scratch_acquire(const s4g_db* db, hipStream_t stream);
+int scratch_release(const s4g_db* db, hipStream_t stream);
+// s4g_pairs.hip
+int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done);
+int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                    const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);

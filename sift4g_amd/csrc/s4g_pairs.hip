@@ -1,0 +1,401 @@
+// s4g_pairs.hip -- C ABI: the latency path, one wave per (query, target) pair (sw_pair.hip.h): explicit pair lists,
+// the pair route of s4g_scan, and the traceback of the survivors of a per-query alignDatabase call
+// (/root/reference/sift4g/src/database_alignment.cpp:70-92).
+#include "s4g_internal.hpp"
+
+// ---------------------------------------------------------------------------
+// Pair lists (the latency path, sw_pair.hip.h): explicit (query, target) pairs, one wave per pair.
+
+constexpr int kPairClasses = 6;
+constexpr int kPairRpl[kPairClasses] = {2, 4, 6, 8, 12, 16};
+inline int pair_class(uint32_t lq) { int c = 0; while (64u * kPairRpl[c] < lq) ++c; return c; }
+// Measured rates (tools/pair_latency.py, profiles/r01_pair): cells per second a chip full of pair waves sustains and
+// the cells per second ONE wave makes on one pair, against the scan's chip rate and the cells per second of one
+// inter-sequence lane (which bounds a scan launch from below: one wave walks a whole (query pair, group) DP).
+constexpr double kPairChipRate = 2.5e12, kPairWaveRate = 2.4e9 / 0.7, kPairCallOverhead = 60e-6;
+constexpr double kScanChipRate = 10e12, kScanLaneRate = 2.4e9 / 37.0;
+
+template <int RPL>
+int launch_pairs(DeviceCtx* cx, PairArgs a, uint32_t* grid_cache, hipStream_t stream) {
+    if (*grid_cache == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan<RPL>, 64, 0));
+        *grid_cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(*grid_cache, a.n_pairs));
+    hipLaunchKernelGGL(sw_pair_scan<RPL>, dim3(grid), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// device tables indexed by original target id (caller holds cx->mu)
+int ensure_seq_tables(const s4g_db* db) {
+    if (db->d_seq_addr || db->n_seqs == 0) return S4G_OK;
+    std::vector<uint64_t> addr(db->n_seqs);
+    db->id_of_pos.resize(db->n_seqs);
+    size_t ti = 0;
+    // walk ids in position order so the tile lookup is a running index
+    for (uint32_t id = 0; id < db->n_seqs; ++id) db->id_of_pos[db->pos_of_id[id]] = id;
+    for (uint32_t pos = 0; pos < db->n_seqs; ++pos) {
+        while (ti + 1 < db->tiles.size() && db->tiles[ti + 1].pos0 <= pos) ++ti;
+        const Tile& t = db->tiles[ti];
+        const uint32_t lp = (uint32_t)(pos - t.pos0);
+        addr[db->id_of_pos[pos]] = (uint64_t)(uintptr_t)(t.d_res + t.h_grp_off[lp >> 6] + (lp & 63));
+    }
+    HIP_TRY(hipMalloc((void**)&db->d_seq_addr, (size_t)db->n_seqs * 8));
+    HIP_TRY(hipMalloc((void**)&db->d_seq_len, (size_t)db->n_seqs * 4));
+    HIP_TRY(hipMemcpy(db->d_seq_addr, addr.data(), (size_t)db->n_seqs * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->d_seq_len, db->len.data(), (size_t)db->n_seqs * 4, hipMemcpyHostToDevice));
+    return S4G_OK;
+}
+
+// pinned staging for n items (caller holds cx->mu); the previous upload out of it has completed on return
+int pair_stage(DeviceCtx* cx, uint64_t n, PairItem** out) {
+    if (cx->items_done) HIP_TRY(hipEventSynchronize(cx->items_done));
+    else HIP_TRY(hipEventCreateWithFlags(&cx->items_done, hipEventDisableTiming));
+    if (cx->items_cap < n) {
+        if (cx->h_items) HIP_TRY(hipHostFree(cx->h_items));
+        if (cx->d_items) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_items)); }
+        cx->h_items = nullptr; cx->d_items = nullptr; cx->items_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(n + n / 4, 1u << 16);
+        HIP_TRY(hipHostMalloc((void**)&cx->h_items, cap * sizeof(PairItem), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&cx->d_items, cap * (sizeof(PairItem) + 4)));       // + int32 scores of the host route
+        cx->items_cap = cap;
+    }
+    *out = cx->h_items;
+    return S4G_OK;
+}
+
+// uploads the staged items (class-major: cls_begin[c] .. cls_begin[c+1]) and launches one kernel per class
+int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n, const uint32_t* cls_begin,
+                int32_t* d_scores, hipStream_t stream) {
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    rc = scratch_acquire(db, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(cx->d_items, cx->h_items, (size_t)n * sizeof(PairItem), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(cx->items_done, stream));
+    HIP_TRY(hipMemsetAsync(cx->d_counter + 24, 0, kPairClasses * 4, stream));
+    for (int c = 0; c < kPairClasses; ++c) {
+        const uint32_t b = cls_begin[c], e = cls_begin[c + 1];
+        if (b == e) continue;
+        PairArgs a;
+        a.items = cx->d_items + b; a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+        a.scores = d_scores; a.counter = cx->d_counter + 24 + c; a.n_pairs = e - b;
+        a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        switch (c) {
+            case 0: rc = launch_pairs<2>(cx, a, &cx->grid_pair[0], stream); break;
+            case 1: rc = launch_pairs<4>(cx, a, &cx->grid_pair[1], stream); break;
+            case 2: rc = launch_pairs<6>(cx, a, &cx->grid_pair[2], stream); break;
+            case 3: rc = launch_pairs<8>(cx, a, &cx->grid_pair[3], stream); break;
+            case 4: rc = launch_pairs<12>(cx, a, &cx->grid_pair[4], stream); break;
+            default: rc = launch_pairs<16>(cx, a, &cx->grid_pair[5], stream); break;
+        }
+        if (rc) return rc;
+    }
+    return scratch_release(db, stream);
+}
+
+// Explicit list -> host scores.  sel = indices into pair_q / pair_t whose queries have <= kPairMaxRows residues.
+// Order inside a class: longest target first at 32-residue granularity (counting sort; a launch cannot end before its
+// longest pair does, so that one must not start last).
+int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                       const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores) {
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    hipStream_t stream = nullptr;
+    static const bool prof = getenv("S4G_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    const uint32_t n = (uint32_t)sel.size();
+    PairItem* items = nullptr;
+    int rc = pair_stage(cx, n, &items);
+    if (rc) return rc;
+    constexpr uint32_t kBuckets = 2048;
+    static thread_local std::vector<uint32_t> count;
+    count.assign((size_t)kPairClasses * kBuckets + 1, 0);
+    auto key_of = [&](uint32_t pi) {
+        const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
+        return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
+    };
+    for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
+    for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+    uint32_t cls_begin[kPairClasses + 1];
+    for (int c = 0; c <= kPairClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t pi = sel[i];
+        const uint32_t at = count[key_of(pi)]++;
+        items[at] = {pair_q[pi], pair_t[pi], at};
+        h_scores[pi] = (int32_t)at;            // remember where this pair's score will sit
+    }
+    auto t1 = now();
+    int32_t* d_sc = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
+    rc = pair_submit(db, q, scorer, n, cls_begin, d_sc, stream);
+    if (rc) return rc;
+    auto t2 = now();
+    static thread_local std::vector<int32_t> sc;
+    sc.resize(n);
+    HIP_TRY(hipMemcpyAsync(sc.data(), d_sc, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < n; ++i) { const uint32_t pi = sel[i]; h_scores[pi] = sc[(uint32_t)h_scores[pi]]; }
+    if (prof) {
+        auto t3 = now();
+        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+        fprintf(stderr, "[s4g profile] pairs n=%u: order %.1f us, upload+launch %.1f us, wait+download %.1f us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return S4G_OK;
+}
+
+// s4g_scan's latency route: the whole [q_count][n_seqs] matrix as pairs (caller holds cx->mu).  Taken when the estimate
+// says the inter-sequence launch would wait on its longest item for longer than a chip full of pair waves needs for
+// everything; never for queries beyond kPairMaxRows or when a kernel was forced by flags.
+int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done) {
+    *done = false;
+    if (flags != 0) return S4G_OK;
+    const uint64_t n_items = (uint64_t)q_count * db->n_seqs;
+    if (n_items > (4u << 20)) return S4G_OK;
+    uint32_t lq_max = 0, max_t = 0;
+    uint64_t rows = 0;
+    for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
+    if (lq_max > (uint32_t)kPairMaxRows) return S4G_OK;
+    for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
+    const double cells = (double)rows * (double)db->residues, longest = (double)lq_max * max_t;
+    const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
+    const double t_scan = std::max(cells / kScanChipRate, longest / kScanLaneRate);
+    if (t_pairs >= t_scan) return S4G_OK;
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    PairItem* items = nullptr;
+    rc = pair_stage(cx, n_items, &items);
+    if (rc) return rc;
+    // class-major; inside a class the targets in length-sorted order (longest first), queries innermost
+    uint32_t cls_begin[kPairClasses + 1];
+    uint32_t at = 0;
+    std::vector<uint32_t> qs;
+    for (int c = 0; c < kPairClasses; ++c) {
+        cls_begin[c] = at;
+        qs.clear();
+        for (uint32_t i = 0; i < q_count; ++i) if (pair_class(q->len[q_begin + i]) == c) qs.push_back(i);
+        if (qs.empty()) continue;
+        for (uint32_t pos = 0; pos < db->n_seqs; ++pos) {
+            const uint32_t id = db->id_of_pos[pos];
+            for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * db->n_seqs + id)};
+        }
+    }
+    cls_begin[kPairClasses] = at;
+    rc = pair_submit(db, q, scorer, at, cls_begin, d_scores, stream);
+    if (rc) return rc;
+    *done = true;
+    return S4G_OK;
+}
+
+
+S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint64_t n_pairs,
+                                 const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, uint32_t flags) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (n_pairs == 0) return S4G_OK;
+    if (!pair_q || !pair_t || !h_scores) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if (n_pairs >= 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "too many pairs in one call");
+    if ((flags & S4G_PAIRS_FORCE_SCAN) && (flags & S4G_PAIRS_FORCE_WAVE)) return fail(S4G_ERR_INVALID, "contradictory flags");
+    for (uint64_t i = 0; i < n_pairs; ++i)
+        if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)i);
+    // Two exact routes.  "wave": one wave per pair (sw_pair_scan), for queries of up to kPairMaxRows residues.
+    // "scan": score the pair's query against the whole resident database and pick the column.  Per query the cheaper
+    // estimate wins: few candidates -> wave, candidate list ~ the whole database -> scan.
+    std::vector<std::vector<uint32_t>> by_q(q->n);
+    for (uint64_t i = 0; i < n_pairs; ++i) by_q[pair_q[i]].push_back((uint32_t)i);
+    std::vector<uint32_t> wave_sel, scan_queries;
+    uint32_t max_t = 0;
+    for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
+    for (uint32_t qi = 0; qi < q->n; ++qi) {
+        if (by_q[qi].empty()) continue;
+        const uint32_t lq = q->len[qi];
+        if (lq == 0) { for (uint32_t i : by_q[qi]) h_scores[i] = 0; continue; }
+        bool wave = lq <= (uint32_t)kPairMaxRows;
+        if (wave && !(flags & S4G_PAIRS_FORCE_WAVE)) {
+            double cells = 0, longest = 0;
+            for (uint32_t i : by_q[qi]) { const double c = (double)lq * db->len[pair_t[i]]; cells += c; longest = std::max(longest, c); }
+            const double t_wave = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
+            const double full = (double)lq * (double)db->residues;
+            const double t_scan = std::max(full / kScanChipRate, (double)lq * max_t / kScanLaneRate) + (double)db->n_seqs * 4.0 / 20e9;
+            wave = t_wave <= t_scan;
+        }
+        if (flags & S4G_PAIRS_FORCE_SCAN) wave = false;
+        if (!wave && (flags & S4G_PAIRS_FORCE_WAVE))
+            return fail(S4G_ERR_INVALID, "query %u has %u residues; the pair kernel takes at most %d", qi, lq, kPairMaxRows);
+        if (wave) {
+            wave_sel.insert(wave_sel.end(), by_q[qi].begin(), by_q[qi].end());
+        } else scan_queries.push_back(qi);
+    }
+    if (!wave_sel.empty()) {
+        int rc = score_pairs_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores);
+        if (rc) return rc;
+    }
+    if (!scan_queries.empty()) {
+        // consecutive runs of scan-route queries share one scan call, bounded to ~1 GiB of host scores
+        const uint32_t batch = std::max<uint32_t>(1, (uint32_t)((1ull << 28) / std::max<uint32_t>(1, db->n_seqs)));
+        std::vector<int32_t> row;
+        for (size_t s0 = 0; s0 < scan_queries.size();) {
+            size_t s1 = s0 + 1;
+            while (s1 < scan_queries.size() && scan_queries[s1] == scan_queries[s1 - 1] + 1 && s1 - s0 < batch) ++s1;
+            const uint32_t cnt = (uint32_t)(s1 - s0);
+            row.resize((size_t)cnt * db->n_seqs);
+            int rc = s4g_scan_host(db, q, scan_queries[s0], cnt, scorer, row.data());
+            if (rc) return rc;
+            for (uint32_t k = 0; k < cnt; ++k)
+                for (uint32_t i : by_q[scan_queries[s0 + k]]) h_scores[i] = row[(size_t)k * db->n_seqs + pair_t[i]];
+            s0 = s1;
+        }
+    }
+    return S4G_OK;
+}
+
+S4G_API int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t* cand_offsets,
+                                 const uint32_t* cand_ids, const s4g_scorer* scorer, int32_t* h_scores) {
+    if (!db || !q || !scorer || !cand_offsets) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q->n == 0 || cand_offsets[q->n] == 0) return S4G_OK;
+    if (!cand_ids || !h_scores) return fail(S4G_ERR_INVALID, "NULL argument");
+    const uint64_t n = cand_offsets[q->n];
+    for (uint64_t i = 0; i < n; ++i)
+        if (cand_ids[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "candidate id %u out of range", cand_ids[i]);
+    std::vector<uint32_t> pq(n);
+    for (uint32_t i = 0; i < q->n; ++i) {
+        if (cand_offsets[i + 1] < cand_offsets[i] || cand_offsets[i + 1] > n) return fail(S4G_ERR_INVALID, "bad candidate offsets at %u", i);
+        for (uint64_t k = cand_offsets[i]; k < cand_offsets[i + 1]; ++k) pq[k] = i;
+    }
+    return s4g_score_pairs_host(db, q, scorer, n, pq.data(), cand_ids, h_scores, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Traceback of the survivors on the device (step 4 of alignDatabase).
+
+template <int RPL>
+int launch_pair_trace(DeviceCtx* cx, PairTraceArgs a, uint32_t* grid_cache, hipStream_t stream) {
+    if (*grid_cache == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace<RPL>, 64, 0));
+        *grid_cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(*grid_cache, a.n_pairs));
+    hipLaunchKernelGGL(sw_pair_trace<RPL>, dim3(grid), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// Traceback with one wave per pair (sw_pair_trace): `sel` = indices of the pairs whose query has <= kPairMaxRows residues.
+int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                    const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
+                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    hipStream_t stream = nullptr;
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    // class-major, longest target first (32-residue granularity), as in score_pairs_device
+    const uint32_t n = (uint32_t)sel.size();
+    constexpr uint32_t kBuckets = 2048;
+    std::vector<uint32_t> count((size_t)kPairClasses * kBuckets + 1, 0), order(n);
+    auto key_of = [&](uint32_t pi) {
+        const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
+        return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
+    };
+    for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
+    for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+    uint32_t cls_begin[kPairClasses + 1];
+    for (int c = 0; c <= kPairClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    for (uint32_t i = 0; i < n; ++i) order[count[key_of(sel[i])]++] = sel[i];
+    auto dir_bytes = [&](uint32_t pi) {
+        const int c = pair_class(q->len[pair_q[pi]]);
+        const uint32_t rpl = (uint32_t)kPairRpl[c], nw = rpl <= 4 ? 1 : (rpl <= 8 ? 2 : 4);
+        const uint64_t steps = (uint64_t)db->len[pair_t[pi]] + (q->len[pair_q[pi]] + rpl - 1) / rpl - 1;
+        return ((steps + 1) & ~1ull) * 64 * nw * 4;
+    };
+    const uint64_t dir_budget = 8ull << 30;
+    std::vector<PairTraceItem> items;
+    std::vector<int32_t> out5, best;
+    std::vector<uint8_t> paths;
+    for (uint32_t b0 = 0; b0 < n;) {
+        // a batch: consecutive pairs of ONE class whose direction blocks fit the budget
+        int c = 0;
+        while (cls_begin[c + 1] <= b0) ++c;
+        uint32_t b1 = b0;
+        uint64_t dir_total = 0, path_total = 0;
+        items.clear();
+        while (b1 < cls_begin[c + 1] && (b1 == b0 || dir_total + dir_bytes(order[b1]) <= dir_budget)) {
+            const uint32_t pi = order[b1];
+            const uint64_t cap = (uint64_t)q->len[pair_q[pi]] + db->len[pair_t[pi]];
+            path_total += cap;
+            items.push_back({pair_q[pi], pair_t[pi], pair_score[pi], b1 - b0, dir_total, path_total});
+            dir_total += dir_bytes(pi);
+            ++b1;
+        }
+        const uint32_t ni = b1 - b0;
+        const bool big_dirs = dir_total > (256ull << 20);
+        DevBuf<uint8_t> d_dirs_big;
+        if (big_dirs) HIP_TRY(d_dirs_big.alloc(dir_total));
+        uint64_t need = 0;
+        auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
+        const uint64_t o_items = reserve((uint64_t)ni * sizeof(PairTraceItem)), o_out = reserve((uint64_t)ni * 20), o_best = reserve((uint64_t)ni * 4);
+        const uint64_t o_paths = reserve(path_total), o_dirs = big_dirs ? 0 : reserve(dir_total);
+        if (cx->arena_bytes < need) {
+            if (cx->arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->arena)); }
+            cx->arena = nullptr; cx->arena_bytes = 0;
+            const uint64_t want = std::max<uint64_t>(need + need / 4, 16ull << 20);
+            HIP_TRY(hipMalloc((void**)&cx->arena, want));
+            cx->arena_bytes = want;
+        }
+        char* A = cx->arena;
+        HIP_TRY(hipMemcpyAsync(A + o_items, items.data(), (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(cx->d_counter + 32, 0, 4, stream));
+        PairTraceArgs a;
+        a.items = reinterpret_cast<const PairTraceItem*>(A + o_items); a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
+        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+        a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
+        a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
+        a.counter = cx->d_counter + 32; a.n_pairs = ni; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        switch (c) {
+            case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
+            case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
+            case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
+            case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
+            case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
+            default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
+        }
+        if (rc) return rc;
+        out5.resize((size_t)ni * 5); best.resize(ni); paths.resize(path_total ? path_total : 1);
+        HIP_TRY(hipMemcpyAsync(out5.data(), A + o_out, (size_t)ni * 20, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(best.data(), A + o_best, (size_t)ni * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(paths.data(), A + o_paths, path_total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (uint32_t x = 0; x < ni; ++x) {
+            const uint32_t pi = order[b0 + x];
+            const int32_t want = pair_score[pi] > 0 && q->len[pair_q[pi]] && db->len[pair_t[pi]] ? pair_score[pi] : 0;
+            if (best[x] != want && !(pair_score[pi] <= 0 && best[x] == 0))
+                return fail(S4G_ERR_INVALID, "pair %u: score %d passed in, traceback kernel computed %d", pi, pair_score[pi], best[x]);
+            memcpy(h_out + (size_t)pi * 5, out5.data() + (size_t)x * 5, 20);
+            const uint32_t len = (uint32_t)out5[(size_t)x * 5 + 4];
+            memcpy(h_paths + path_off[pi], paths.data() + items[x].path_end - len, len);
+        }
+        b0 = b1;
+    }
+    return S4G_OK;
+}
+

@@ -1,0 +1,704 @@
+// s4g_scan.hip -- C ABI: the scan (step 1 of swsharp's alignDatabase as sift4g calls it,
+// /root/reference/sift4g/src/database_alignment.cpp:83-86) and the device top-k (steps 2-3): per-tile plan, tier routing,
+// persistent-grid launches, streaming scan + running top-k.
+#include "s4g_internal.hpp"
+
+// ---------------------------------------------------------------------------
+
+constexpr int kStripRows = 32;      // sw_scan_i32
+constexpr int kStripRows16 = 32;    // sw_scan_i16x2
+constexpr uint64_t kWorkspaceBudget = 24ull << 30;   // strip-boundary workspace cap; long-sequence tiles run on a smaller grid
+constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of the [query batch][tile columns] buffer
+
+// Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
+// is EXACT for it (score bound = sum_i max(0, max_b M[q_i][b]); see sw_kernels.hip.h for each window):
+//   drift  sw_scan_pkd          bound + B + (rows + tile columns) * ext <= 0x7BFF      6.5 ops / pair of cells
+//   m3     sw_scan_pk<I16M3>    bound + B <= 0x7BFF   (or ArithF16: bound <= 4096)     7.5
+//   pk     sw_scan_pk<I16>      bound <= 32767                                          9
+//   wide   sw_scan_i32          anything                                                7.5 per single cell
+struct TileWork {
+    uint32_t off_drift = 0, n_drift = 0;   // offsets / pair counts into Plan::flat (pairs = 2 ids each)
+    uint32_t off_m3 = 0, n_m3 = 0;
+    uint32_t off_pk = 0, n_pk = 0;
+    uint32_t off_wide = 0, n_wide = 0;     // single ids
+    uint32_t prio_cost[3] = {0, 0, 0};     // per packed tier: rows * len4 at or above which an item runs at raised wave priority
+};
+
+struct Plan {
+    std::vector<TileWork> tiles;    // one per database tile
+    std::vector<uint32_t> flat;     // all id lists, uploaded once per call
+    bool f16_arith = false;         // m3 tier runs ArithF16 instead of ArithI16M3
+    uint32_t bias = 0;              // bias B of the maximum3-based tiers
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_m3 = 0, grid_drift = 0;   // full persistent grids
+    uint64_t ws_bytes = 0;          // workspace needed for the largest tile launch
+    uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
+};
+
+int device_props(DeviceCtx* cx) {
+    if (!cx->have_prop) {
+        HIP_TRY(hipGetDeviceProperties(&cx->prop, cx->device));
+        cx->have_prop = true;
+    }
+    return S4G_OK;
+}
+
+int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
+    if (*cache == 0) {
+        DeviceCtx* cx = device_ctx(db->device);
+        int rc = device_props(cx);
+        if (rc) return rc;
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+        if (per_cu < 1) per_cu = 1;
+        *cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)per_cu;
+    }
+    return S4G_OK;
+}
+
+inline uint64_t ws_slot_elems(const Tile& t) { return 2ull * (t.max_len4 ? t.max_len4 : 1) * 64 * 4; }   // int32 per wave slot
+
+// grid of a tile launch: the full persistent grid unless the tile's sequences are so long that the per-wave
+// strip-boundary workspace would exceed the budget
+inline uint32_t tile_grid(const Tile& t, uint32_t full_grid) {
+    const uint64_t per_block = ws_slot_elems(t) * 4 * kWavesPerBlock;
+    const uint64_t fit = kWorkspaceBudget / per_block;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, fit));
+}
+
+// per-query upper bound of any reachable score under this scorer (host, O(residues), cached per scorer)
+void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer) {
+    if (q->bound_scorer == scorer->serial) return;
+    q->score_bound.assign(q->n, 0);
+    for (uint32_t i = 0; i < q->n; ++i) {
+        uint64_t b = 0;
+        const uint8_t* c = q->codes.data() + q->off[i];
+        for (uint32_t j = 0; j < q->len[i]; ++j) b += (uint64_t)scorer->row_max[c[j]];
+        q->score_bound[i] = b;
+    }
+    q->bound_scorer = scorer->serial;
+}
+
+int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* sc,
+              uint32_t flags, Plan* p) {
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = grid_for(db, (const void*)sw_scan_i32<kStripRows>, &cx->grid_i32);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &cx->grid_i16);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &cx->grid_f16);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
+    if (rc) return rc;
+    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = cx->grid_drift;
+    const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
+    p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
+    // bias of the maximum3-on-bit-patterns tiers: keeps diag+s, h-open, E-ext (and H~(0,-1) = B - ext in the drift frame) >= 0
+    p->bias = (uint32_t)std::max(std::max(-kPadScore, -sc->min_score), std::max(sc->open, 2 * sc->ext));
+    const uint64_t cap = 0x7BFF;     // largest int16 bit pattern that is a finite f16
+    const uint64_t m3_window = p->f16_arith ? 4096 : (p->bias < cap ? cap - p->bias : 0);
+    const bool m3_gaps = p->f16_arith ? (sc->open <= 2048 && sc->ext <= 2048) : gaps16;
+    const bool no_m3 = (flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16)) != 0;
+    const bool no_drift = no_m3 || p->f16_arith || (flags & S4G_SCAN_NO_DRIFT) != 0;
+
+    std::vector<uint32_t> ids[4];
+    auto add_pairs = [&](std::vector<uint32_t>& v, uint32_t* off, uint32_t* n) {
+        // pair queries of similar length (the pair runs to the longer one); longest pairs first
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
+        *off = (uint32_t)p->flat.size();
+        for (size_t i = 0; i < v.size(); i += 2) {
+            p->flat.push_back(v[i]);
+            p->flat.push_back(i + 1 < v.size() ? v[i + 1] : 0xFFFFFFFFu);
+        }
+        *n = (uint32_t)((v.size() + 1) / 2);
+    };
+    const uint32_t full = std::max(std::max(p->grid_i32, p->grid_i16), std::max(p->grid_m3, p->grid_drift));
+    for (const Tile& t : db->tiles) {
+        for (auto& v : ids) v.clear();
+        const uint64_t cols = (uint64_t)t.max_len4 * 4 + 8;
+        for (uint32_t i = 0; i < q_count; ++i) {
+            const uint32_t id = q_begin + i;
+            const uint64_t b = q->score_bound[id];
+            const uint64_t rows = (uint64_t)q->len[id] + 2 * kStripRows16;          // padded rows of the pair's strips
+            int tier;
+            if (!no_drift && gaps16 && b + p->bias + (rows + cols) * (uint64_t)sc->ext <= cap) tier = 0;
+            else if (!no_m3 && m3_gaps && b <= m3_window) tier = 1;
+            else if (!(flags & S4G_SCAN_FORCE_I32) && gaps16 && b <= 32767) tier = 2;
+            else tier = 3;
+            ids[tier].push_back(id);
+            p->n_by_tier[tier]++;
+        }
+        // Every tier is its own launch, and a launch can never finish before its largest item does (one wave walks the
+        // whole (query pair, group) DP).  With few queries the tiers' launches become short and tail-dominated, so
+        // fold a tier into the next slower one whenever the estimate says one launch beats two.  Units: VALU ops.
+        {
+            static const double ops[4] = {6.5, 7.5, 9.0, 15.0};     // per pair of cells (int32: two single-query items)
+            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double cols_sum = (double)t.padded_residues / 64.0;           // sum over groups of padded length
+            const double cols_max = (double)t.max_len4 * 4.0;
+            auto launch_time = [&](const std::vector<uint32_t>& v, int tier) -> double {
+                if (v.empty()) return 0.0;
+                double rows_sum = 0, rows_max = 0;
+                for (uint32_t id : v) { rows_sum += q->len[id]; rows_max = std::max<double>(rows_max, q->len[id]); }
+                if (tier < 3) rows_sum *= 0.5;                                   // two queries share an item
+                return ops[tier] * std::max(rows_sum * cols_sum / waves, rows_max * cols_max);
+            };
+            for (int tier = 0; tier < 3; ++tier) {
+                if (ids[tier].empty() || ids[tier + 1].empty()) continue;
+                std::vector<uint32_t> merged(ids[tier + 1]);
+                merged.insert(merged.end(), ids[tier].begin(), ids[tier].end());
+                if (launch_time(merged, tier + 1) <= launch_time(ids[tier], tier) + launch_time(ids[tier + 1], tier + 1)) {
+                    p->n_by_tier[tier] -= ids[tier].size();
+                    p->n_by_tier[tier + 1] += ids[tier].size();
+                    ids[tier + 1].swap(merged);
+                    ids[tier].clear();
+                }
+            }
+        }
+        TileWork w;
+        // critical-path items: larger than a quarter of the per-wave share of their launch (only then can unfair issue
+        // arbitration between co-resident waves stretch the launch)
+        for (int tier = 0; tier < 3; ++tier) {
+            if (ids[tier].empty()) continue;
+            double rows_sum = 0;
+            for (uint32_t id : ids[tier]) rows_sum += q->len[id];
+            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double share = 0.5 * rows_sum * ((double)t.padded_residues / 256.0) / waves;       // (rows * len4) per wave
+            w.prio_cost[tier] = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, share / 4.0));
+        }
+        add_pairs(ids[0], &w.off_drift, &w.n_drift);
+        add_pairs(ids[1], &w.off_m3, &w.n_m3);
+        add_pairs(ids[2], &w.off_pk, &w.n_pk);
+        w.off_wide = (uint32_t)p->flat.size(); w.n_wide = (uint32_t)ids[3].size();
+        p->flat.insert(p->flat.end(), ids[3].begin(), ids[3].end());
+        p->tiles.push_back(w);
+        // workspace: one slot per wave of the largest launch of this tile (grids are capped by the item count)
+        const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+        p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
+    }
+    return S4G_OK;
+}
+
+int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStream_t stream) {
+    DeviceCtx* cx = device_ctx(db->device);
+    if (cx->ws_bytes < p.ws_bytes) {
+        if (cx->d_ws) HIP_TRY(hipFree(cx->d_ws));
+        cx->d_ws = nullptr; cx->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_ws, p.ws_bytes));
+        cx->ws_bytes = p.ws_bytes;
+    }
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    const uint64_t need = p.flat.size();
+    if (cx->qlist_cap < need) {
+        if (cx->d_qlist) HIP_TRY(hipFree(cx->d_qlist));
+        cx->d_qlist = nullptr; cx->qlist_cap = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_qlist, need * 4));
+        cx->qlist_cap = need;
+    }
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
+    if (need) HIP_TRY(hipMemcpyAsync(cx->d_qlist, p.flat.data(), need * 4, hipMemcpyHostToDevice, stream));
+    return S4G_OK;
+}
+
+// One tile: one launch per non-empty tier.  perm/stride select the output layout: original ids into the caller's
+// [q][n_seqs] matrix, or tile columns.
+int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
+                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream, bool side = false) {
+    if (t.n_seqs == 0) return S4G_OK;
+    DeviceCtx* cx = device_ctx(db->device);
+    int32_t* const ws = side ? cx->d_ws_side : cx->d_ws;
+    unsigned* const counters = cx->d_counter + (side ? 8 : 0);
+    // a persistent grid larger than the number of items only launches blocks that exit at once
+    auto grid_of = [&](uint32_t full, uint64_t items) {
+        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), (items + kWavesPerBlock - 1) / kWavesPerBlock));
+    };
+    const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+    if ((uint64_t)t.n_groups * most >= 0xFFFFFFFFull)
+        return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
+    HIP_TRY(hipMemsetAsync(counters, 0, 16, stream));
+    ScanArgs16 a;
+    a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.mat = cx->d_mat;
+    a.scores = d_scores; a.score_stride = stride;
+    a.ws = ws; a.ws_slot = ws_slot_elems(t);
+    a.n_groups = t.n_groups; a.q_begin = q_begin;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    if (w.n_drift) {
+        a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
+        a.floor_bits = p.bias | (p.bias << 16);
+        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)t.n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (w.n_m3) {
+        a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2; a.prio_cost = w.prio_cost[1];
+        const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)t.n_groups * w.n_m3);
+        if (p.f16_arith) {
+            a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
+            hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
+        } else {
+            a.floor_bits = p.bias | (p.bias << 16);
+            hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (w.n_pk) {
+        a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
+        a.floor_bits = 0;
+        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)t.n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (w.n_wide) {
+        ScanArgs b;
+        b.db_res = t.d_res; b.grp_off = t.d_grp_off; b.grp_len4 = t.d_grp_len4; b.grp_perm = perm;
+        b.q_codes = q->d_codes; b.q_off = q->d_off; b.q_len = q->d_len;
+        b.mat = cx->d_mat;
+        b.scores = d_scores; b.score_stride = stride;
+        b.ws = ws; b.ws_slot = ws_slot_elems(t);
+        b.counter = counters + 1;
+        b.n_groups = t.n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
+        b.q_list = cx->d_qlist + w.off_wide;
+        b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)t.n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
+        HIP_TRY(hipGetLastError());
+    }
+    return S4G_OK;
+}
+
+// The scratch buffers (workspace, work-queue counter, query lists) are shared by all launches on this database:
+// a launch on another stream must not start before the previous one has finished with them.
+int scratch_acquire(const s4g_db* db, hipStream_t stream) {
+    DeviceCtx* cx = device_ctx(db->device);
+    if (!cx->last_use) HIP_TRY(hipEventCreateWithFlags(&cx->last_use, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
+    return S4G_OK;
+}
+int scratch_release(const s4g_db* db, hipStream_t stream) {
+    DeviceCtx* cx = device_ctx(db->device);
+    HIP_TRY(hipEventRecord(cx->last_use, stream));
+    return S4G_OK;
+}
+
+int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    return S4G_OK;
+}
+
+S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, char* kernel_name,
+                          size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
+                          uint32_t* strip_rows, uint64_t* workspace_bytes) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    ensure_bounds(q, scorer);
+    Plan p;
+    int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
+    if (rc) return rc;
+    // report the kernel that carries most of the queries
+    int top = 0;
+    for (int k = 1; k < 4; ++k) if (p.n_by_tier[k] > p.n_by_tier[top]) top = k;
+    const char* names[4] = {"sw_scan_pkd<32>", p.f16_arith ? "sw_scan_pk<ArithF16,32>" : "sw_scan_pk<ArithI16M3,32>", "sw_scan_pk<ArithI16,32>",
+                            "sw_scan_i32<32>"};
+    const uint32_t grids[4] = {p.grid_drift, p.grid_m3, p.grid_i16, p.grid_i32};
+    if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", names[top]);
+    if (grid_blocks) *grid_blocks = grids[top];
+    if (block_threads) *block_threads = kBlock;
+    if (strip_rows) *strip_rows = top == 3 ? kStripRows : kStripRows16;
+    if (workspace_bytes) *workspace_bytes = p.ws_bytes;
+    return S4G_OK;
+}
+
+S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                           const s4g_scorer* scorer, int32_t* d_scores, void* stream_, uint32_t flags) {
+    int rc = check_scan_args(db, q, scorer, q_begin, q_count);
+    if (rc) return rc;
+    if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
+    if (!d_scores) return fail(S4G_ERR_INVALID, "d_scores is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    {   // latency-bound call (few queries against a small database, the per-query alignDatabase pattern)?  Then every
+        // (query, target) pair gets a wave of its own instead of 64 targets sharing one: see scan_as_pairs.
+        bool as_pairs = false;
+        rc = scan_as_pairs(db, q, q_begin, q_count, scorer, d_scores, stream, flags, &as_pairs);
+        if (rc || as_pairs) return rc;
+    }
+    ensure_bounds(q, scorer);
+    Plan p;
+    rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
+    if (rc) return rc;
+    rc = scratch_acquire(db, stream);
+    if (rc) return rc;
+    rc = ensure_scratch(db, scorer, p, stream);
+    if (rc) return rc;
+    // long-sequence tiles first, on the side stream with their own workspace: their few huge items then run underneath
+    // the main tiles' launches instead of as a tail-dominated launch of their own
+    bool forked = false;
+    const uint32_t full = std::max(std::max(p.grid_i32, p.grid_i16), std::max(p.grid_m3, p.grid_drift));
+    if (db->tiles.size() > 1) {
+        uint64_t need = 0;
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
+            const TileWork& w = p.tiles[ti];
+            const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
+            const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+            need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
+        }
+        if (need) {
+            if (!cx->side_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+            }
+            if (cx->ws_side_bytes < need) {
+                if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
+                cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&cx->d_ws_side, need));
+                cx->ws_side_bytes = need;
+            }
+            HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
+            HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+            for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+                const Tile& t = db->tiles[ti];
+                if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true);
+                if (rc) return rc;
+            }
+            HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
+            forked = true;
+        }
+    }
+    for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+        const Tile& t = db->tiles[ti];
+        if (forked && (uint64_t)t.max_len4 * 4 > kLongSeq) continue;
+        rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
+        if (rc) return rc;
+    }
+    if (forked) HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
+    return scratch_release(db, stream);
+}
+
+S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                     const s4g_scorer* scorer, int32_t* d_scores, void* stream) {
+    return s4g_scan_flags(db, q, q_begin, q_count, scorer, d_scores, stream, 0);
+}
+
+S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                                const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags);
+
+S4G_API int s4g_scan_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                          const s4g_scorer* scorer, int32_t* h_scores) {
+    return s4g_scan_host_flags(db, q, q_begin, q_count, scorer, h_scores, 0);
+}
+
+S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
+                                const s4g_scorer* scorer, int32_t* h_scores, uint32_t flags) {
+    if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
+    if (!h_scores) return fail(S4G_ERR_INVALID, "h_scores is NULL");
+    DeviceGuard guard(db->device);
+    DevBuf<int32_t> d;
+    const size_t bytes = (size_t)q_count * db->n_seqs * 4;
+    HIP_TRY(d.alloc((size_t)q_count * db->n_seqs));
+    int rc = s4g_scan_flags(db, q, q_begin, q_count, scorer, d.p, nullptr, flags);
+    if (rc != S4G_OK) return rc;
+    HIP_TRY(hipMemcpy(h_scores, d.p, bytes, hipMemcpyDeviceToHost));
+    return S4G_OK;
+}
+
+// ---------------------------------------------------------------------------
+// top-k (steps 2-3 of alignDatabase on the device): one 256-thread block per query row.
+//   1. two-level radix select on the int32 score (high 12 bits of a 24-bit score, then low 12 bits) finds the cut
+//      score exactly: the k-th largest score >= min_score;
+//   2. everything above the cut is kept; among the ties AT the cut the smallest target ids are kept (ordered
+//      block scan), so the result is the exact, deterministic top-k under (score desc, id asc);
+//   3. bitonic sort of the <= k survivors in LDS on the 64-bit key (~score << 32 | id).
+
+constexpr int kTopkBlock = 256;
+constexpr int kBins = 4096;
+constexpr int kTopkMax = 4096;     // LDS: 4096 keys * 8 B = 32 KiB
+constexpr int kScoreCap = (1 << 24) - 1;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// finds, scanning bins from the top, the bin where the running count reaches `want`; returns bin (or -1) and the
+// count strictly above it.  Single-threaded over 4096 LDS words: ~4k cycles per row, negligible next to the scan.
+__device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned* above) {
+    unsigned acc = 0;
+    int b = kBins - 1;
+    for (; b >= 0; --b) {
+        if (acc + hist[b] >= want) break;
+        acc += hist[b];
+    }
+    *bin = b;
+    *above = acc;
+}
+
+__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k, uint32_t kpad,
+                                                        int32_t min_score, uint32_t* __restrict__ out_ids,
+                                                        int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                        const uint32_t* __restrict__ col_ids,
+                                                        const int32_t* __restrict__ row_min_scores) {
+    __shared__ unsigned hist[kBins];
+    __shared__ unsigned long long keys[kTopkMax];
+    __shared__ int s_hi, s_cut;
+    __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
+    const int tid = threadIdx.x;
+    const int32_t* row = scores + (uint64_t)blockIdx.x * n;
+    if (row_min_scores) min_score = row_min_scores[blockIdx.x];       // per-query cut (e-value driven)
+    if (min_score < 0) min_score = 0;
+
+    // ---- level 1: high 12 bits ----
+    for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kTopkBlock) {
+        const int v = row[i];
+        if (v >= min_score) atomicAdd(&hist[clampi(v, 0, kScoreCap) >> 12], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) { int b; unsigned a; find_bin(hist, k, &b, &a); s_hi = b; s_above = a; }
+    __syncthreads();
+    const int hi = s_hi;
+    if (hi < 0) {
+        // fewer than k entries pass min_score: keep them all
+        if (tid == 0) { s_cut = min_score; s_quota = 0xFFFFFFFFu; }
+    } else {
+        // ---- level 2: low 12 bits inside the high bin ----
+        const unsigned above_hi = s_above;
+        __syncthreads();
+        for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kTopkBlock) {
+            const int v = row[i];
+            if (v >= min_score && (clampi(v, 0, kScoreCap) >> 12) == hi) atomicAdd(&hist[clampi(v, 0, kScoreCap) & (kBins - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int b; unsigned a;
+            find_bin(hist, k - above_hi, &b, &a);
+            s_cut = (hi << 12) | b;                       // exact cut score (scores are < 2^24)
+            s_quota = k - (above_hi + a);                 // ties at the cut to keep (smallest ids)
+        }
+    }
+    if (tid == 0) { s_nout = 0; s_tie_base = 0; }
+    __syncthreads();
+    const int cut = s_cut;
+    const unsigned quota = s_quota;
+
+    // ---- compaction: > cut unordered, == cut in id order up to quota ----
+    for (uint32_t base = 0; base < n; base += kTopkBlock) {
+        const uint32_t i = base + tid;
+        const int v = i < n ? row[i] : -1;
+        const bool ok = i < n && v >= min_score;
+        const bool above = ok && (v > cut || quota == 0xFFFFFFFFu);
+        const bool tie = ok && !above && v == cut;
+        if (above) keys[atomicAdd(&s_nout, 1u)] = ((unsigned long long)(unsigned)(0x7FFFFFFF - v) << 32) | i;
+        const unsigned long long tb = __ballot(tie);
+        if ((tid & 63) == 0) s_wave_cnt[tid >> 6] = __popcll(tb);
+        __syncthreads();
+        unsigned rank = s_tie_base + __popcll(tb & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) rank += s_wave_cnt[w];
+        if (tie && rank < quota) keys[atomicAdd(&s_nout, 1u)] = ((unsigned long long)(unsigned)(0x7FFFFFFF - v) << 32) | i;
+        __syncthreads();
+        if (tid == 0) { unsigned t = 0; for (int w = 0; w < kTopkBlock / 64; ++w) t += s_wave_cnt[w]; s_tie_base += t; }
+        __syncthreads();
+    }
+    const unsigned m = s_nout;                             // <= k by construction
+    for (unsigned i = m + tid; i < kpad; i += kTopkBlock) keys[i] = ~0ull;
+    __syncthreads();
+    // ---- bitonic sort ascending on the key = score descending, id ascending ----
+    for (unsigned size = 2; size <= kpad; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < kpad / 2; t += kTopkBlock) {
+                const unsigned lo = 2 * t - (t & (stride - 1));
+                const unsigned hi2 = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a > b) == up) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (unsigned i = tid; i < k; i += kTopkBlock) {
+        const unsigned long long key = keys[i];
+        const bool valid = i < m;
+        out_ids[(uint64_t)blockIdx.x * k + i] = valid ? (col_ids ? col_ids[(uint32_t)key] : (uint32_t)key) : 0xFFFFFFFFu;
+        out_scores[(uint64_t)blockIdx.x * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+    }
+    if (tid == 0) out_counts[blockIdx.x] = m;
+}
+
+// running[q] <- best k of (running[q] U cand[q]) under (score desc, id asc); both inputs hold global ids.
+__global__ __launch_bounds__(kTopkBlock) void merge_rows(uint32_t* __restrict__ run_ids, int32_t* __restrict__ run_sc,
+                                                         uint32_t* __restrict__ run_cnt, const uint32_t* __restrict__ cand_ids,
+                                                         const int32_t* __restrict__ cand_sc, const uint32_t* __restrict__ cand_cnt,
+                                                         uint32_t k, uint32_t kpad2) {
+    __shared__ unsigned long long keys[2 * kTopkMax];
+    const int tid = threadIdx.x;
+    const uint64_t row = (uint64_t)blockIdx.x * k;
+    const unsigned na = run_cnt[blockIdx.x], nb = cand_cnt[blockIdx.x];
+    for (unsigned i = tid; i < kpad2; i += kTopkBlock) {
+        unsigned long long key = ~0ull;
+        if (i < na) key = ((unsigned long long)(unsigned)(0x7FFFFFFF - run_sc[row + i]) << 32) | run_ids[row + i];
+        else if (i - na < nb) key = ((unsigned long long)(unsigned)(0x7FFFFFFF - cand_sc[row + i - na]) << 32) | cand_ids[row + i - na];
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (unsigned size = 2; size <= kpad2; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < kpad2 / 2; t += kTopkBlock) {
+                const unsigned lo = 2 * t - (t & (stride - 1));
+                const unsigned hi2 = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a > b) == up) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned m = na + nb < k ? na + nb : k;
+    for (unsigned i = tid; i < k; i += kTopkBlock) {
+        const unsigned long long key = keys[i];
+        run_ids[row + i] = i < m ? (uint32_t)key : 0xFFFFFFFFu;
+        run_sc[row + i] = i < m ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+    }
+    __syncthreads();
+    if (tid == 0) run_cnt[blockIdx.x] = m;
+}
+
+
+S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+                     uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts, void* stream_) {
+    if (!db || !d_scores || !d_ids || !d_top_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (k == 0 || k > (uint32_t)kTopkMax) return fail(S4G_ERR_INVALID, "k must be in 1..%d (got %u)", kTopkMax, k);
+    if (q_count == 0) return S4G_OK;
+    DeviceGuard guard(db->device);
+    uint32_t kpad = 2;
+    while (kpad < k) kpad <<= 1;
+    hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, k, kpad,
+                       min_score, d_ids, d_top_scores, d_counts, (const uint32_t*)nullptr, (const int32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// Streaming scan + running top-k: the score matrix is never materialised.  For each batch of queries and each
+// database tile: scan into a [batch][tile columns] buffer, exact tile top-k (ids translated to original ids), merge
+// into the running per-query lists.  Tile columns are ordered by original id, so ties break by id exactly as in
+// s4g_topk on the full matrix.  This is the path for databases whose Q x N scores do not fit (BASELINE configs[3]).
+static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, const int32_t* d_min_scores, uint32_t* d_ids, int32_t* d_top_scores,
+                          uint32_t* d_counts, void* stream_, uint32_t flags);
+
+S4G_API int s4g_scan_topk(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, uint32_t* d_ids, int32_t* d_top_scores, uint32_t* d_counts,
+                          void* stream_, uint32_t flags) {
+    return scan_topk_impl(db, q, q_begin, q_count, scorer, k, min_score, nullptr, d_ids, d_top_scores, d_counts, stream_, flags);
+}
+
+// Same with one score cut per query (h_min_scores[q_count], host memory) and host outputs: the form the e-value driven
+// selection uses (a conservative integer score cut per query on the device, exact e-values on the survivors on the host).
+S4G_API int s4g_scan_topk_host(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                               uint32_t k, const int32_t* h_min_scores, uint32_t* h_ids, int32_t* h_top_scores, uint32_t* h_counts,
+                               uint32_t flags) {
+    if (!db || !q || !scorer || !h_ids || !h_top_scores || !h_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q_count == 0) return S4G_OK;
+    DeviceGuard guard(db->device);
+    DevBuf<uint32_t> d_ids, d_cnt;
+    DevBuf<int32_t> d_sc, d_min;
+    HIP_TRY(d_ids.alloc((size_t)q_count * k)); HIP_TRY(d_sc.alloc((size_t)q_count * k)); HIP_TRY(d_cnt.alloc(q_count));
+    if (h_min_scores) {
+        HIP_TRY(d_min.alloc(q_count));
+        HIP_TRY(hipMemcpy(d_min.p, h_min_scores, (size_t)q_count * 4, hipMemcpyHostToDevice));
+    }
+    int rc = scan_topk_impl(db, q, q_begin, q_count, scorer, k, 1, h_min_scores ? d_min.p : nullptr, d_ids.p, d_sc.p, d_cnt.p, nullptr, flags);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h_counts, d_cnt.p, (size_t)q_count * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_ids, d_ids.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_top_scores, d_sc.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost));
+    return S4G_OK;
+}
+
+static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                          uint32_t k, int32_t min_score, const int32_t* d_min_scores, uint32_t* d_ids, int32_t* d_top_scores,
+                          uint32_t* d_counts, void* stream_, uint32_t flags) {
+    int rc = check_scan_args(db, q, scorer, q_begin, q_count);
+    if (rc) return rc;
+    if (k == 0 || k > (uint32_t)kTopkMax) return fail(S4G_ERR_INVALID, "k must be in 1..%d (got %u)", kTopkMax, k);
+    if (q_count == 0) return S4G_OK;
+    if (!d_ids || !d_top_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    rc = scratch_acquire(db, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)q_count * k * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_top_scores, 0, (size_t)q_count * k * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)q_count * 4, stream));
+    if (db->n_seqs == 0) return scratch_release(db, stream);
+    ensure_bounds(q, scorer);
+    const uint64_t cols = db->max_tile_seqs;
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
+    const uint64_t need = (uint64_t)batch * cols * 4 + (uint64_t)batch * k * 8 + (uint64_t)batch * 4;
+    if (cx->tile_scores_bytes < need) {
+        if (cx->d_tile_scores) HIP_TRY(hipFree(cx->d_tile_scores));
+        cx->d_tile_scores = nullptr; cx->tile_scores_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_tile_scores, need));
+        cx->tile_scores_bytes = need;
+    }
+    int32_t* d_buf = cx->d_tile_scores;
+    uint32_t* c_ids = reinterpret_cast<uint32_t*>(d_buf + (uint64_t)batch * cols);
+    int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + (uint64_t)batch * k);
+    uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + (uint64_t)batch * k);
+    uint32_t kpad = 2, kpad2;
+    while (kpad < k) kpad <<= 1;
+    kpad2 = kpad * 2;
+    for (uint32_t b = 0; b < q_count; b += batch) {
+        const uint32_t cnt = std::min(batch, q_count - b);
+        if (b) HIP_TRY(hipStreamSynchronize(stream));   // the next batch rewrites the query lists the previous launches read
+        Plan p;
+        rc = make_plan(db, q, q_begin + b, cnt, scorer, flags, &p);
+        if (rc) return rc;
+        rc = ensure_scratch(db, scorer, p, stream);
+        if (rc) return rc;
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
+                               c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
+            hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
+                               d_top_scores + (uint64_t)b * k, d_counts + b, c_ids, c_sc, c_cnt, k, kpad2);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return scratch_release(db, stream);
+}
+
+S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,
+                          uint32_t* h_ids, int32_t* h_scores, uint32_t* h_counts, void* stream_) {
+    if (!db || !d_scores || !h_ids || !h_scores || !h_counts) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (q_count == 0) return S4G_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(db->device);
+    DevBuf<uint32_t> d_ids, d_counts;
+    DevBuf<int32_t> d_sc;
+    HIP_TRY(d_ids.alloc((size_t)q_count * k));
+    HIP_TRY(d_sc.alloc((size_t)q_count * k));
+    HIP_TRY(d_counts.alloc(q_count));
+    int rc = s4g_topk(db, d_scores, q_count, k, min_score, d_ids.p, d_sc.p, d_counts.p, stream_);
+    if (rc != S4G_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts.p, (size_t)q_count * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_ids, d_ids.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_scores, d_sc.p, (size_t)q_count * k * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return S4G_OK;
+}
+
