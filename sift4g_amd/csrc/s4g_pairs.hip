@@ -6,9 +6,16 @@
 // ---------------------------------------------------------------------------
 // Pair lists (the latency path, sw_pair.hip.h): explicit (query, target) pairs, one wave per pair.
 
-constexpr int kPairClasses = 6;
+constexpr int kPairClasses = 6;                 // row-block classes of sw_pair_scan / sw_pair_trace
 constexpr int kPairRpl[kPairClasses] = {2, 4, 6, 8, 12, 16};
-inline int pair_class(uint32_t lq) { int c = 0; while (64u * kPairRpl[c] < lq) ++c; return c; }
+constexpr int kScanClasses = kPairClasses + 1;  // + the banded kernel (sw_pair_scan_band) for queries beyond 1024 residues
+inline int pair_class(uint32_t lq) {
+    if (lq > (uint32_t)kPairMaxRows) return kPairClasses;
+    int c = 0;
+    while (64u * kPairRpl[c] < lq) ++c;
+    return c;
+}
+constexpr uint64_t kBandWsBudget = 4ull << 30;  // boundary workspace of the banded kernel (8 B per column and wave)
 // Measured rates (tools/pair_latency.py, profiles/r01_pair): cells per second a chip full of pair waves sustains and
 // the cells per second ONE wave makes on one pair, against the scan's chip rate and the cells per second of one
 // inter-sequence lane (which bounds a scan launch from below: one wave walks a whole (query pair, group) DP).
@@ -68,7 +75,7 @@ int pair_stage(DeviceCtx* cx, uint64_t n, PairItem** out) {
 
 // uploads the staged items (class-major: cls_begin[c] .. cls_begin[c+1]) and launches one kernel per class
 int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n, const uint32_t* cls_begin,
-                int32_t* d_scores, hipStream_t stream) {
+                int32_t* d_scores, hipStream_t stream, uint32_t max_lt_band) {
     DeviceCtx* cx = device_ctx(db->device);
     int rc = device_props(cx);
     if (rc) return rc;
@@ -81,8 +88,8 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(cx->d_items, cx->h_items, (size_t)n * sizeof(PairItem), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->items_done, stream));
-    HIP_TRY(hipMemsetAsync(cx->d_counter + 24, 0, kPairClasses * 4, stream));
-    for (int c = 0; c < kPairClasses; ++c) {
+    HIP_TRY(hipMemsetAsync(cx->d_counter + 24, 0, kScanClasses * 4, stream));
+    for (int c = 0; c < kScanClasses; ++c) {
         const uint32_t b = cls_begin[c], e = cls_begin[c + 1];
         if (b == e) continue;
         PairArgs a;
@@ -90,6 +97,26 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
         a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
         a.scores = d_scores; a.counter = cx->d_counter + 24 + c; a.n_pairs = e - b;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        if (c == kPairClasses) {        // banded kernel: per-wave boundary workspace sized by the launch's longest target
+            if (cx->grid_pair_band == 0) {
+                int per_cu = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan_band<16>, 64, 0));
+                cx->grid_pair_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+            }
+            const uint64_t slot = ((uint64_t)std::max(1u, max_lt_band) + 63) / 64 * 64;
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(cx->grid_pair_band, a.n_pairs), kBandWsBudget / (slot * 8)));
+            if (cx->band_ws_bytes < slot * 8 * grid) {
+                if (cx->d_band_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_band_ws)); }
+                cx->d_band_ws = nullptr; cx->band_ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&cx->d_band_ws, slot * 8 * grid));
+                cx->band_ws_bytes = slot * 8 * grid;
+            }
+            PairBandArgs ba;
+            ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
+            hipLaunchKernelGGL(sw_pair_scan_band<16>, dim3(grid), dim3(64), 0, stream, ba);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         switch (c) {
             case 0: rc = launch_pairs<2>(cx, a, &cx->grid_pair[0], stream); break;
             case 1: rc = launch_pairs<4>(cx, a, &cx->grid_pair[1], stream); break;
@@ -103,7 +130,7 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     return scratch_release(db, stream);
 }
 
-// Explicit list -> host scores.  sel = indices into pair_q / pair_t whose queries have <= kPairMaxRows residues.
+// Explicit list -> host scores.  sel = indices into pair_q / pair_t.
 // Order inside a class: longest target first at 32-residue granularity (counting sort; a launch cannot end before its
 // longest pair does, so that one must not start last).
 int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
@@ -121,15 +148,19 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     if (rc) return rc;
     constexpr uint32_t kBuckets = 2048;
     static thread_local std::vector<uint32_t> count;
-    count.assign((size_t)kPairClasses * kBuckets + 1, 0);
+    count.assign((size_t)kScanClasses * kBuckets + 1, 0);
+    uint32_t max_lt_band = 0;
     auto key_of = [&](uint32_t pi) {
         const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
         return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
     };
-    for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
+    for (uint32_t i = 0; i < n; ++i) {
+        ++count[key_of(sel[i]) + 1];
+        if (pair_class(q->len[pair_q[sel[i]]]) == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[sel[i]]]);
+    }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
-    uint32_t cls_begin[kPairClasses + 1];
-    for (int c = 0; c <= kPairClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    uint32_t cls_begin[kScanClasses + 1];
+    for (int c = 0; c <= kScanClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t pi = sel[i];
         const uint32_t at = count[key_of(pi)]++;
@@ -138,8 +169,7 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
     auto t1 = now();
     int32_t* d_sc = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
-    rc = pair_submit(db, q, scorer, n, cls_begin, d_sc, stream);
-    if (rc) return rc;
+    rc = pair_submit(db, q, scorer, n, cls_begin, d_sc, stream, max_lt_band);
     auto t2 = now();
     static thread_local std::vector<int32_t> sc;
     sc.resize(n);
@@ -156,7 +186,7 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
 
 // s4g_scan's latency route: the whole [q_count][n_seqs] matrix as pairs (caller holds cx->mu).  Taken when the estimate
 // says the inter-sequence launch would wait on its longest item for longer than a chip full of pair waves needs for
-// everything; never for queries beyond kPairMaxRows or when a kernel was forced by flags.
+// everything; never when a kernel was forced by flags.
 int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done) {
     *done = false;
@@ -166,7 +196,6 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
     uint32_t lq_max = 0, max_t = 0;
     uint64_t rows = 0;
     for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
-    if (lq_max > (uint32_t)kPairMaxRows) return S4G_OK;
     for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
     const double cells = (double)rows * (double)db->residues, longest = (double)lq_max * max_t;
     const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
@@ -179,10 +208,10 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
     rc = pair_stage(cx, n_items, &items);
     if (rc) return rc;
     // class-major; inside a class the targets in length-sorted order (longest first), queries innermost
-    uint32_t cls_begin[kPairClasses + 1];
+    uint32_t cls_begin[kScanClasses + 1];
     uint32_t at = 0;
     std::vector<uint32_t> qs;
-    for (int c = 0; c < kPairClasses; ++c) {
+    for (int c = 0; c < kScanClasses; ++c) {
         cls_begin[c] = at;
         qs.clear();
         for (uint32_t i = 0; i < q_count; ++i) if (pair_class(q->len[q_begin + i]) == c) qs.push_back(i);
@@ -192,8 +221,8 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
             for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * db->n_seqs + id)};
         }
     }
-    cls_begin[kPairClasses] = at;
-    rc = pair_submit(db, q, scorer, at, cls_begin, d_scores, stream);
+    cls_begin[kScanClasses] = at;
+    rc = pair_submit(db, q, scorer, at, cls_begin, d_scores, stream, max_t);
     if (rc) return rc;
     *done = true;
     return S4G_OK;
@@ -210,7 +239,7 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
     if ((flags & S4G_PAIRS_FORCE_SCAN) && (flags & S4G_PAIRS_FORCE_WAVE)) return fail(S4G_ERR_INVALID, "contradictory flags");
     for (uint64_t i = 0; i < n_pairs; ++i)
         if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)i);
-    // Two exact routes.  "wave": one wave per pair (sw_pair_scan), for queries of up to kPairMaxRows residues.
+    // Two exact routes.  "wave": one wave per pair (sw_pair_scan; sw_pair_scan_band beyond 1024 query residues).
     // "scan": score the pair's query against the whole resident database and pick the column.  Per query the cheaper
     // estimate wins: few candidates -> wave, candidate list ~ the whole database -> scan.
     std::vector<std::vector<uint32_t>> by_q(q->n);
@@ -222,7 +251,7 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
         if (by_q[qi].empty()) continue;
         const uint32_t lq = q->len[qi];
         if (lq == 0) { for (uint32_t i : by_q[qi]) h_scores[i] = 0; continue; }
-        bool wave = lq <= (uint32_t)kPairMaxRows;
+        bool wave = true;
         if (wave && !(flags & S4G_PAIRS_FORCE_WAVE)) {
             double cells = 0, longest = 0;
             for (uint32_t i : by_q[qi]) { const double c = (double)lq * db->len[pair_t[i]]; cells += c; longest = std::max(longest, c); }
@@ -232,8 +261,6 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
             wave = t_wave <= t_scan;
         }
         if (flags & S4G_PAIRS_FORCE_SCAN) wave = false;
-        if (!wave && (flags & S4G_PAIRS_FORCE_WAVE))
-            return fail(S4G_ERR_INVALID, "query %u has %u residues; the pair kernel takes at most %d", qi, lq, kPairMaxRows);
         if (wave) {
             wave_sel.insert(wave_sel.end(), by_q[qi].begin(), by_q[qi].end());
         } else scan_queries.push_back(qi);

@@ -570,18 +570,14 @@ def test_pairs_random_lists_all_codes(s4g, oracle_mod, blosum62, scorer):
 
 def test_pairs_target_windows_and_long_queries(s4g, oracle_mod, blosum62, scorer):
     """targets longer than the LDS window of the pair kernels (kPairWindow columns: several windows, lengths on both sides
-    of the boundaries, odd step counts); queries beyond 1024 residues take the scan route inside the same call."""
+    of the boundaries, odd step counts); queries beyond 1024 residues run band by band (sw_pair_scan_band)."""
     rng = np.random.default_rng(33)
     qs = [rand_seqs(rng, 1, l, l)[0] for l in (97, 350, 640, 1024, 1025, 2300)]
     ts = [rand_seqs(rng, 1, l, l)[0] for l in (4095, 4096, 4097, 8191, 8200, 12289, 13001, 40, 1, 1985, 2047, 2048, 2049, 2112)]
     ts[4][100:450] = qs[1]                                   # a real hit deep inside the second window
     ts[6][8100:8740] = qs[2]
     pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
-    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), scorer, routes=(None, "scan"))
-    short = pq.ravel() < 4
-    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel()[short], pt.ravel()[short], scorer, routes=("wave",))
-    with pytest.raises(RuntimeError):
-        s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [5], [0], route="wave")
+    _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), scorer, routes=(None, "scan", "wave"))
 
 
 def test_pairs_empty_sequences_and_other_scorers(s4g, oracle_mod, blosum62, scorer):
@@ -749,3 +745,27 @@ def test_database_from_device_resident_codes(s4g, oracle_mod, blosum62, scorer):
         s4g.Database.from_device(bad, torch.tensor([0, 10], dtype=torch.int64, device="cuda:0"))
     with pytest.raises(ValueError):
         s4g.Database.from_device(bad.cpu(), torch.tensor([0, 10], dtype=torch.int64))
+
+
+def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
+    """sw_pair_scan_band: queries of 1025 .. 5000 residues (2 to 5 bands of 1024 rows, partial last bands of 1 row and of
+    1023 rows), alignments that cross band boundaries, targets across window boundaries, three scorers, and the scan
+    entry point choosing the pair route for a long query on its own."""
+    rng = np.random.default_rng(39)
+    qlens = [1025, 1026, 2047, 2048, 2049, 3000, 3073, 4096, 5000]
+    qs = [rand_seqs(rng, 1, l, l, 26)[0] for l in qlens]
+    ts = rand_seqs(rng, 60, 1, 900, 26) + [rand_seqs(rng, 1, l, l, 26)[0] for l in (2047, 2049, 4100, 6000)]
+    for k, src in enumerate(qs):                               # homologs of a stretch straddling the first band boundary
+        piece = src[700:1500].copy()
+        piece[rng.integers(0, len(piece), size=60)] = rng.integers(0, 20, size=60)
+        ts[k] = np.concatenate([rand_seqs(rng, 1, 40, 40)[0], piece[:390], piece[400:], rand_seqs(rng, 1, 25, 25)[0]])
+    ts[20] = qs[5].copy()                                      # a whole 3000-residue query as a target: path through 3 bands
+    ts[21] = np.concatenate([qs[8][:2500], qs[8][2510:]])
+    pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    for go, ge in ((10, 1), (2, 2), (30, 3)):
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq.ravel(), pt.ravel(), sc, go, ge, routes=("wave", None))
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=5, q_count=1), exp[5:6])       # pair route, banded
+    assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), exp)
