@@ -153,9 +153,10 @@ int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t*
  * (/root/reference/sift4g/src/database_alignment.cpp:83-86 with `indexes` = that query's candidates):
  * every pair gets a wave of its own (anti-diagonal sweep, sw_pair.hip.h) instead of sharing a wave with 63
  * length-sorted neighbours, so a call is bounded by ~0.7 cycles per cell of its longest pair rather than ~26.
- * Queries longer than 1024 residues, and candidate lists that approach the whole database, are served exactly by
- * scanning the resident database and picking the columns; flags force one route (tests, measurements). */
-#define S4G_PAIRS_FORCE_WAVE 1u  /* one wave per pair; error if a query exceeds 1024 residues */
+ * Queries beyond 1024 residues run band by band (1024 rows per band, the boundary row through HBM).  Candidate
+ * lists that approach the whole database are served exactly by scanning the resident database and picking the
+ * columns; flags force one route (tests, measurements). */
+#define S4G_PAIRS_FORCE_WAVE 1u  /* one wave per pair */
 #define S4G_PAIRS_FORCE_SCAN 2u  /* full scan + column pick */
 int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint64_t n_pairs,
                          const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, uint32_t flags);

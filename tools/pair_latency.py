@@ -2,7 +2,7 @@
 """Latency of the per-query candidate-list call (sift4g's alignDatabase pattern): one query, a few thousand candidates
 scattered over the resident database.  Compares the two exact routes of s4g_score_pairs_host: one wave per pair
 (sw_pair_scan) vs scanning the whole database and picking the columns.
-usage: tools/pair_latency.py [n_targets] [n_candidates] [n_queries]"""
+usage: tools/pair_latency.py [n_targets] [n_candidates] [n_queries] [query_length (default: the configs[1] generator, 300-400)]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,9 @@ nc = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 c = synth.make_config(2, nq, nt)
 qs = [c["q_codes"][c["q_off"][i]:c["q_off"][i + 1]] for i in range(nq)]
+if len(sys.argv) > 4:                      # long queries: random residues of the given length
+    qlen = int(sys.argv[4])
+    qs = [np.random.default_rng(100 + i).integers(0, 20, size=qlen).astype(np.uint8) for i in range(nq)]
 ts = [c["t_codes"][c["t_off"][i]:c["t_off"][i + 1]] for i in range(nt)]
 scorer = s4g.Scorer("BLOSUM_62", 10, 1)
 db = s4g.Database(ts)
