@@ -194,9 +194,9 @@ int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, u
 int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
                        const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                        int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);
-/* Same with a forced route: S4G_PAIRS_FORCE_WAVE = one wave per pair (sw_pair_trace, queries of <= 1024 residues),
- * S4G_PAIRS_FORCE_SCAN = the 64-pairs-per-wave strip kernels (sw_trace_fill + sw_trace_walk).  0 = per pair by query
- * length, which is what s4g_traceback_host does. */
+/* Same with a forced route: S4G_PAIRS_FORCE_SCAN = the 64-pairs-per-wave strip kernels (sw_trace_fill +
+ * sw_trace_walk); 0 or S4G_PAIRS_FORCE_WAVE = one wave per pair (sw_pair_trace, band by band beyond 1024 query
+ * residues), which is what s4g_traceback_host does. */
 int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
                              const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                              int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths, uint32_t flags);

@@ -105,7 +105,7 @@ struct DeviceCtx {
     uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
     uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t grid_pair_band = 0;
+    uint32_t grid_pair_band = 0, grid_pair_trace_band = 0;
     char* d_band_ws = nullptr;          // boundary rows of sw_pair_scan_band, one slot per wave
     uint64_t band_ws_bytes = 0;
     // pair lists: pinned staging for the items of the current call, their device copy (+ host-route scores behind it)

@@ -320,7 +320,7 @@ int launch_pair_trace(DeviceCtx* cx, PairTraceArgs a, uint32_t* grid_cache, hipS
     return S4G_OK;
 }
 
-// Traceback with one wave per pair (sw_pair_trace): `sel` = indices of the pairs whose query has <= kPairMaxRows residues.
+// Traceback with one wave per pair (sw_pair_trace; sw_pair_trace_band beyond 1024 query residues): `sel` = pair indices.
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
@@ -339,18 +339,22 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     // class-major, longest target first (32-residue granularity), as in score_pairs_device
     const uint32_t n = (uint32_t)sel.size();
     constexpr uint32_t kBuckets = 2048;
-    std::vector<uint32_t> count((size_t)kPairClasses * kBuckets + 1, 0), order(n);
+    std::vector<uint32_t> count((size_t)kScanClasses * kBuckets + 1, 0), order(n);
     auto key_of = [&](uint32_t pi) {
         const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
         return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
     };
     for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
-    uint32_t cls_begin[kPairClasses + 1];
-    for (int c = 0; c <= kPairClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    uint32_t cls_begin[kScanClasses + 1];
+    for (int c = 0; c <= kScanClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
     for (uint32_t i = 0; i < n; ++i) order[count[key_of(sel[i])]++] = sel[i];
     auto dir_bytes = [&](uint32_t pi) {
         const int c = pair_class(q->len[pair_q[pi]]);
+        if (c == kPairClasses) {        // banded: every band has the block of a full band of sw_pair_trace<16>
+            const uint64_t nbands = ((uint64_t)q->len[pair_q[pi]] + kPairMaxRows - 1) / kPairMaxRows;
+            return nbands * ((((uint64_t)db->len[pair_t[pi]] + 63) + 1) & ~1ull) * 64 * 16;
+        }
         const uint32_t rpl = (uint32_t)kPairRpl[c], nw = rpl <= 4 ? 1 : (rpl <= 8 ? 2 : 4);
         const uint64_t steps = (uint64_t)db->len[pair_t[pi]] + (q->len[pair_q[pi]] + rpl - 1) / rpl - 1;
         return ((steps + 1) & ~1ull) * 64 * nw * 4;
@@ -365,9 +369,11 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         while (cls_begin[c + 1] <= b0) ++c;
         uint32_t b1 = b0;
         uint64_t dir_total = 0, path_total = 0;
+        uint32_t max_lt = 0;
         items.clear();
         while (b1 < cls_begin[c + 1] && (b1 == b0 || dir_total + dir_bytes(order[b1]) <= dir_budget)) {
             const uint32_t pi = order[b1];
+            max_lt = std::max(max_lt, db->len[pair_t[pi]]);
             const uint64_t cap = (uint64_t)q->len[pair_q[pi]] + db->len[pair_t[pi]];
             path_total += cap;
             items.push_back({pair_q[pi], pair_t[pi], pair_score[pi], b1 - b0, dir_total, path_total});
@@ -398,6 +404,25 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
         a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
         a.counter = cx->d_counter + 32; a.n_pairs = ni; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        if (c == kPairClasses) {
+            if (cx->grid_pair_trace_band == 0) {
+                int per_cu = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace_band<16>, 64, 0));
+                cx->grid_pair_trace_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+            }
+            const uint64_t slot = ((uint64_t)std::max(1u, max_lt) + 63) / 64 * 64;
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(cx->grid_pair_trace_band, ni), kBandWsBudget / (slot * 8)));
+            if (cx->band_ws_bytes < slot * 8 * grid) {
+                if (cx->d_band_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_band_ws)); }
+                cx->d_band_ws = nullptr; cx->band_ws_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&cx->d_band_ws, slot * 8 * grid));
+                cx->band_ws_bytes = slot * 8 * grid;
+            }
+            PairTraceBandArgs ba;
+            ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
+            hipLaunchKernelGGL(sw_pair_trace_band<16>, dim3(grid), dim3(64), 0, stream, ba);
+            HIP_TRY(hipGetLastError());
+        } else
         switch (c) {
             case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
             case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;

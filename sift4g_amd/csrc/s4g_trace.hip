@@ -23,40 +23,12 @@ S4G_API int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, con
         if (path_off[i + 1] - path_off[i] < (uint64_t)q->len[pair_q[i]] + db->len[pair_t[i]])
             return fail(S4G_ERR_INVALID, "pair %u: path capacity must be at least query length + target length", i);
     }
-    // one wave per pair (sw_pair_trace) for queries of up to kPairMaxRows residues; the 64-pairs-per-wave strip kernels
-    // (sw_trace_fill + sw_trace_walk) for the rest
-    std::vector<uint32_t> wave_sel, group_sel;
-    for (uint32_t i = 0; i < n_pairs; ++i) {
-        const bool wave = !(flags & S4G_PAIRS_FORCE_SCAN) && q->len[pair_q[i]] <= (uint32_t)kPairMaxRows;
-        if (!wave && (flags & S4G_PAIRS_FORCE_WAVE))
-            return fail(S4G_ERR_INVALID, "pair %u: query of %u residues; the pair kernel takes at most %d", i, q->len[pair_q[i]], kPairMaxRows);
-        (wave ? wave_sel : group_sel).push_back(i);
-    }
-    if (!wave_sel.empty()) {
-        int rc = traceback_pairs(db, q, scorer, wave_sel, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
-        if (rc) return rc;
-    }
-    if (group_sel.empty()) return S4G_OK;
-    if (group_sel.size() == n_pairs) return traceback_groups(db, q, scorer, n_pairs, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
-    // mixed call: compact the remaining pairs, run them, scatter the results
-    const uint32_t m = (uint32_t)group_sel.size();
-    std::vector<uint32_t> gq(m), gt(m);
-    std::vector<int32_t> gs(m), gout((size_t)m * 5);
-    std::vector<uint64_t> goff(m + 1, 0);
-    for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t i = group_sel[k];
-        gq[k] = pair_q[i]; gt[k] = pair_t[i]; gs[k] = pair_score[i];
-        goff[k + 1] = goff[k] + (path_off[i + 1] - path_off[i]);
-    }
-    std::vector<uint8_t> gpaths(goff[m] ? goff[m] : 1);
-    int rc = traceback_groups(db, q, scorer, m, gq.data(), gt.data(), gs.data(), gout.data(), goff.data(), gpaths.data());
-    if (rc) return rc;
-    for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t i = group_sel[k];
-        memcpy(h_out + (size_t)i * 5, gout.data() + (size_t)k * 5, 20);
-        memcpy(h_paths + path_off[i], gpaths.data() + goff[k], (size_t)gout[(size_t)k * 5 + 4]);
-    }
-    return S4G_OK;
+    // one wave per pair (sw_pair_trace, banded beyond 1024 query residues) unless the strip kernels are forced
+    // (sw_trace_fill + sw_trace_walk, 64 pairs per wave: the throughput form, kept as an independent implementation)
+    if (flags & S4G_PAIRS_FORCE_SCAN) return traceback_groups(db, q, scorer, n_pairs, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
+    std::vector<uint32_t> all(n_pairs);
+    std::iota(all.begin(), all.end(), 0u);
+    return traceback_pairs(db, q, scorer, all, pair_q, pair_t, pair_score, h_out, path_off, h_paths);
 }
 
 S4G_API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,

@@ -214,8 +214,8 @@ __global__ __launch_bounds__(64) void sw_pair_scan(const PairArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // Queries beyond 64 * 16 rows: the same sweep band by band.  A band is 1024 query rows (16 per lane); its last row's
 // H and F (the F the row below receives) go to a per-wave workspace in HBM, one (H, F) pair per target column, and
-// the next band shifts them in at lane 0 instead of zeros.  8 bytes written and read per column and band -- 1/1024 of
-// a byte per cell.  Lane 63 writes its pair each step (column k - 63); a window of the boundary is staged in LDS
+// the next band shifts them in at lane 0 instead of zeros.  8 bytes written and read per column and band -- 1/128
+// byte per cell.  Lane 63 writes its pair each step (column k - 63); a window of the boundary is staged in LDS
 // next to the target window and read as a wave-uniform (broadcast) address, pipelined one step ahead like the scores.
 struct PairBandArgs {
     PairArgs p;
@@ -538,6 +538,205 @@ __global__ __launch_bounds__(64) void sw_pair_trace(const PairTraceArgs a) {
                     } else {
                         *(pe - 1 - n) = 3; ++n;                                      // MOVE_UP
                         if (b & 8u) state = 0;
+                        --i;
+                    }
+                }
+                out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Traceback for queries beyond 64 * 16 rows: sw_pair_trace band by band, boundary row through HBM as in
+// sw_pair_scan_band (F travels with its "opened here" bit).  The direction block of band b starts
+// b * band_steps * 1024 bytes into the pair's block, band_steps = (lt + 63) rounded up to even; inside a band the
+// layout is that of sw_pair_trace<16>.
+struct PairTraceBandArgs {
+    PairTraceArgs p;
+    int2* __restrict__ band_ws;
+    uint64_t band_ws_slot;
+};
+
+template <int RPL>
+__global__ __launch_bounds__(64) void sw_pair_trace_band(const PairTraceBandArgs b) {
+    static_assert(RPL == 16, "a band is 64 lanes x 16 rows");
+    constexpr int NW = 4, BAND = 64 * RPL;
+    constexpr int W = kPairWindow;
+    typedef v4i vnw;
+    const PairTraceArgs& a = b.p;
+    __shared__ __attribute__((aligned(16))) char lds[1024 + 32 * 64 * NW * 4 + W + 192 + (W + 64) * 8];
+    const int lane = threadIdx.x;
+    const int* lmat4 = reinterpret_cast<const int*>(lds);
+    char* prof = lds + 1024;
+    char* stage = prof + 32 * 64 * NW * 4;
+    int2* bnd = reinterpret_cast<int2*>(stage + W + 192);
+    for (int i = lane; i < 256; i += 64) reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __builtin_amdgcn_wave_barrier();
+    const unsigned open = a.open, ext = a.ext;
+    int2* ws = b.band_ws + (uint64_t)blockIdx.x * b.band_ws_slot;
+
+    auto next_item = [&]() -> unsigned {        // canonical loop shape, see sw_pair_scan_band
+        unsigned it = 0;
+        if (lane == 0) it = atomicAdd(a.counter, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+    };
+    for (unsigned item = next_item(); item < a.n_pairs; item = next_item()) {
+        const PairTraceItem it = a.items[item];
+        const unsigned q = it.q;
+        const unsigned lq = a.q_len[q];
+        const unsigned lt = a.seq_len[it.t];
+        const int want = it.score;
+        int32_t* out = a.out5 + (uint64_t)it.slot * 5;
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(a.seq_addr[it.t]);
+        const int len4 = (int)((lt + 3) / 4);
+        const unsigned nbands = (lt && want > 0) ? (lq + BAND - 1) / BAND : 0;       // nothing to trace: no band
+        const uint64_t band_bytes = (uint64_t)(((lt + 63) + 1) & ~1u) * 64 * (NW * 4);
+        int best = 0;
+        unsigned key = 0xFFFFFFFFu;
+        const char* prof_lane = prof + lane * (NW * 4);
+
+        for (unsigned band = 0; band < nbands; ++band) {
+            const unsigned row0 = band * BAND;
+            const unsigned rows = lq - row0 < (unsigned)BAND ? lq - row0 : (unsigned)BAND;
+            const bool last_band = band + 1 == nbands;
+            pair_build_profile<RPL, NW>(prof, lmat4, a.q_codes + a.q_off[q] + row0, rows, lane);
+            if (band) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            const unsigned lanes_used = (rows + RPL - 1) / RPL;
+            const unsigned nsteps = lt + lanes_used - 1;
+            int H[RPL];
+            unsigned E[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
+            int hu_prev = 0;
+            unsigned f_out = 0;
+            unsigned eopen = 0;
+            vnw* dst = reinterpret_cast<vnw*>(a.dirs + it.dir_off + band * band_bytes) + lane;
+            unsigned cell0 = ((row0 + (unsigned)(lane * RPL)) << 16) - (unsigned)lane;
+            auto step = [&](const vnw& sc, const int2 top) {
+                const int hu = __builtin_amdgcn_update_dpp(top.x, H[RPL - 1], 0x138, 0xf, 0xf, false);
+                const unsigned fin = (unsigned)__builtin_amdgcn_update_dpp(top.y, (int)f_out, 0x138, 0xf, 0xf, false);
+                unsigned F = fin & 0x7FFFFFFFu;
+                unsigned fopen = fin >> 31;
+                int d[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int w = pk_get(sc, r / 4);
+                    const int s = (int)(signed char)(w >> (8 * (r % 4)));
+                    d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
+                }
+                int D[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) D[w] = 0;
+                unsigned eopen_next = 0;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int h = imax(imax(d[r], (int)E[r]), (int)F);
+                    const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (h == (int)F ? 2u : 3u));
+                    D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
+                    if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
+                    best = imax(best, h);
+                    const unsigned hm = usub_sat((unsigned)h, open);
+                    const unsigned En = umax_s(usub_sat(E[r], ext), hm);
+                    const unsigned Fn = umax_s(usub_sat(F, ext), hm);
+                    eopen_next |= (En == hm ? 1u : 0u) << r;
+                    fopen = (Fn == hm) ? 1u : 0u;
+                    E[r] = En;
+                    F = Fn;
+                    H[r] = h;
+                }
+                eopen = eopen_next;
+                f_out = F | (fopen << 31);
+                hu_prev = hu;
+                vnw Dv;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
+                *dst = Dv;
+                dst += 64;
+                ++cell0;
+            };
+
+            for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
+                const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
+                pair_stage_window(stage, res, len4, w0, kend, lane);
+                for (unsigned e = lane; e < kend - w0 + 3; e += 64) {
+                    int2 v = {0, 0};
+                    if (band && w0 + e < lt) v = ws[w0 + e];
+                    bnd[e] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned char* sa = reinterpret_cast<const unsigned char*>(stage) + 64 - lane;
+                const int2* ba = bnd;
+                unsigned tB = sa[0];
+                vnw scA = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+                int2 topA = ba[0];
+                tB = sa[1];
+                pin(tB);
+                pin(scA);
+                pin(topA.x); pin(topA.y);
+                for (unsigned k = w0; k < kend; k += 2) {
+                    vnw scB = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+                    unsigned tC = sa[2];
+                    int2 topB = ba[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(scA, topA);
+                    if (!last_band && lane == 63 && k >= 63 && k - 63 < lt) ws[k - 63] = int2{H[RPL - 1], (int)f_out};
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin(tC);
+                    pin(scB);
+                    pin(topB.x); pin(topB.y);
+                    scA = *reinterpret_cast<const vnw*>(prof_lane + tC * (64 * NW * 4));
+                    tB = sa[3];
+                    topA = ba[2];
+                    sa += 2;
+                    ba += 2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(scB, topB);
+                    if (!last_band && lane == 63 && k + 1 >= 63 && k + 1 - 63 < lt) ws[k + 1 - 63] = int2{H[RPL - 1], (int)f_out};
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin(tB);
+                    pin(scA);
+                    pin(topA.x); pin(topA.y);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            best = imax(best, __shfl_xor(best, off, 64));
+            const unsigned other = (unsigned)__shfl_xor((int)key, off, 64);
+            key = other < key ? other : key;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) {
+            a.best[it.slot] = best;
+            if (key == 0xFFFFFFFFu) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; }
+            else {
+                const uint8_t* dirs = a.dirs + it.dir_off;
+                uint8_t* pe = a.paths + it.path_end;
+                int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
+                const int ei = i, ej = j;
+                unsigned n = 0, state = 0;
+                const unsigned cap = lq + lt;
+                while (i >= 0 && j >= 0 && n < cap) {
+                    const unsigned bd = (unsigned)i / BAND, ib = (unsigned)i % BAND;
+                    const unsigned l = ib / RPL, r = ib % RPL;
+                    const unsigned c = dirs[bd * band_bytes + ((uint64_t)((unsigned)j + l) * 64 + l) * (NW * 4) + r];
+                    if (state == 0) {
+                        const unsigned src = c & 3u;
+                        if (src == 0u) break;
+                        if (src == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }
+                        else state = (src == 2u) ? 2u : 1u;
+                    } else if (state == 1) {
+                        *(pe - 1 - n) = 2; ++n;
+                        if (c & 4u) state = 0;
+                        --j;
+                    } else {
+                        *(pe - 1 - n) = 3; ++n;
+                        if (c & 8u) state = 0;
                         --i;
                     }
                 }

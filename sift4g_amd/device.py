@@ -266,7 +266,7 @@ def topk(db, scores, k, min_score=1, stream=None):
 def traceback(db, queries, scorer, pair_q, pair_t, pair_score, route=None):
     """Device traceback of (query, target) pairs with known scores -> list of dicts(score, q_start, q_end, t_start, t_end, path)
     (path: uint8 array of swsharp move codes 1 DIAG / 2 LEFT / 3 UP, start to end).
-    route = None (one wave per pair for queries up to 1024 residues, strip kernels beyond) | "wave" | "scan" (strip kernels)."""
+    route = None / "wave" (one wave per pair) | "scan" (the 64-pairs-per-wave strip kernels)."""
     pair_q = np.ascontiguousarray(pair_q, dtype=np.uint32)
     pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
     pair_score = np.ascontiguousarray(pair_score, dtype=np.int32)

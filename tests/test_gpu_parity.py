@@ -598,8 +598,8 @@ def test_pairs_empty_sequences_and_other_scorers(s4g, oracle_mod, blosum62, scor
 
 
 def test_pair_traceback_row_block_classes_windows_and_mixed_routes(s4g, oracle_mod, blosum62, scorer):
-    """sw_pair_trace over every rows-per-lane class, targets beyond one 4096-column window, gap-rich alignments; queries
-    beyond 1024 residues in the same call fall to the strip kernels."""
+    """sw_pair_trace over every rows-per-lane class, targets beyond one LDS window, gap-rich alignments; queries beyond
+    1024 residues in the same call run band by band (sw_pair_trace_band)."""
     rng = np.random.default_rng(35)
     qlens = [1, 2, 64, 65, 128, 129, 200, 256, 257, 384, 385, 512, 513, 700, 768, 769, 1024, 1025, 1500]
     qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
@@ -633,8 +633,6 @@ def test_pair_traceback_row_block_classes_windows_and_mixed_routes(s4g, oracle_m
         assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"]), (a, b)
         assert r["path"].tolist() == [MOVE[m] for m in o["path"]], (a, b)
     assert n_pos > 500
-    with pytest.raises(RuntimeError):
-        s4g.traceback(db, q, scorer, [len(qs) - 1], [0], [int(scores[-1, 0])], route="wave")
     for go, ge in ((1, 1), (0, 0), (5, 5)):                  # cheap gaps: long gap runs and many ties
         sc = s4g.Scorer("BLOSUM_62", go, ge)
         sub = rng.choice(len(pq), size=150, replace=False)
@@ -769,3 +767,15 @@ def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
     exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
     assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=5, q_count=1), exp[5:6])       # pair route, banded
     assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), exp)
+    # banded traceback: alignments through one, two and three band boundaries, against the oracle and the strip kernels
+    MOVE = {0: 1, 1: 2, 2: 3}
+    sel = [(k, k) for k in range(len(qs))] + [(5, 20), (8, 21), (8, 63), (3, 62), (0, 30), (7, 61)]
+    pq2 = np.array([a for a, _ in sel]); pt2 = np.array([b for _, b in sel])
+    res = s4g.traceback(db, q, scorer, pq2, pt2, exp[pq2, pt2])
+    ref = s4g.traceback(db, q, scorer, pq2, pt2, exp[pq2, pt2], route="scan")
+    for a, b, r, g in zip(pq2, pt2, res, ref):
+        o = oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1)
+        assert o["score"] == r["score"] and r["path"].tolist() == [MOVE[m] for m in o["path"]], (int(a), int(b))
+        assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+        assert g["path"].tolist() == r["path"].tolist()
+    assert len(res[len(qs)]["path"]) >= 3000                  # the 3000-residue self alignment crosses two band boundaries
