@@ -339,8 +339,19 @@ int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t
     // length sort, longest first (ties by original index): items are issued in this order so the longest
     // work runs first and the tail of every launch is short work.
     std::vector<uint32_t> order(n_seqs);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
+    {
+        uint32_t max_len = 0;
+        for (uint32_t i = 0; i < n_seqs; ++i) max_len = std::max(max_len, db->len[i]);
+        if (max_len < (1u << 22)) {         // counting sort by length, descending, ids ascending inside a length: O(n)
+            std::vector<uint32_t> start((size_t)max_len + 2, 0);
+            for (uint32_t i = 0; i < n_seqs; ++i) ++start[max_len - db->len[i] + 1];
+            for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+            for (uint32_t i = 0; i < n_seqs; ++i) order[start[max_len - db->len[i]]++] = i;
+        } else {
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return db->len[a] > db->len[b]; });
+        }
+    }
 
     db->pos_of_id.resize(n_seqs);
     for (uint32_t pp = 0; pp < n_seqs; ++pp) db->pos_of_id[order[pp]] = pp;
