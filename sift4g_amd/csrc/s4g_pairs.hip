@@ -187,12 +187,10 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
 // s4g_scan's latency route: the whole [q_count][n_seqs] matrix as pairs (caller holds cx->mu).  Taken when the estimate
 // says the inter-sequence launch would wait on its longest item for longer than a chip full of pair waves needs for
 // everything; never when a kernel was forced by flags.
-int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done) {
-    *done = false;
-    if (flags != 0) return S4G_OK;
-    const uint64_t n_items = (uint64_t)q_count * db->n_seqs;
-    if (n_items > (4u << 20)) return S4G_OK;
+// the estimate behind that choice (also what s4g_scan_plan reports)
+bool scan_prefers_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags) {
+    if (flags != 0 || q_count == 0 || db->n_seqs == 0) return false;
+    if ((uint64_t)q_count * db->n_seqs > (4u << 20)) return false;
     uint32_t lq_max = 0, max_t = 0;
     uint64_t rows = 0;
     for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
@@ -200,7 +198,16 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
     const double cells = (double)rows * (double)db->residues, longest = (double)lq_max * max_t;
     const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
     const double t_scan = std::max(cells / kScanChipRate, longest / kScanLaneRate);
-    if (t_pairs >= t_scan) return S4G_OK;
+    return t_pairs < t_scan;
+}
+
+int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done) {
+    *done = false;
+    if (!scan_prefers_pairs(db, q, q_begin, q_count, flags)) return S4G_OK;
+    const uint64_t n_items = (uint64_t)q_count * db->n_seqs;
+    uint32_t max_t = 0;
+    for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
     DeviceCtx* cx = device_ctx(db->device);
     int rc = ensure_seq_tables(db);
     if (rc) return rc;

@@ -294,6 +294,16 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
+    if (scan_prefers_pairs(db, q, 0, q->n, 0)) {        // a call this small takes the latency route (one wave per pair)
+        int rc0 = device_props(cx);
+        if (rc0) return rc0;
+        if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", q->max_len > (uint32_t)kPairMaxRows ? "sw_pair_scan_band<16>" : "sw_pair_scan<RPL>");
+        if (grid_blocks) *grid_blocks = (uint32_t)std::min<uint64_t>((uint64_t)q->n * db->n_seqs, (uint64_t)cx->prop.multiProcessorCount * 8);
+        if (block_threads) *block_threads = 64;
+        if (strip_rows) *strip_rows = 0;
+        if (workspace_bytes) *workspace_bytes = 0;
+        return S4G_OK;
+    }
     ensure_bounds(q, scorer);
     Plan p;
     int rc = make_plan(db, q, 0, q->n, scorer, 0, &p);
