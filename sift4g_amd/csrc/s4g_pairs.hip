@@ -184,6 +184,59 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     return S4G_OK;
 }
 
+// One tile of a scan as pairs: the tile's sequences x the queries [q_begin, q_begin + q_count), scores written to
+// d_scores[(query - q_begin) * stride + column], column = original target id (local_cols = false) or the rank of the id
+// inside the tile (local_cols = true, the layout s4g_scan_topk's tile buffer uses).  Used for tiles whose few, very long
+// sequences would make an inter-sequence launch wait on one wave (a titin among the targets); caller holds cx->mu.
+bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags,
+                        double t_hidden) {
+    if (flags != 0 || q_count == 0 || t.n_seqs == 0) return false;
+    if ((uint64_t)q_count * t.n_seqs > (4u << 20)) return false;
+    uint32_t lq_max = 0;
+    uint64_t rows = 0;
+    for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
+    const double cells = (double)rows * (double)t.residues, longest = (double)lq_max * t.max_len4 * 4.0;
+    const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
+    const double t_scan = std::max(cells / kScanChipRate, longest / kScanLaneRate);
+    return t_scan > t_hidden && t_pairs < t_scan;       // t_hidden: other work of the call the tile's launch runs underneath
+}
+
+int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                  int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream) {
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    const uint64_t n_items = (uint64_t)q_count * t.n_seqs;
+    if (n_items * 1 > 0xFFFFFFFFull || (uint64_t)q_count * stride > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "tile too large for the pair route");
+    PairItem* items = nullptr;
+    rc = pair_stage(cx, n_items, &items);
+    if (rc) return rc;
+    std::vector<uint32_t> col;      // column of the sequence at tile position p
+    if (local_cols) {
+        std::vector<uint32_t> ids(db->id_of_pos.begin() + t.pos0, db->id_of_pos.begin() + t.pos0 + t.n_seqs);
+        std::sort(ids.begin(), ids.end());
+        col.resize(t.n_seqs);
+        for (uint32_t p = 0; p < t.n_seqs; ++p)
+            col[p] = (uint32_t)(std::lower_bound(ids.begin(), ids.end(), db->id_of_pos[t.pos0 + p]) - ids.begin());
+    }
+    uint32_t cls_begin[kScanClasses + 1];
+    uint32_t at = 0;
+    std::vector<uint32_t> qs;
+    for (int c = 0; c < kScanClasses; ++c) {
+        cls_begin[c] = at;
+        qs.clear();
+        for (uint32_t i = 0; i < q_count; ++i) if (pair_class(q->len[q_begin + i]) == c) qs.push_back(i);
+        if (qs.empty()) continue;
+        for (uint32_t p = 0; p < t.n_seqs; ++p) {        // tile positions are length-sorted, longest first
+            const uint32_t id = db->id_of_pos[t.pos0 + p];
+            const uint32_t column = local_cols ? col[p] : id;
+            for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * stride + column)};
+        }
+    }
+    cls_begin[kScanClasses] = at;
+    return pair_submit(db, q, scorer, at, cls_begin, d_scores, stream, t.max_len4 * 4);
+}
+
 // s4g_scan's latency route: the whole [q_count][n_seqs] matrix as pairs (caller holds cx->mu).  Taken when the estimate
 // says the inter-sequence launch would wait on its longest item for longer than a chip full of pair waves needs for
 // everything; never when a kernel was forced by flags.

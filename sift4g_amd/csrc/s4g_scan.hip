@@ -374,10 +374,19 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
             }
             HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
             HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+            // what the long tiles run underneath: the other tiles of this call at the chip rate
+            double rows = 0, main_res = 0;
+            for (uint32_t i = 0; i < q_count; ++i) rows += q->len[q_begin + i];
+            for (const Tile& t : db->tiles) if ((uint64_t)t.max_len4 * 4 <= kLongSeq) main_res += (double)t.residues;
+            const double t_main = rows * main_res / 10e12;
             for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
                 const Tile& t = db->tiles[ti];
                 if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
-                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true);
+                // one wave per pair when the tile's longest item would outlast everything else in the call
+                if ((uint64_t)q_count * db->n_seqs <= 0xFFFFFFFFull && tile_prefers_pairs(db, t, q, q_begin, q_count, flags, t_main))
+                    rc = tile_as_pairs(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, false, cx->side_stream);
+                else
+                    rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true);
                 if (rc) return rc;
             }
             HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
@@ -680,7 +689,11 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         if (rc) return rc;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+            // a tile whose launch would wait on one wave walking a very long target goes to one wave per pair instead
+            if (tile_prefers_pairs(db, t, q, q_begin + b, cnt, flags, 0.0))
+                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream);
+            else
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
             if (rc) return rc;
             hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
                                c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);

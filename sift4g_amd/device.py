@@ -217,7 +217,7 @@ def score_pairs(db, queries, scorer, pair_q, pair_t, route=None):
 
 
 def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False,
-              f16_arith=False, no_drift=False):
+              f16_arith=False, no_drift=False, no_pairs=False):
     """Streaming scan + running top-k (no score matrix): -> device tensors (ids int32 [q,k] (-1 unused), scores [q,k], counts [q])."""
     import torch
     q_count = queries.n - q_begin if q_count is None else q_count
@@ -229,7 +229,7 @@ def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stre
         stream = torch.cuda.current_stream(device)
     check(lib.s4g_scan_topk(db._h, queries._h, q_begin, q_count, scorer._h, k, int(min_score), ctypes.c_void_p(ids.data_ptr()),
                             ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(stream.cuda_stream),
-                            _flags(force_i32, no_f16, f16_arith, no_drift)), "s4g_scan_topk")
+                            _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs)), "s4g_scan_topk")
     return ids, sc, cnt
 
 

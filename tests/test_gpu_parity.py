@@ -779,3 +779,50 @@ def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
         assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
         assert g["path"].tolist() == r["path"].tolist()
     assert len(res[len(qs)]["path"]) >= 3000                  # the 3000-residue self alignment crosses two band boundaries
+
+
+def test_very_long_targets_take_the_pair_route_per_tile(s4g, oracle_mod, blosum62, scorer):
+    """a few titin-sized targets among ordinary ones: their tile (sequences beyond 12288 residues) is scored by one wave
+    per pair while the rest of the database runs through the scan kernels, in s4g_scan and in the streaming top-k;
+    same scores and the same top-k as with the scan kernels alone."""
+    rng = np.random.default_rng(40)
+    qs = rand_seqs(rng, 3, 150, 420, 26) + [rand_seqs(rng, 1, 1300, 1300, 26)[0]]
+    ts = rand_seqs(rng, 400, 20, 700, 26) + [rand_seqs(rng, 1, l, l, 26)[0] for l in (12289, 15000, 20000)]
+    ts[401][9000:9400] = qs[0][:400] if len(qs[0]) >= 400 else np.resize(qs[0], 400)
+    ts[402][18000:18000 + len(qs[1])] = qs[1]
+    ts[7] = qs[2][10:].copy()
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    assert len(db.tiles()) == 2
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    for mode in (dict(), dict(no_pairs=True)):
+        assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp), mode
+    for k, ms in ((5, 1), (50, 40)):
+        want = None
+        for mode in (dict(), dict(no_pairs=True)):
+            ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms, **mode)
+            got = (ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy())
+            for i in range(len(qs)):
+                order = sorted((j for j in range(len(ts)) if exp[i, j] >= ms), key=lambda j: (-exp[i, j], j))[:k]
+                assert got[0][i, :len(order)].tolist() == order and int(got[2][i]) == len(order), (k, ms, mode, i)
+                assert got[1][i, :len(order)].tolist() == [int(exp[i, j]) for j in order]
+
+
+def test_long_tile_pair_route_inside_a_large_scan(s4g, oracle_mod, blosum62, scorer):
+    """a call too large for the whole-call pair route (64 queries x 70k targets) whose three 13k-20k-residue targets sit in
+    a tile of their own: s4g_scan scores that tile with one wave per pair on the side stream while the scan kernels do the
+    rest; same matrix as with the scan kernels alone, spot-checked against the oracle (all long columns, 2000 others)."""
+    rng = np.random.default_rng(41)
+    qs = rand_seqs(rng, 64, 200, 420, 26)
+    lens = rng.integers(20, 180, size=70000)
+    ts = [rand_seqs(rng, 1, int(l), int(l), 26)[0] for l in lens] + [rand_seqs(rng, 1, l, l, 26)[0] for l in (13000, 16001, 20000)]
+    ts[70001][5000:5000 + len(qs[3])] = qs[3]
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    assert len(db.tiles()) == 2 and len(qs) * len(ts) > (4 << 20)
+    got = s4g.scan_host(db, q, scorer)
+    ref = s4g.scan_host(db, q, scorer, no_pairs=True)
+    assert np.array_equal(got, ref)
+    cols = np.concatenate([np.arange(70000, 70003), rng.choice(70000, size=2000, replace=False)])
+    sub = [ts[c] for c in cols]
+    exp = oracle_mod.scan(qs, sub, blosum62, 10, 1, threads=8)
+    assert np.array_equal(got[:, cols], exp)
+    assert got[3, 70001] > 1000
