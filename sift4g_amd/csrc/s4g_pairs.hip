@@ -195,10 +195,16 @@ bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     uint32_t lq_max = 0;
     uint64_t rows = 0;
     for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
-    const double cells = (double)rows * (double)t.residues, longest = (double)lq_max * t.max_len4 * 4.0;
-    const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
-    const double t_scan = std::max(cells / kScanChipRate, longest / kScanLaneRate);
-    return t_scan > t_hidden && t_pairs < t_scan;       // t_hidden: other work of the call the tile's launch runs underneath
+    // chip time of both routes (the scan kernels also pay for the empty lanes of a partly filled group: a tile of three
+    // titins is 3/64 full) and the time one wave needs for the longest item
+    const double longest = (double)lq_max * t.max_len4 * 4.0;
+    const double work_scan = (double)rows * (double)t.padded_residues / kScanChipRate;
+    const double work_pairs = (double)rows * (double)t.residues / kPairChipRate;
+    const double t_scan = std::max(work_scan, longest / kScanLaneRate);
+    const double t_pairs = std::max(work_pairs, longest / kPairWaveRate) + kPairCallOverhead;
+    if (t_pairs >= t_scan) return false;
+    // t_hidden: other work of the call the tile's launch runs underneath; then only the chip time counts
+    return t_scan > t_hidden || work_pairs < work_scan;
 }
 
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
