@@ -190,11 +190,22 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
         t.pos0 = p0;
         return hipSuccess;
     }
-    std::vector<uint32_t> res(dwords ? dwords : 1, 0x1F1F1F1Fu);
+    // small tile: every array goes into ONE host blob laid out like the device block, so the tile is one allocation
+    // (taken from the per-device cache when one fits) and one upload instead of six of each
+    uint64_t need = 0;
+    auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
+    const uint64_t o_res = reserve(dwords * 4), o_off = reserve((uint64_t)G * 8), o_len4 = reserve((uint64_t)G * 4);
+    const uint64_t o_pg = reserve((uint64_t)G * 256), o_pl = reserve((uint64_t)G * 256), o_col = reserve((uint64_t)n * 4);
+    const uint64_t o_extra = reserve(extra_bytes);
+    const bool use_block = need <= kBlockMax;
+    std::vector<char> blob(use_block ? need : 0);
+    std::vector<uint32_t> res_vec(use_block ? 0 : (dwords ? dwords : 1), 0x1F1F1F1Fu);
+    uint32_t* const res = use_block ? reinterpret_cast<uint32_t*>(blob.data() + o_res) : res_vec.data();
+    if (use_block) std::fill(res, res + dwords, 0x1F1F1F1Fu);
     std::atomic<bool> bad{false};
     auto pack = [&](uint32_t g0, uint32_t g1) {
         for (uint32_t g = g0; g < g1; ++g) {
-            uint32_t* base = res.data() + grp_off[g];
+            uint32_t* base = res + grp_off[g];
             const uint32_t lanes = std::min<uint32_t>(64, n - g * 64);
             for (uint32_t lane = 0; lane < lanes; ++lane) {
                 const uint32_t id = order[p0 + (size_t)g * 64 + lane];
@@ -244,46 +255,54 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
         return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     hipError_t e;
-    {   // small tile: one allocation (taken from the per-device cache when one fits) instead of six
-        uint64_t need = 0;
-        auto reserve = [&](uint64_t bytes) { const uint64_t at = need; need = (need + bytes + 255) / 256 * 256; return at; };
-        const uint64_t o_res = reserve(dwords * 4), o_off = reserve((uint64_t)G * 8), o_len4 = reserve((uint64_t)G * 4);
-        const uint64_t o_pg = reserve((uint64_t)G * 256), o_pl = reserve((uint64_t)G * 256), o_col = reserve((uint64_t)n * 4);
-        const uint64_t o_extra = reserve(extra_bytes);
-        if (need <= kBlockMax) {
-            DeviceCtx* cx = device_ctx(db->device);
-            char* blk = nullptr;
-            uint64_t blk_bytes = 0;
-            {
-                std::lock_guard<std::mutex> lk(cx->mu);
-                for (size_t k = 0; k < cx->block_cache.size(); ++k)
-                    if (cx->block_cache[k].second >= need && cx->block_cache[k].second <= 4 * need + (1u << 20)) {
-                        blk = cx->block_cache[k].first; blk_bytes = cx->block_cache[k].second;
-                        cx->block_cache.erase(cx->block_cache.begin() + k);
-                        break;
-                    }
-            }
-            if (!blk) {
-                blk_bytes = need + need / 4;          // a little slack so the next, slightly larger database still fits
-                if ((e = hipMalloc((void**)&blk, blk_bytes)) != hipSuccess) return e;
-            }
-            t.d_block = blk; t.block_bytes = blk_bytes;
-            db->hbm_bytes += blk_bytes;
-            t.d_res = reinterpret_cast<uint32_t*>(blk + o_res); t.d_grp_off = reinterpret_cast<uint64_t*>(blk + o_off);
-            t.d_grp_len4 = reinterpret_cast<uint32_t*>(blk + o_len4); t.d_perm_global = reinterpret_cast<uint32_t*>(blk + o_pg);
-            t.d_perm_local = reinterpret_cast<uint32_t*>(blk + o_pl); t.d_col_ids = reinterpret_cast<uint32_t*>(blk + o_col);
-            if (extra_off) *extra_off = o_extra;
-            auto cp = [&](void* d, const void* h, size_t bytes) { return bytes ? hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) : hipSuccess; };
-            if ((e = cp(t.d_res, res.data(), dwords * 4)) != hipSuccess || (e = cp(t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess ||
-                (e = cp(t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess || (e = cp(t.d_perm_global, perm_g.data(), (size_t)G * 256)) != hipSuccess ||
-                (e = cp(t.d_perm_local, perm_l.data(), (size_t)G * 256)) != hipSuccess || (e = cp(t.d_col_ids, col_ids.data(), (size_t)n * 4)) != hipSuccess)
-                return e;
-            t.h_grp_off.swap(grp_off);
-            t.pos0 = p0;
-            return hipSuccess;
+    if (use_block) {
+        DeviceCtx* cx = device_ctx(db->device);
+        char* blk = nullptr;
+        uint64_t blk_bytes = 0;
+        {
+            std::lock_guard<std::mutex> lk(cx->mu);
+            for (size_t k = 0; k < cx->block_cache.size(); ++k)
+                if (cx->block_cache[k].second >= need && cx->block_cache[k].second <= 4 * need + (1u << 20)) {
+                    blk = cx->block_cache[k].first; blk_bytes = cx->block_cache[k].second;
+                    cx->block_cache.erase(cx->block_cache.begin() + k);
+                    break;
+                }
         }
+        if (!blk) {
+            blk_bytes = need + need / 4;          // a little slack so the next, slightly larger database still fits
+            if ((e = hipMalloc((void**)&blk, blk_bytes)) != hipSuccess) return e;
+        }
+        t.d_block = blk; t.block_bytes = blk_bytes;
+        db->hbm_bytes += blk_bytes;
+        t.d_res = reinterpret_cast<uint32_t*>(blk + o_res); t.d_grp_off = reinterpret_cast<uint64_t*>(blk + o_off);
+        t.d_grp_len4 = reinterpret_cast<uint32_t*>(blk + o_len4); t.d_perm_global = reinterpret_cast<uint32_t*>(blk + o_pg);
+        t.d_perm_local = reinterpret_cast<uint32_t*>(blk + o_pl); t.d_col_ids = reinterpret_cast<uint32_t*>(blk + o_col);
+        memcpy(blob.data() + o_off, grp_off.data(), (size_t)G * 8);
+        memcpy(blob.data() + o_len4, grp_len4.data(), (size_t)G * 4);
+        memcpy(blob.data() + o_pg, perm_g.data(), (size_t)G * 256);
+        memcpy(blob.data() + o_pl, perm_l.data(), (size_t)G * 256);
+        memcpy(blob.data() + o_col, col_ids.data(), (size_t)n * 4);
+        if (extra_bytes) {      // the database is this one tile: the per-sequence tables of the pair kernels ride along
+            uint64_t* addr = reinterpret_cast<uint64_t*>(blob.data() + o_extra);
+            const uint64_t o_len = o_extra + ((uint64_t)n * 8 + 255) / 256 * 256;
+            uint32_t* lens = reinterpret_cast<uint32_t*>(blob.data() + o_len);
+            for (uint32_t pos = 0; pos < n; ++pos) {
+                const uint32_t id = order[p0 + pos];
+                addr[id] = (uint64_t)(uintptr_t)(t.d_res + grp_off[pos >> 6] + (pos & 63));
+                lens[id] = db->len[id];
+            }
+            db->d_seq_addr = reinterpret_cast<uint64_t*>(blk + o_extra);
+            db->d_seq_len = reinterpret_cast<uint32_t*>(blk + o_len);
+            db->seq_tables_in_block = true;
+            db->id_of_pos.assign(order.begin() + p0, order.begin() + p1);
+        }
+        if (extra_off) *extra_off = o_extra;
+        if ((e = hipMemcpy(blk, blob.data(), need, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        t.h_grp_off.swap(grp_off);
+        t.pos0 = p0;
+        return hipSuccess;
     }
-    if ((e = up((void**)&t.d_res, res.data(), dwords * 4)) != hipSuccess) return e;
+    if ((e = up((void**)&t.d_res, res, dwords * 4)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_grp_off, grp_off.data(), (size_t)G * 8)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_grp_len4, grp_len4.data(), (size_t)G * 4)) != hipSuccess) return e;
     if ((e = up((void**)&t.d_perm_global, perm_g.data(), (size_t)G * 64 * 4)) != hipSuccess) return e;
@@ -394,23 +413,12 @@ int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t
         }
         db->tiles.emplace_back();
         std::string err;
-        // a database that is one small tile also carries the per-sequence tables of the pair kernels in its block
+        // a database that is one small tile also carries the per-sequence tables of the pair kernels in its block (built and
+        // uploaded with the tile)
         const bool whole = (p == 0 && q == n_seqs);
         uint64_t tab_off = 0;
         hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off,
                                   raw_dev, d_bad.p);
-        if (e == hipSuccess && whole && db->tiles.back().d_block && n_seqs) {
-            const Tile& t0 = db->tiles.back();
-            std::vector<uint64_t> addr(n_seqs);
-            for (uint32_t pos = 0; pos < n_seqs; ++pos)
-                addr[order[pos]] = (uint64_t)(uintptr_t)(t0.d_res + t0.h_grp_off[pos >> 6] + (pos & 63));
-            db->d_seq_addr = reinterpret_cast<uint64_t*>(t0.d_block + tab_off);
-            db->d_seq_len = reinterpret_cast<uint32_t*>(t0.d_block + tab_off + (((uint64_t)n_seqs * 8 + 255) / 256 * 256));
-            db->seq_tables_in_block = true;
-            db->id_of_pos = order;
-            if ((e = hipMemcpy(db->d_seq_addr, addr.data(), (size_t)n_seqs * 8, hipMemcpyHostToDevice)) == hipSuccess)
-                e = hipMemcpy(db->d_seq_len, db->len.data(), (size_t)n_seqs * 4, hipMemcpyHostToDevice);
-        }
         if (e != hipSuccess) {
             std::string msg = err.empty() ? std::string(hipGetErrorString(e)) : err;
             s4g_db_destroy(db);
