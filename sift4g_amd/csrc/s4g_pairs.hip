@@ -22,6 +22,21 @@ constexpr uint64_t kBandWsBudget = 4ull << 30;  // boundary workspace of the ban
 constexpr double kPairChipRate = 2.5e12, kPairWaveRate = 2.4e9 / 0.7, kPairCallOverhead = 60e-6;
 constexpr double kScanChipRate = 10e12, kScanLaneRate = 2.4e9 / 37.0;
 
+// boundary workspace of the banded kernels: one slot of `slot` columns per resident wave; the grid shrinks if the longest
+// target of the launch would push it over the budget (caller holds cx->mu)
+int ensure_band_ws(DeviceCtx* cx, uint32_t max_lt, uint32_t n_items, uint32_t full_grid, uint32_t* grid, uint64_t* slot) {
+    *slot = ((uint64_t)std::max(1u, max_lt) + 63) / 64 * 64;
+    *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(full_grid, n_items), kBandWsBudget / (*slot * 8)));
+    const uint64_t bytes = *slot * 8 * *grid;
+    if (cx->band_ws_bytes < bytes) {
+        if (cx->d_band_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_band_ws)); }
+        cx->d_band_ws = nullptr; cx->band_ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_band_ws, bytes));
+        cx->band_ws_bytes = bytes;
+    }
+    return S4G_OK;
+}
+
 template <int RPL>
 int launch_pairs(DeviceCtx* cx, PairArgs a, uint32_t* grid_cache, hipStream_t stream) {
     if (*grid_cache == 0) {
@@ -103,14 +118,10 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan_band<16>, 64, 0));
                 cx->grid_pair_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
             }
-            const uint64_t slot = ((uint64_t)std::max(1u, max_lt_band) + 63) / 64 * 64;
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(cx->grid_pair_band, a.n_pairs), kBandWsBudget / (slot * 8)));
-            if (cx->band_ws_bytes < slot * 8 * grid) {
-                if (cx->d_band_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_band_ws)); }
-                cx->d_band_ws = nullptr; cx->band_ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&cx->d_band_ws, slot * 8 * grid));
-                cx->band_ws_bytes = slot * 8 * grid;
-            }
+            uint64_t slot = 0;
+            uint32_t grid = 0;
+            rc = ensure_band_ws(cx, max_lt_band, a.n_pairs, cx->grid_pair_band, &grid, &slot);
+            if (rc) return rc;
             PairBandArgs ba;
             ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
             hipLaunchKernelGGL(sw_pair_scan_band<16>, dim3(grid), dim3(64), 0, stream, ba);
@@ -476,26 +487,23 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace_band<16>, 64, 0));
                 cx->grid_pair_trace_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
             }
-            const uint64_t slot = ((uint64_t)std::max(1u, max_lt) + 63) / 64 * 64;
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(cx->grid_pair_trace_band, ni), kBandWsBudget / (slot * 8)));
-            if (cx->band_ws_bytes < slot * 8 * grid) {
-                if (cx->d_band_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_band_ws)); }
-                cx->d_band_ws = nullptr; cx->band_ws_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&cx->d_band_ws, slot * 8 * grid));
-                cx->band_ws_bytes = slot * 8 * grid;
-            }
+            uint64_t slot = 0;
+            uint32_t grid = 0;
+            rc = ensure_band_ws(cx, max_lt, ni, cx->grid_pair_trace_band, &grid, &slot);
+            if (rc) return rc;
             PairTraceBandArgs ba;
             ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
             hipLaunchKernelGGL(sw_pair_trace_band<16>, dim3(grid), dim3(64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
-        } else
-        switch (c) {
-            case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
-            case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
-            case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
-            case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
-            case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
-            default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
+        } else {
+            switch (c) {
+                case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
+                case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
+                case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
+                case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
+                case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
+                default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
+            }
         }
         if (rc) return rc;
         out5.resize((size_t)ni * 5); best.resize(ni); paths.resize(path_total ? path_total : 1);
