@@ -164,10 +164,11 @@ int scratch_release(const s4g_db* db, hipStream_t stream);
 bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags,
                         double t_hidden);
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                  int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream);
+                  int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);
+uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);
 bool scan_prefers_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);
 int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done);
+                  int32_t* d_scores, hipStream_t stream, bool* done);
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);

@@ -218,12 +218,49 @@ bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     return t_scan > t_hidden || work_pairs < work_scan;
 }
 
+// How many of a tile's leading groups (its longest sequences) should be scored as pairs while the scan kernels take the
+// rest: the scan kernels are bounded from below by one wave walking the longest group it is given (37 cycles per cell),
+// pair waves by 0.7 cycles per cell of the longest pair but at a quarter of the chip rate.  Estimate for a handful of
+// split points; both parts run concurrently, so the call takes max(latencies, sum of the chip times).  0 = no split.
+uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags) {
+    if (flags != 0 || q_count == 0 || t.n_groups == 0) return 0;
+    uint32_t lq_max = 0;
+    double rows = 0;
+    for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
+    const uint32_t G = t.n_groups;
+    auto len_of = [&](uint32_t g) {     // padded length of group g, residues
+        const uint64_t end = g + 1 < G ? t.h_grp_off[g + 1] : t.padded_residues / 4;
+        return (double)((end - t.h_grp_off[g]) / 64 * 4);
+    };
+    const double total = (double)t.padded_residues;
+    auto cost = [&](uint32_t g0) {
+        const double res_pairs = g0 < G ? (double)t.h_grp_off[g0] * 4.0 : total;
+        const double lat_pairs = g0 ? lq_max * len_of(0) / kPairWaveRate + kPairCallOverhead : 0.0;
+        const double lat_scan = g0 < G ? lq_max * len_of(g0) / kScanLaneRate : 0.0;
+        const double work = rows * res_pairs / kPairChipRate + rows * (total - res_pairs) / kScanChipRate;
+        return std::max(std::max(lat_pairs, lat_scan), work);
+    };
+    double best = cost(0);
+    uint32_t best_g0 = 0;
+    const double base = best;
+    for (uint32_t g0 = 1;; g0 = g0 < 8 ? g0 + 1 : g0 + g0 / 4) {
+        if (g0 > G) g0 = G;
+        if ((uint64_t)q_count * std::min<uint64_t>(t.n_seqs, (uint64_t)g0 * 64) <= (4u << 20)) {
+            const double c = cost(g0);
+            if (c < best) { best = c; best_g0 = g0; }
+        }
+        if (g0 == G) break;
+    }
+    return best < 0.9 * base ? best_g0 : 0;
+}
+
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                  int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream) {
+                  int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos) {
+    n_pos = std::min(n_pos, t.n_seqs);          // the tile's first n_pos sequences (its longest)
     DeviceCtx* cx = device_ctx(db->device);
     int rc = ensure_seq_tables(db);
     if (rc) return rc;
-    const uint64_t n_items = (uint64_t)q_count * t.n_seqs;
+    const uint64_t n_items = (uint64_t)q_count * n_pos;
     if (n_items * 1 > 0xFFFFFFFFull || (uint64_t)q_count * stride > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "tile too large for the pair route");
     PairItem* items = nullptr;
     rc = pair_stage(cx, n_items, &items);
@@ -244,7 +281,7 @@ int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_
         qs.clear();
         for (uint32_t i = 0; i < q_count; ++i) if (pair_class(q->len[q_begin + i]) == c) qs.push_back(i);
         if (qs.empty()) continue;
-        for (uint32_t p = 0; p < t.n_seqs; ++p) {        // tile positions are length-sorted, longest first
+        for (uint32_t p = 0; p < n_pos; ++p) {           // tile positions are length-sorted, longest first
             const uint32_t id = db->id_of_pos[t.pos0 + p];
             const uint32_t column = local_cols ? col[p] : id;
             for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * stride + column)};
@@ -257,24 +294,17 @@ int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_
 // s4g_scan's latency route: the whole [q_count][n_seqs] matrix as pairs (caller holds cx->mu).  Taken when the estimate
 // says the inter-sequence launch would wait on its longest item for longer than a chip full of pair waves needs for
 // everything; never when a kernel was forced by flags.
-// the estimate behind that choice (also what s4g_scan_plan reports)
+// what s4g_scan_plan reports: does a scan of these queries go to the pair kernels entirely?
 bool scan_prefers_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags) {
-    if (flags != 0 || q_count == 0 || db->n_seqs == 0) return false;
-    if ((uint64_t)q_count * db->n_seqs > (4u << 20)) return false;
-    uint32_t lq_max = 0, max_t = 0;
-    uint64_t rows = 0;
-    for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
-    for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
-    const double cells = (double)rows * (double)db->residues, longest = (double)lq_max * max_t;
-    const double t_pairs = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
-    const double t_scan = std::max(cells / kScanChipRate, longest / kScanLaneRate);
-    return t_pairs < t_scan;
+    if (flags != 0 || q_count == 0 || db->n_seqs == 0 || (uint64_t)q_count * db->n_seqs > 0xFFFFFFFFull) return false;
+    for (const Tile& t : db->tiles)
+        if (t.n_seqs && split_groups(db, t, q, q_begin, q_count, flags) < t.n_groups) return false;
+    return true;
 }
 
 int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                  int32_t* d_scores, hipStream_t stream, uint32_t flags, bool* done) {
+                  int32_t* d_scores, hipStream_t stream, bool* done) {
     *done = false;
-    if (!scan_prefers_pairs(db, q, q_begin, q_count, flags)) return S4G_OK;
     const uint64_t n_items = (uint64_t)q_count * db->n_seqs;
     uint32_t max_t = 0;
     for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);

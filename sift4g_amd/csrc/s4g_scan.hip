@@ -204,8 +204,10 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
 // One tile: one launch per non-empty tier.  perm/stride select the output layout: original ids into the caller's
 // [q][n_seqs] matrix, or tile columns.
 int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
-                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream, bool side = false) {
-    if (t.n_seqs == 0) return S4G_OK;
+                uint32_t q_begin, int32_t* d_scores, uint64_t stride, const uint32_t* perm, hipStream_t stream, bool side = false,
+                uint32_t g0 = 0) {      // g0: skip the tile's first g0 groups (they are scored as pairs, see split_groups)
+    if (t.n_seqs == 0 || g0 >= t.n_groups) return S4G_OK;
+    const uint32_t n_groups = t.n_groups - g0;
     DeviceCtx* cx = device_ctx(db->device);
     int32_t* const ws = side ? cx->d_ws_side : cx->d_ws;
     unsigned* const counters = cx->d_counter + (side ? 8 : 0);
@@ -214,26 +216,26 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), (items + kWavesPerBlock - 1) / kWavesPerBlock));
     };
     const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
-    if ((uint64_t)t.n_groups * most >= 0xFFFFFFFFull)
+    if ((uint64_t)n_groups * most >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
     HIP_TRY(hipMemsetAsync(counters, 0, 16, stream));
     ScanArgs16 a;
-    a.db_res = t.d_res; a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4; a.grp_perm = perm;
+    a.db_res = t.d_res; a.grp_off = t.d_grp_off + g0; a.grp_len4 = t.d_grp_len4 + g0; a.grp_perm = perm + (size_t)g0 * 64;
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
     a.mat = cx->d_mat;
     a.scores = d_scores; a.score_stride = stride;
     a.ws = ws; a.ws_slot = ws_slot_elems(t);
-    a.n_groups = t.n_groups; a.q_begin = q_begin;
+    a.n_groups = n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     if (w.n_drift) {
         a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
         a.floor_bits = p.bias | (p.bias << 16);
-        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)t.n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
         a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2; a.prio_cost = w.prio_cost[1];
-        const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)t.n_groups * w.n_m3);
+        const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)n_groups * w.n_m3);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
             hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
@@ -246,21 +248,21 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     if (w.n_pk) {
         a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
         a.floor_bits = 0;
-        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)t.n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_wide) {
         ScanArgs b;
-        b.db_res = t.d_res; b.grp_off = t.d_grp_off; b.grp_len4 = t.d_grp_len4; b.grp_perm = perm;
+        b.db_res = t.d_res; b.grp_off = t.d_grp_off + g0; b.grp_len4 = t.d_grp_len4 + g0; b.grp_perm = perm + (size_t)g0 * 64;
         b.q_codes = q->d_codes; b.q_off = q->d_off; b.q_len = q->d_len;
         b.mat = cx->d_mat;
         b.scores = d_scores; b.score_stride = stride;
         b.ws = ws; b.ws_slot = ws_slot_elems(t);
         b.counter = counters + 1;
-        b.n_groups = t.n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
+        b.n_groups = n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
         b.q_list = cx->d_qlist + w.off_wide;
         b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
-        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)t.n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
+        hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
         HIP_TRY(hipGetLastError());
     }
     return S4G_OK;
@@ -332,11 +334,22 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
-    {   // latency-bound call (few queries against a small database, the per-query alignDatabase pattern)?  Then every
-        // (query, target) pair gets a wave of its own instead of 64 targets sharing one: see scan_as_pairs.
-        bool as_pairs = false;
-        rc = scan_as_pairs(db, q, q_begin, q_count, scorer, d_scores, stream, flags, &as_pairs);
-        if (rc || as_pairs) return rc;
+    // Routing per tile (split_groups): the first g0 groups of a tile -- its longest sequences -- go to one wave per pair,
+    // the rest to the scan kernels.  g0 = 0 for a throughput-bound call (bench.py), g0 = all groups for a latency-bound
+    // one (few queries against a small database: the per-query alignDatabase pattern) and for a tile of titin-sized
+    // targets; something in between when only the longest groups would make the launch wait.
+    std::vector<uint32_t> g0s(db->tiles.size(), 0);
+    bool all_pairs = true, any_pairs = false;
+    const bool pairs_possible = (uint64_t)q_count * db->n_seqs <= 0xFFFFFFFFull;      // 32-bit score indices in the pair kernels
+    for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+        const Tile& t = db->tiles[ti];
+        if (pairs_possible) g0s[ti] = split_groups(db, t, q, q_begin, q_count, flags);
+        all_pairs = all_pairs && (t.n_seqs == 0 || g0s[ti] >= t.n_groups);
+        any_pairs = any_pairs || g0s[ti] != 0;
+    }
+    if (all_pairs && any_pairs) {       // nothing for the scan kernels: one submission, no plan, no strip workspace
+        bool done = false;
+        return scan_as_pairs(db, q, q_begin, q_count, scorer, d_scores, stream, &done);
     }
     ensure_bounds(q, scorer);
     Plan p;
@@ -346,57 +359,54 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (rc) return rc;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
-    // long-sequence tiles first, on the side stream with their own workspace: their few huge items then run underneath
-    // the main tiles' launches instead of as a tail-dominated launch of their own
-    bool forked = false;
+    // The side stream carries (a) the pair parts and (b) the scan launches of long-sequence tiles (own workspace): their
+    // few huge items then run underneath the main tiles' launches instead of as a tail-dominated launch of their own.
     const uint32_t full = std::max(std::max(p.grid_i32, p.grid_i16), std::max(p.grid_m3, p.grid_drift));
-    if (db->tiles.size() > 1) {
-        uint64_t need = 0;
+    std::vector<char> on_side(db->tiles.size(), 0);
+    uint64_t need = 0;
+    if (db->tiles.size() > 1)
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
+            if ((uint64_t)t.max_len4 * 4 <= kLongSeq || g0s[ti] >= t.n_groups) continue;
+            on_side[ti] = 1;
             const TileWork& w = p.tiles[ti];
             const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
             const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
             need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
         }
-        if (need) {
-            if (!cx->side_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
-            }
-            if (cx->ws_side_bytes < need) {
-                if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
-                cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&cx->d_ws_side, need));
-                cx->ws_side_bytes = need;
-            }
-            HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
-            HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
-            // what the long tiles run underneath: the other tiles of this call at the chip rate
-            double rows = 0, main_res = 0;
-            for (uint32_t i = 0; i < q_count; ++i) rows += q->len[q_begin + i];
-            for (const Tile& t : db->tiles) if ((uint64_t)t.max_len4 * 4 <= kLongSeq) main_res += (double)t.residues;
-            const double t_main = rows * main_res / 10e12;
-            for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
-                const Tile& t = db->tiles[ti];
-                if ((uint64_t)t.max_len4 * 4 <= kLongSeq) continue;
-                // one wave per pair when the tile's longest item would outlast everything else in the call
-                if ((uint64_t)q_count * db->n_seqs <= 0xFFFFFFFFull && tile_prefers_pairs(db, t, q, q_begin, q_count, flags, t_main))
-                    rc = tile_as_pairs(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, false, cx->side_stream);
-                else
-                    rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true);
+    const bool forked = need != 0 || any_pairs;
+    if (forked) {
+        if (!cx->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+        }
+        if (cx->ws_side_bytes < need) {
+            if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
+            cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&cx->d_ws_side, need));
+            cx->ws_side_bytes = need;
+        }
+        HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
+        HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            if (g0s[ti]) {
+                rc = tile_as_pairs(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, false, cx->side_stream,
+                                   (uint32_t)std::min<uint64_t>(t.n_seqs, (uint64_t)g0s[ti] * 64));
                 if (rc) return rc;
             }
-            HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
-            forked = true;
+            if (on_side[ti]) {
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, cx->side_stream, true, g0s[ti]);
+                if (rc) return rc;
+            }
         }
+        HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
     }
     for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+        if (on_side[ti]) continue;
         const Tile& t = db->tiles[ti];
-        if (forked && (uint64_t)t.max_len4 * 4 > kLongSeq) continue;
-        rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream);
+        rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream, false, g0s[ti]);
         if (rc) return rc;
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
@@ -691,7 +701,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             const Tile& t = db->tiles[ti];
             // a tile whose launch would wait on one wave walking a very long target goes to one wave per pair instead
             if (tile_prefers_pairs(db, t, q, q_begin + b, cnt, flags, 0.0))
-                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream);
+                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream, t.n_seqs);
             else
                 rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
             if (rc) return rc;
