@@ -161,8 +161,6 @@ int device_props(DeviceCtx* cx);
 int scratch_acquire(const s4g_db* db, hipStream_t stream);
 int scratch_release(const s4g_db* db, hipStream_t stream);
 // s4g_pairs.hip
-bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags,
-                        double t_hidden);
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);
 uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);

@@ -199,25 +199,6 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
 // d_scores[(query - q_begin) * stride + column], column = original target id (local_cols = false) or the rank of the id
 // inside the tile (local_cols = true, the layout s4g_scan_topk's tile buffer uses).  Used for tiles whose few, very long
 // sequences would make an inter-sequence launch wait on one wave (a titin among the targets); caller holds cx->mu.
-bool tile_prefers_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags,
-                        double t_hidden) {
-    if (flags != 0 || q_count == 0 || t.n_seqs == 0) return false;
-    if ((uint64_t)q_count * t.n_seqs > (4u << 20)) return false;
-    uint32_t lq_max = 0;
-    uint64_t rows = 0;
-    for (uint32_t i = 0; i < q_count; ++i) { lq_max = std::max(lq_max, q->len[q_begin + i]); rows += q->len[q_begin + i]; }
-    // chip time of both routes (the scan kernels also pay for the empty lanes of a partly filled group: a tile of three
-    // titins is 3/64 full) and the time one wave needs for the longest item
-    const double longest = (double)lq_max * t.max_len4 * 4.0;
-    const double work_scan = (double)rows * (double)t.padded_residues / kScanChipRate;
-    const double work_pairs = (double)rows * (double)t.residues / kPairChipRate;
-    const double t_scan = std::max(work_scan, longest / kScanLaneRate);
-    const double t_pairs = std::max(work_pairs, longest / kPairWaveRate) + kPairCallOverhead;
-    if (t_pairs >= t_scan) return false;
-    // t_hidden: other work of the call the tile's launch runs underneath; then only the chip time counts
-    return t_scan > t_hidden || work_pairs < work_scan;
-}
-
 // How many of a tile's leading groups (its longest sequences) should be scored as pairs while the scan kernels take the
 // rest: the scan kernels are bounded from below by one wave walking the longest group it is given (37 cycles per cell),
 // pair waves by 0.7 cycles per cell of the longest pair but at a quarter of the chip rate.  Estimate for a handful of
@@ -234,10 +215,13 @@ uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uin
     };
     const double total = (double)t.padded_residues;
     auto cost = [&](uint32_t g0) {
-        const double res_pairs = g0 < G ? (double)t.h_grp_off[g0] * 4.0 : total;
+        // the scan kernels pay for every lane of a group, filled or not (a tile of three titins is 3/64 full); pair waves
+        // only for the sequences that exist
+        const double res_scan = g0 < G ? total - (double)t.h_grp_off[g0] * 4.0 : 0.0;
+        const double res_pairs = g0 < G ? (double)t.h_grp_off[g0] * 4.0 : (double)t.residues;
         const double lat_pairs = g0 ? lq_max * len_of(0) / kPairWaveRate + kPairCallOverhead : 0.0;
         const double lat_scan = g0 < G ? lq_max * len_of(g0) / kScanLaneRate : 0.0;
-        const double work = rows * res_pairs / kPairChipRate + rows * (total - res_pairs) / kScanChipRate;
+        const double work = rows * res_pairs / kPairChipRate + rows * res_scan / kScanChipRate;
         return std::max(std::max(lat_pairs, lat_scan), work);
     };
     double best = cost(0);

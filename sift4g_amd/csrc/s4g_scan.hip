@@ -699,11 +699,28 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         if (rc) return rc;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            // a tile whose launch would wait on one wave walking a very long target goes to one wave per pair instead
-            if (tile_prefers_pairs(db, t, q, q_begin + b, cnt, flags, 0.0))
+            // same routing as s4g_scan (split_groups): the tile's longest groups to one wave per pair (on the side stream
+            // when the scan kernels take the rest), joined before the tile's top-k
+            const uint32_t g0 = (uint64_t)cnt * t.n_seqs <= 0xFFFFFFFFull ? split_groups(db, t, q, q_begin + b, cnt, flags) : 0;
+            if (g0 >= t.n_groups && t.n_seqs) {
                 rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream, t.n_seqs);
-            else
+            } else if (g0) {
+                if (!cx->side_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(cx->side_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, cx->side_stream, g0 * 64);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream, false, g0);
+                if (rc) return rc;
+                HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
+            } else {
                 rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+            }
             if (rc) return rc;
             hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
                                c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
