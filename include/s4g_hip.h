@@ -119,7 +119,12 @@ int s4g_scan_cells(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uin
 /* Score queries [q_begin, q_begin+q_count) against every target.
  * d_scores: DEVICE pointer to q_count * n_seqs int32, row = query (relative to
  * q_begin), column = target in the ORIGINAL order given to s4g_db_create.
- * Asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Two device mappings serve it, both exact: the inter-sequence scan kernels (64 targets per wave, the throughput
+ * form) and one wave per (query, target) pair (sw_pair.hip.h, the latency form).  Per database tile the library
+ * estimates how many of the tile's longest groups would make a scan launch wait and gives those to pair waves on a
+ * side stream: all of them for one query against a few thousand targets (the per-query alignDatabase call of
+ * database_alignment.cpp:83-86), none for a thousand queries, the titin-sized end of the database in between. */
 int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
              const s4g_scorer* scorer, int32_t* d_scores, void* stream);
 
@@ -130,7 +135,7 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 #define S4G_SCAN_FORCE_I32 1u
 #define S4G_SCAN_NO_F16    2u   /* skip the v_pk_maximum3_f16 tier (those queries then run in the plain packed int16 kernel) */
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */
-#define S4G_SCAN_NO_PAIRS  16u  /* never take the one-wave-per-pair latency route (sw_pair_scan); any other flag implies this */
+#define S4G_SCAN_NO_PAIRS  16u  /* scan kernels only: no group goes to the one-wave-per-pair kernels; any other flag implies this */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
