@@ -826,3 +826,29 @@ def test_long_tile_pair_route_inside_a_large_scan(s4g, oracle_mod, blosum62, sco
     exp = oracle_mod.scan(qs, sub, blosum62, 10, 1, threads=8)
     assert np.array_equal(got[:, cols], exp)
     assert got[3, 70001] > 1000
+
+
+def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
+    """a few queries against 20k targets with a long-tailed length distribution: s4g_scan gives the longest groups of the
+    tile to pair waves and the rest to the scan kernels; the matrix equals the scan kernels' and the oracle's, for several
+    query counts (different split points) and through the streaming top-k."""
+    rng = np.random.default_rng(42)
+    lens = np.clip(np.exp(rng.normal(5.6, 0.6, size=20000)), 20, 3000).astype(int)
+    ts = [rand_seqs(rng, 1, int(l), int(l), 26)[0] for l in lens]
+    qs = rand_seqs(rng, 6, 250, 420, 26)
+    ts[11] = qs[0][20:].copy()
+    db = s4g.Database(ts)
+    tc, to = oracle_mod._flat(ts)
+    qc, qo = oracle_mod._flat(qs)
+    exp = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, 10, 1, threads=8)
+    if exp is None:
+        exp = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, 10, 1, threads=8)
+    q = s4g.QuerySet(qs)
+    for nq in (1, 2, 4, 6):
+        assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=0, q_count=nq), exp[:nq]), nq
+        assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=0, q_count=nq, no_pairs=True), exp[:nq]), nq
+    ids, sc, cnt = s4g.scan_topk(db, q, scorer, 30, 1)
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    for i in range(len(qs)):
+        order = sorted(range(len(ts)), key=lambda j: (-exp[i, j], j))[:30]
+        assert ids[i].tolist() == order and sc[i].tolist() == [int(exp[i, j]) for j in order]
