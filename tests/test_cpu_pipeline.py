@@ -1,0 +1,31 @@
+"""End-to-end equality of the two pipelines on the reference's own fixture, without a GPU: the reference's unmodified CLI
+(build/dropin/sift4g, compiled in place from /root/reference by `make dropin`) is run with a TEST-ONLY stand-in for
+libs4g_hip.so that answers the device ABI with the CPU oracle (tests/cpu_shim/).  Its .SIFTprediction files must be byte
+for byte the ones the same CLI wrote on an MI355X through the HIP kernels (tests/golden/dropin_predictions/) -- "GPU path ==
+its own CPU path", the strongest end-to-end statement available while swsharp is absent (parity unpinned)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
+SHIM = os.path.join(ROOT, "tests", "cpu_shim")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+def test_reference_cli_on_the_cpu_oracle_reproduces_the_gpu_predictions(tmp_path):
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    ldd = subprocess.run(["ldd", DROPIN], env=env, capture_output=True, text=True).stdout
+    assert os.path.join(SHIM, "lib", "libs4g_hip.so") in ldd, ldd          # the stand-in, not the HIP library, is what gets loaded
+    files = os.path.join(GOLDEN, "test_files")
+    r = subprocess.run([DROPIN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep,
+                        "-d", os.path.join(files, "sample_protein_database.fa"), "--cards", "0", "--out", str(tmp_path), "--sub-results"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = sorted(f for f in os.listdir(tmp_path) if f.endswith(".SIFTprediction"))
+    assert names == ["LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"]
+    for n in names + ["alignments.txt"]:     # alignments.txt: scores, e-values, coordinates, identity / gap counts of every hit (bm9)
+        assert (tmp_path / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n

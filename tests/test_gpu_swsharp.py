@@ -132,9 +132,12 @@ def test_reference_cli_runs_on_our_library(tmp_path):
     the predictions are well-formed and stable against the committed run of this same path."""
     tf = os.path.join(GOLDEN, "test_files")
     r = subprocess.run([DROPIN, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d",
-                        os.path.join(tf, "sample_protein_database.fa"), "--out", str(tmp_path), "--cards", "0"],
-                       capture_output=True, text=True, timeout=600)
+                        os.path.join(tf, "sample_protein_database.fa"), "--out", str(tmp_path), "--cards", "0", "--sub-results"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
+    # every reported hit (score, e-value, coordinates, identity / gaps from the device traceback): the same bytes the CPU
+    # oracle pipeline produces (tests/test_cpu_pipeline.py compares its own run with this same file)
+    assert (tmp_path / "alignments.txt").read_text() == open(os.path.join(GOLDEN, "dropin_predictions", "alignments.txt")).read()
     for name, n_subst in (("LACI_ECOLI", 3), ("PURR_SALTY", 2)):
         path = tmp_path / f"{name}.SIFTprediction"
         assert path.exists(), r.stderr[-2000:]
