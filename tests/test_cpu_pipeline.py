@@ -9,6 +9,7 @@ import subprocess
 import pytest
 
 from conftest import GOLDEN, ROOT
+import dropin_synth
 
 DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
 SHIM = os.path.join(ROOT, "tests", "cpu_shim")
@@ -29,3 +30,15 @@ def test_reference_cli_on_the_cpu_oracle_reproduces_the_gpu_predictions(tmp_path
     assert names == ["LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"]
     for n in names + ["alignments.txt"]:     # alignments.txt: scores, e-values, coordinates, identity / gap counts of every hit (bm9)
         assert (tmp_path / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+def test_reference_cli_on_the_cpu_oracle_reproduces_the_gpu_alignments_of_a_synthetic_set(tmp_path):
+    """8 queries x 1500 synthetic targets with planted, gapped homologs: 250 reported alignments, byte-identical between the
+    oracle pipeline (here) and the MI355X run (tests/golden/dropin_synth/, re-checked on the GPU by tests/test_gpu_swsharp.py)."""
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    got = dropin_synth.run(DROPIN, str(tmp_path), env=env)
+    want = open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+    assert got == want
+    assert got.count(b"\n") == 250

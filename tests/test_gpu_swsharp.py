@@ -149,3 +149,13 @@ def test_reference_cli_runs_on_our_library(tmp_path):
         gold = os.path.join(GOLDEN, "dropin_predictions", f"{name}.SIFTprediction")
         if os.path.exists(gold):
             assert path.read_text() == open(gold).read()
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+def test_reference_cli_synthetic_set_matches_the_committed_run(tmp_path):
+    """the reference CLI on 8 queries x 1500 synthetic targets (per-query candidate databases -> pair kernels for scores and
+    traceback): alignments.txt equals tests/golden/dropin_synth/, which the CPU oracle pipeline reproduces byte for byte
+    (tests/test_cpu_pipeline.py)."""
+    import dropin_synth
+    got = dropin_synth.run(DROPIN, str(tmp_path))
+    assert got == open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
