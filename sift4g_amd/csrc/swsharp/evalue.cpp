@@ -12,6 +12,7 @@
 // "existence" excludes it, so existence = open - extend.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "impl.hpp"
 
@@ -66,35 +67,54 @@ SW_API EValueParams* createEValueParams(long long length, Scorer* scorer) {
 
 SW_API void deleteEValueParams(EValueParams* p) { delete p; }
 
-static double spouge_evalue(int score, int m, int n, const EValueParams* p) {
+// Spouge's finite-size corrected e-value.  Everything that depends on the score and the query length only is
+// computed once per distinct score of a call (ScoreTerms); the per-target part is one erfc and one exp.  The expressions
+// and their order are those of the straightforward formula, so the doubles are the same.
+struct ScoreTerms { double sqrt_v, p1, P_m_F, c_y, expl, shift; bool set = false; };
+
+static ScoreTerms score_terms(int score, int m, const EValueParams* p) {
     const double inv_sqrt_2pi = 0.39894228040143267793994605993438;
     const double y = (double)score;
-    const double scale = (double)p->length / (double)(n > 0 ? n : 1);   // pair -> database
-
-    const double m_li_y = m - (p->a * y + p->b);
+    ScoreTerms t;
+    t.shift = p->a * y + p->b;
+    const double m_li_y = m - t.shift;
     double vi_y = p->alpha * y + p->beta;
     if (vi_y < 2.0 * p->alpha / p->lambda) vi_y = 2.0 * p->alpha / p->lambda;
-    const double sqrt_vi_y = sqrt(vi_y);
-    const double m_F = m_li_y / sqrt_vi_y;
-    const double P_m_F = 0.5 * erfc(-m_F / sqrt(2.0));
-    const double p1 = m_li_y * P_m_F + sqrt_vi_y * inv_sqrt_2pi * exp(-0.5 * m_F * m_F);
-
-    const double n_lj_y = n - (p->a * y + p->b);                        // symmetric matrix: same a, b, alpha, beta
-    const double sqrt_vj_y = sqrt_vi_y;
-    const double n_F = n_lj_y / sqrt_vj_y;
-    const double P_n_F = 0.5 * erfc(-n_F / sqrt(2.0));
-    const double p2 = n_lj_y * P_n_F + sqrt_vj_y * inv_sqrt_2pi * exp(-0.5 * n_F * n_F);
-
-    double c_y = p->sigma * y + p->tau;
-    if (c_y < 2.0 * p->sigma / p->lambda) c_y = 2.0 * p->sigma / p->lambda;
-    const double area = p1 * p2 + c_y * P_m_F * P_n_F;
-    return area * p->K * exp(-p->lambda * y) * scale;
+    t.sqrt_v = sqrt(vi_y);
+    const double m_F = m_li_y / t.sqrt_v;
+    t.P_m_F = 0.5 * erfc(-m_F / sqrt(2.0));
+    t.p1 = m_li_y * t.P_m_F + t.sqrt_v * inv_sqrt_2pi * exp(-0.5 * m_F * m_F);
+    t.c_y = p->sigma * y + p->tau;
+    if (t.c_y < 2.0 * p->sigma / p->lambda) t.c_y = 2.0 * p->sigma / p->lambda;
+    t.expl = exp(-p->lambda * y);
+    t.set = true;
+    return t;
 }
+
+static double spouge_evalue(const ScoreTerms& t, int n, const EValueParams* p) {
+    const double inv_sqrt_2pi = 0.39894228040143267793994605993438;
+    const double scale = (double)p->length / (double)(n > 0 ? n : 1);   // pair -> database
+    const double n_lj_y = n - t.shift;                                   // symmetric matrix: same a, b, alpha, beta
+    const double n_F = n_lj_y / t.sqrt_v;
+    const double P_n_F = 0.5 * erfc(-n_F / sqrt(2.0));
+    const double p2 = n_lj_y * P_n_F + t.sqrt_v * inv_sqrt_2pi * exp(-0.5 * n_F * n_F);
+    const double area = t.p1 * p2 + t.c_y * t.P_m_F * P_n_F;
+    return area * p->K * t.expl * scale;
+}
+
+static double spouge_evalue(int score, int m, int n, const EValueParams* p) { return spouge_evalue(score_terms(score, m, p), n, p); }
 
 SW_API void eValues(double* values, int* scores, Chain* query, Chain** database, int databaseLen,
                     int* cards, int cardsLen, EValueParams* p) {
     (void)cards; (void)cardsLen;   // double-precision host math on <= a few thousand scores: not worth a launch, and
                                    // device erfc/exp would differ from glibc by ULPs (SURVEY.md section 7 hard parts)
     const int m = chainGetLength(query);
-    for (int i = 0; i < databaseLen; ++i) values[i] = spouge_evalue(scores[i], m, chainGetLength(database[i]), p);
+    std::vector<ScoreTerms> memo;           // by score; most of a candidate list shares a few dozen small scores
+    for (int i = 0; i < databaseLen; ++i) {
+        const int sc = scores[i];
+        if (sc < 0 || sc > (1 << 20)) { values[i] = spouge_evalue(sc, m, chainGetLength(database[i]), p); continue; }
+        if ((size_t)sc >= memo.size()) memo.resize((size_t)sc + 1);
+        if (!memo[sc].set) memo[sc] = score_terms(sc, m, p);
+        values[i] = spouge_evalue(memo[sc], chainGetLength(database[i]), p);
+    }
 }
