@@ -452,8 +452,7 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     };
     const uint64_t dir_budget = 8ull << 30;
     std::vector<PairTraceItem> items;
-    std::vector<int32_t> out5, best;
-    std::vector<uint8_t> paths;
+    std::vector<uint8_t> back;
     for (uint32_t b0 = 0; b0 < n;) {
         // a batch: consecutive pairs of ONE class whose direction blocks fit the budget
         int c = 0;
@@ -520,19 +519,21 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
             }
         }
         if (rc) return rc;
-        out5.resize((size_t)ni * 5); best.resize(ni); paths.resize(path_total ? path_total : 1);
-        HIP_TRY(hipMemcpyAsync(out5.data(), A + o_out, (size_t)ni * 20, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(best.data(), A + o_best, (size_t)ni * 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(paths.data(), A + o_paths, path_total, hipMemcpyDeviceToHost, stream));
+        // out5, best and the paths sit back to back in the arena: one download
+        back.resize(o_paths + path_total - o_out);
+        HIP_TRY(hipMemcpyAsync(back.data(), A + o_out, back.size(), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        const int32_t* out5 = reinterpret_cast<const int32_t*>(back.data());
+        const int32_t* best = reinterpret_cast<const int32_t*>(back.data() + (o_best - o_out));
+        const uint8_t* paths = back.data() + (o_paths - o_out);
         for (uint32_t x = 0; x < ni; ++x) {
             const uint32_t pi = order[b0 + x];
             const int32_t want = pair_score[pi] > 0 && q->len[pair_q[pi]] && db->len[pair_t[pi]] ? pair_score[pi] : 0;
             if (best[x] != want && !(pair_score[pi] <= 0 && best[x] == 0))
                 return fail(S4G_ERR_INVALID, "pair %u: score %d passed in, traceback kernel computed %d", pi, pair_score[pi], best[x]);
-            memcpy(h_out + (size_t)pi * 5, out5.data() + (size_t)x * 5, 20);
+            memcpy(h_out + (size_t)pi * 5, out5 + (size_t)x * 5, 20);
             const uint32_t len = (uint32_t)out5[(size_t)x * 5 + 4];
-            memcpy(h_paths + path_off[pi], paths.data() + items[x].path_end - len, len);
+            memcpy(h_paths + path_off[pi], paths + items[x].path_end - len, len);
         }
         b0 = b1;
     }
