@@ -215,9 +215,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit, AFTER the JSON:
+        # flush it first so that the JSON line is the last line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
