@@ -163,7 +163,7 @@ static DbAlignment* make_db_alignment(Chain* query, int query_idx, Chain* target
     DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
     a->query = query; a->query_idx = query_idx; a->query_start = r.q_start; a->query_end = r.q_end;
     a->target = target; a->target_idx = target_idx; a->target_start = r.t_start; a->target_end = r.t_end;
-    a->score = r.score; a->value = value; a->scorer = scorer;
+    a->score = r.score; a->value = value; a->scorer = swimpl::scorer_retain(scorer);
     a->path_len = (int)r.path.size();
     a->path = (char*)malloc(a->path_len ? a->path_len : 1);
     if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
@@ -184,13 +184,13 @@ SW_API Scorer* dbAlignmentGetScorer(DbAlignment* a) { return a->scorer; }
 SW_API int dbAlignmentGetPathLen(DbAlignment* a) { return a->path_len; }
 SW_API char dbAlignmentGetMove(DbAlignment* a, int index) { return a->path[index]; }
 SW_API void dbAlignmentCopyPath(DbAlignment* a, char* dest) { memcpy(dest, a->path, a->path_len); }
-SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { free(a->path); free(a); } }
+SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { swimpl::scorer_release(a->scorer); free(a->path); free(a); } }
 
 SW_API Alignment* dbAlignmentToAlignment(DbAlignment* d) {
     Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
     a->query = d->query; a->query_start = d->query_start; a->query_end = d->query_end;
     a->target = d->target; a->target_start = d->target_start; a->target_end = d->target_end;
-    a->score = d->score; a->scorer = d->scorer; a->path_len = d->path_len;
+    a->score = d->score; a->scorer = swimpl::scorer_retain(d->scorer); a->path_len = d->path_len;
     a->path = (char*)malloc(d->path_len ? d->path_len : 1);
     if (d->path_len) memcpy(a->path, d->path, d->path_len);
     return a;
@@ -207,7 +207,7 @@ SW_API Scorer* alignmentGetScorer(Alignment* a) { return a->scorer; }
 SW_API int alignmentGetPathLen(Alignment* a) { return a->path_len; }
 SW_API char alignmentGetMove(Alignment* a, int index) { return a->path[index]; }
 SW_API void alignmentCopyPath(Alignment* a, char* dest) { memcpy(dest, a->path, a->path_len); }
-SW_API void alignmentDelete(Alignment* a) { if (a) { free(a->path); free(a); } }
+SW_API void alignmentDelete(Alignment* a) { if (a) { swimpl::scorer_release(a->scorer); free(a->path); free(a); } }
 
 SW_API void alignPair(Alignment** alignment, int type, Chain* query, Chain* target, Scorer* scorer,
                       int* cards, int cardsLen, Thread* thread) {
@@ -218,7 +218,7 @@ SW_API void alignPair(Alignment** alignment, int type, Chain* query, Chain* targ
     Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
     a->query = query; a->query_start = r.q_start; a->query_end = r.q_end;
     a->target = target; a->target_start = r.t_start; a->target_end = r.t_end;
-    a->score = r.score; a->scorer = scorer; a->path_len = (int)r.path.size();
+    a->score = r.score; a->scorer = swimpl::scorer_retain(scorer); a->path_len = (int)r.path.size();
     a->path = (char*)malloc(a->path_len ? a->path_len : 1);
     if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
     *alignment = a;
@@ -333,7 +333,7 @@ static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** que
             a->target = cdb->chains[sv.idx]; a->target_idx = sv.idx;
             a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
             a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
-            a->score = sv.score; a->value = sv.value; a->scorer = scorer;
+            a->score = sv.score; a->value = sv.value; a->scorer = swimpl::scorer_retain(scorer);
             a->path_len = out5[(size_t)x * 5 + 4];
             a->path = (char*)malloc(a->path_len ? a->path_len : 1);
             memcpy(a->path, paths.data() + path_off[x], a->path_len);

@@ -211,7 +211,10 @@ SW_API void scorerCreate(Scorer** scorer, const char* name, int* scores, char ma
     *scorer = s;
 }
 
-SW_API void scorerDelete(Scorer* scorer) { if (scorer) { s4g_scorer_destroy(scorer->dev); delete scorer; } }
+void swimpl::scorer_release(Scorer* s) {
+    if (s && s->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) { s4g_scorer_destroy(s->dev); delete s; }
+}
+SW_API void scorerDelete(Scorer* scorer) { swimpl::scorer_release(scorer); }
 SW_API int scorerGetGapOpen(Scorer* s) { return s->gap_open; }
 SW_API int scorerGetGapExtend(Scorer* s) { return s->gap_extend; }
 SW_API const char* scorerGetName(Scorer* s) { return s->name.c_str(); }

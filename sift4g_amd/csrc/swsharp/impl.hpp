@@ -1,5 +1,6 @@
 // impl.hpp -- internal object layouts of libswsharp (the swsharp-compatible host API, include/swsharp/*.h).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,9 @@ struct Scorer {
     int32_t table[26 * 26];
     int gap_open, gap_extend, max_score;
     s4g_scorer* dev;         // device-side twin (host object inside libs4g_hip)
+    // The reference deletes its scorer BEFORE it writes the alignments (main.cpp:223 then :227), and the alignments'
+    // statistics need the table: every DbAlignment / Alignment holds a reference, scorerDelete drops the caller's.
+    std::atomic<int> refs{1};
 };
 
 struct ChainDatabase {
@@ -84,5 +88,8 @@ struct PairResult {
 };
 // Host Smith-Waterman with traceback (the "traceback of the <= maxAlignments survivors" stage).
 void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc, PairResult* out);
+
+inline Scorer* scorer_retain(Scorer* s) { if (s) s->refs.fetch_add(1, std::memory_order_relaxed); return s; }
+void scorer_release(Scorer* s);    // core.cpp: destroys the scorer with its last reference
 
 }  // namespace swimpl

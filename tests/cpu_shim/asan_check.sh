@@ -1,0 +1,27 @@
+#!/bin/bash
+# Host-side memory check (AddressSanitizer + UBSan; the GPU pool has no sanitizer support, so this runs on the CPU build):
+# libswsharp (the C++ host API), the test-only oracle stand-in for libs4g_hip.so and the reference's unmodified CLI
+# (compiled in place from /root/reference) are built with -fsanitize=address,undefined under build/asan/ and the CLI is
+# run on the reference's fixture; its three outputs must equal tests/golden/dropin_predictions/ and the sanitizers must
+# stay silent (leak check included).  Usage: tests/cpu_shim/asan_check.sh   (needs /root/reference; ~3 min)
+set -euo pipefail
+ROOT=$(cd "$(dirname "$0")/../.." && pwd); cd "$ROOT"
+REF=${REF:-/root/reference}
+B=build/asan; mkdir -p $B/lib $B/out
+SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
+gcc $SAN -std=c11 -fPIC -c oracle/sw_oracle.c -o $B/sw_oracle.o
+g++ $SAN -std=c++17 -fPIC -shared -Iinclude -o $B/lib/libs4g_hip.so tests/cpu_shim/s4g_oracle_shim.cpp $B/sw_oracle.o -lpthread
+g++ $SAN -std=c++17 -fPIC -shared -Iinclude -o $B/lib/libswsharp.so sift4g_amd/csrc/swsharp/core.cpp sift4g_amd/csrc/swsharp/evalue.cpp \
+    sift4g_amd/csrc/swsharp/align.cpp sift4g_amd/csrc/swsharp/output.cpp -L$B/lib -ls4g_hip -lpthread
+g++ $SAN -std=c++11 -w -Iinclude -o $B/sift4g $REF/sift4g/src/*.cpp -L$B/lib -lswsharp -ls4g_hip -lpthread -lm
+g++ $SAN -std=c++17 -Iinclude -o $B/shotgun_demo tools/shotgun_demo.cpp -L$B/lib -lswsharp -ls4g_hip -lpthread
+F=tests/golden/test_files
+rm -f $B/out/*
+LD_LIBRARY_PATH=$B/lib $B/sift4g -q $F/query.fasta --subst $F/ -d $F/sample_protein_database.fa --cards 0 --out $B/out --sub-results \
+    > $B/out/stdout.txt 2> $B/out/stderr.txt
+for f in LACI_ECOLI.SIFTprediction PURR_SALTY.SIFTprediction alignments.txt; do cmp $B/out/$f tests/golden/dropin_predictions/$f; done
+for ev in 0 1; do      # the batched entry points: callback selection and e-value driven selection
+    LD_LIBRARY_PATH=$B/lib $B/shotgun_demo $F/query.fasta $F/sample_protein_database.fa 400 1e-4 4 $ev > $B/out/shotgun_$ev.txt 2>> $B/out/stderr.txt
+done
+if grep -q "Sanitizer\|runtime error" $B/out/stderr.txt; then grep -m5 "Sanitizer\|runtime error" $B/out/stderr.txt; exit 1; fi
+echo "asan_check: clean, outputs identical to tests/golden/dropin_predictions"

@@ -49,7 +49,7 @@ SIG = {
     "dbAlignmentGetTargetStart": (ci, [vp]), "dbAlignmentGetTargetEnd": (ci, [vp]),
     "dbAlignmentGetScore": (ci, [vp]), "dbAlignmentGetValue": (cd, [vp]),
     "dbAlignmentGetPathLen": (ci, [vp]), "dbAlignmentGetMove": (cc, [vp, ci]),
-    "dbAlignmentToAlignment": (vp, [vp]), "dbAlignmentDelete": (None, [vp]),
+    "dbAlignmentToAlignment": (vp, [vp]), "dbAlignmentDelete": (None, [vp]), "dbAlignmentGetScorer": (vp, [vp]),
     "dbAlignmentsMerge": (None, [ctypes.POINTER(pvp), pi, ctypes.POINTER(pvp), pi, ci, ci]),
     "deleteShotgunDatabase": (None, [ctypes.POINTER(pvp), pi, ci]),
     "outputShotgunDatabase": (None, [ctypes.POINTER(pvp), pi, ci, ctypes.c_char_p, ci]),

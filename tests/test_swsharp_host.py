@@ -157,6 +157,33 @@ def test_selection_sorting_threshold_and_paths(oracle_mod, blosum62, cfg1):
     L.scorerDelete(s)
 
 
+def test_alignments_outlive_the_callers_scorer(cfg1):
+    """The reference deletes its scorer (main.cpp:223) BEFORE it writes --sub-results (main.cpp:227); the writer needs the
+    table for the "positives" column, so alignments keep the scorer alive (found by tests/cpu_shim/asan_check.sh)."""
+    s = sw.scorer(10, 1)
+    targets = [sw.chain(n, c) for n, c in cfg1["targets"]]
+    qn, qc = cfg1["queries"][0]
+    q = sw.chain(qn, qc)
+    out, n = _lists_from_scores(q, targets, cfg1["scores"][0], s, 400, 1e-4, 3091)
+    lens = (ci * 1)(n.value); outer = (pvp * 1)(out)
+    ref_path = f"/tmp/s4g_life_{os.getpid()}_a.txt".encode(); late_path = f"/tmp/s4g_life_{os.getpid()}_b.txt".encode()
+    L.outputShotgunDatabase(outer, lens, 1, ref_path, 0)
+    L.scorerDelete(s)
+    churn = [sw.scorer(11 + i, 1) for i in range(8)]          # would recycle the freed block if the alignments did not own a reference
+    assert L.scorerGetGapOpen(L.dbAlignmentGetScorer(out[0])) == 10
+    L.outputShotgunDatabase(outer, lens, 1, late_path, 0)
+    assert open(ref_path, "rb").read() == open(late_path, "rb").read()
+    os.remove(ref_path); os.remove(late_path)
+    for c in churn:
+        L.scorerDelete(c)
+    for k in range(n.value):
+        L.dbAlignmentDelete(out[k])
+    sw.libc.free(out)
+    L.chainDelete(q)
+    for t in targets:
+        L.chainDelete(t)
+
+
 def test_merge_of_chunks_equals_whole(oracle_mod, blosum62):
     """dbAlignmentsMerge across database chunks (database_alignment.cpp:97-104) == one pass over the whole set."""
     rng = np.random.default_rng(9)
