@@ -42,7 +42,7 @@ class Scorer:
               "s4g_scorer_create")
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # module globals are already cleared at interpreter exit
             lib.s4g_scorer_destroy(self._h)
             self._h = None
 
