@@ -169,14 +169,28 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
         const double t_pack0 = now_s();
         std::vector<uint64_t> src_off((size_t)G * 64, 0);
         std::vector<uint32_t> src_len((size_t)G * 64, 0);
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t id = order[p0 + k];
-            perm_g[k] = id;
-            perm_l[k] = rank_of(id);
-            src_off[k] = offsets[id];
-            src_len[k] = db->len[id];
-            t.residues += db->len[id];
+        // random gathers over the whole id range: split over host threads when the tile is large
+        const unsigned nth = n >= (1u << 18) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+        std::vector<uint64_t> part_res(nth, 0);
+        auto gather = [&](unsigned w) {
+            uint64_t r = 0;
+            for (uint32_t k = (uint32_t)((uint64_t)n * w / nth), k1 = (uint32_t)((uint64_t)n * (w + 1) / nth); k < k1; ++k) {
+                const uint32_t id = order[p0 + k];
+                perm_g[k] = id;
+                perm_l[k] = rank_of(id);
+                src_off[k] = offsets[id];
+                src_len[k] = db->len[id];
+                r += db->len[id];
+            }
+            part_res[w] = r;
+        };
+        if (nth == 1) gather(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned w = 0; w < nth; ++w) th.emplace_back(gather, w);
+            for (auto& x : th) x.join();
         }
+        for (uint64_t r : part_res) t.residues += r;
         const double t_up0 = now_s();
         g_create_clock.t[1] += t_up0 - t_pack0;
         struct UpTimer { double t0; ~UpTimer() { g_create_clock.t[2] += now_s() - t0; } } up_timer{t_up0};
