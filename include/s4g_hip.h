@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_scattered / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -93,6 +93,11 @@ int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const uint64_t
  * the length-sorted order; tiles bound the strip-boundary workspace and the s4g_scan_topk score buffer. */
 int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
                         uint32_t max_tile_seqs);
+
+/* The same for sequences held as separate host arrays (what a Chain*[] is: sift4g builds one candidate database per
+ * query out of chains it already holds, /root/reference/sift4g/src/database_alignment.cpp:136-162 then :80): seqs[i]
+ * points at the lens[i] residue codes of target i.  Saves the caller the concatenation. */
+int s4g_db_create_scattered(s4g_db** out, int device, const uint8_t* const* seqs, const uint32_t* lens, uint32_t n_seqs);
 
 /* The same for residue codes and offsets that already live on `device` (a database generated, decompressed or
  * received there): only the n_seqs+1 offsets come back to the host (length sort, tile cuts); the codes are

@@ -39,6 +39,7 @@ SIGNATURES = {
     "s4g_scorer_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "s4g_db_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32]),
     "s4g_db_create_tiled": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_uint32]),
+    "s4g_db_create_scattered": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_u32p, ctypes.c_uint32]),
     "s4g_db_create_from_device": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
     "s4g_db_tiles": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.c_uint32]),
     "s4g_db_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),

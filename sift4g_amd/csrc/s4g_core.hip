@@ -127,7 +127,8 @@ void free_tile(Tile& t, DeviceCtx* cx) {
 // collects its validity flag (checked by the caller after the last tile).
 hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, size_t p0, size_t p1,
                       const uint8_t* codes, const uint64_t* offsets, std::string* err, uint64_t extra_bytes = 0,
-                      uint64_t* extra_off = nullptr, const uint8_t* d_raw = nullptr, int* d_bad = nullptr) {
+                      uint64_t* extra_off = nullptr, const uint8_t* d_raw = nullptr, int* d_bad = nullptr,
+                      const uint8_t* const* seq_ptrs = nullptr) {
     const uint32_t n = (uint32_t)(p1 - p0);
     const uint32_t G = (n + 63) / 64;
     t.n_seqs = n; t.n_groups = G;
@@ -242,7 +243,7 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
                 const uint32_t id = order[p0 + (size_t)g * 64 + lane];
                 perm_g[(size_t)g * 64 + lane] = id;
                 perm_l[(size_t)g * 64 + lane] = rank_of(id);
-                const uint8_t* src = codes + offsets[id];
+                const uint8_t* src = seq_ptrs ? seq_ptrs[id] : codes + offsets[id];
                 const uint32_t l = db->len[id];
                 // four residues per dword; a byte >= 26 anywhere is an error (SWAR test: bit 7 of b | ((b & 0x7F) + 102))
                 uint32_t c4 = 0, any_bad = 0;
@@ -346,8 +347,29 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
 
 
 // codes: host copy of the residues, or NULL when d_codes (device copy, caller-owned) is given
+// seq_ptrs / seq_lens: the sequences as separate host arrays (small databases only; codes and offsets are NULL then)
 int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t* d_codes, const uint64_t* offsets, uint32_t n_seqs,
-                   uint32_t max_tile_seqs);
+                   uint32_t max_tile_seqs, const uint8_t* const* seq_ptrs = nullptr, const uint32_t* seq_lens = nullptr);
+
+constexpr uint64_t kDevicePackMin = 8ull << 20;     // residues from which the lane transposition runs on the device
+
+S4G_API int s4g_db_create_scattered(s4g_db** out, int device, const uint8_t* const* seqs, const uint32_t* lens, uint32_t n_seqs) {
+    if (!out || (n_seqs && (!seqs || !lens))) return fail(S4G_ERR_INVALID, "NULL argument");
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        if (lens[i] && !seqs[i]) return fail(S4G_ERR_INVALID, "NULL sequence at %u", i);
+        total += lens[i];
+    }
+    if (total < kDevicePackMin) return db_create_impl(out, device, nullptr, nullptr, nullptr, n_seqs, 0, seqs, lens);
+    // large: one contiguous copy, then the regular path (raw upload + device packing)
+    std::vector<uint8_t> codes(total);
+    std::vector<uint64_t> off((size_t)n_seqs + 1, 0);
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        if (lens[i]) memcpy(codes.data() + off[i], seqs[i], lens[i]);
+        off[i + 1] = off[i] + lens[i];
+    }
+    return db_create_impl(out, device, codes.data(), nullptr, off.data(), n_seqs, 0);
+}
 
 S4G_API int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_seqs,
                                 uint32_t max_tile_seqs) {
@@ -368,7 +390,7 @@ S4G_API int s4g_db_create_from_device(s4g_db** out, int device, const uint8_t* d
 }
 
 int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t* d_codes, const uint64_t* offsets, uint32_t n_seqs,
-                   uint32_t max_tile_seqs) {
+                   uint32_t max_tile_seqs, const uint8_t* const* seq_ptrs, const uint32_t* seq_lens) {
     int have = device_count_raw();
     if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
     if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
@@ -381,10 +403,12 @@ int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t
     db->n_seqs = n_seqs;
     db->len.resize(n_seqs);
     const double t_begin = now_s();
+    uint64_t total_res = 0;
     for (uint32_t i = 0; i < n_seqs; ++i) {
-        uint64_t l = offsets[i + 1] - offsets[i];
-        if (offsets[i + 1] < offsets[i] || l > 0x7FFFFFF0ull) { delete db; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
+        uint64_t l = seq_ptrs ? seq_lens[i] : offsets[i + 1] - offsets[i];
+        if ((!seq_ptrs && offsets[i + 1] < offsets[i]) || l > 0x7FFFFFF0ull) { delete db; return fail(S4G_ERR_INVALID, "bad offsets at %u", i); }
         db->len[i] = (uint32_t)l;
+        total_res += l;
     }
     // length sort, longest first (ties by original index): items are issued in this order so the longest
     // work runs first and the tail of every launch is short work.
@@ -409,11 +433,10 @@ int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t
     // Databases from 8 MB to 16 GB of residues are transposed on the device: one upload of the raw codes, then one
     // sw_pack_tile launch per tile.  Smaller ones are packed by the host (a launch and two allocations would cost more
     // than they save); larger ones tile by tile on the host, so that the raw copy never doubles the footprint.
-    const uint64_t total_res = n_seqs ? offsets[n_seqs] : 0;
     DevBuf<uint8_t> d_raw;
     DevBuf<int> d_bad;
     const uint8_t* raw_dev = d_codes;       // codes that already live on the device are packed there whatever their size
-    if (d_codes || (total_res >= (8ull << 20) && total_res <= (16ull << 30))) {
+    if (d_codes || (!seq_ptrs && total_res >= kDevicePackMin && total_res <= (16ull << 30))) {
         const double t_raw = now_s();
         hipError_t e1 = hipSuccess;
         if (!d_codes) {
@@ -449,7 +472,7 @@ int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t
         const bool whole = (p == 0 && q == n_seqs);
         uint64_t tab_off = 0;
         hipError_t e = build_tile(db, db->tiles.back(), order, p, q, codes, offsets, &err, whole ? (uint64_t)n_seqs * 12 + 512 : 0, &tab_off,
-                                  raw_dev, d_bad.p);
+                                  raw_dev, d_bad.p, seq_ptrs);
         if (e != hipSuccess) {
             std::string msg = err.empty() ? std::string(hipGetErrorString(e)) : err;
             s4g_db_destroy(db);

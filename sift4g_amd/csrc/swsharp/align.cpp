@@ -134,14 +134,21 @@ SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, i
     db->device = pick_device(cards, cardsLen);
     db->dev = NULL;
     if (cards && cardsLen > 0) db->cards.assign(cards, cards + cardsLen); else db->cards.assign(1, 0);
-    std::vector<uint8_t> codes; std::vector<uint64_t> off;
-    flatten(db->chains, databaseLen, codes, off);
-    db->residues = (long long)off[databaseLen];
+    // the chains stay where they are: the device library packs straight out of their code arrays
+    std::vector<const uint8_t*> seqs((size_t)databaseLen);
+    std::vector<uint32_t> lens((size_t)databaseLen);
+    db->residues = 0;
+    for (int i = 0; i < databaseLen; ++i) {
+        SW_ASSERT(db->chains[i] != NULL, "NULL chain at index %d", i);
+        seqs[i] = reinterpret_cast<const uint8_t*>(chainGetCodes(db->chains[i]));
+        lens[i] = (uint32_t)chainGetLength(db->chains[i]);
+        db->residues += lens[i];
+    }
     // one resident replica per card: queries are split across the cards (the reference hands its `cards` list through
     // chainDatabaseCreate and alignDatabase for the same purpose, database_alignment.cpp:80-86)
     for (int card : db->cards) {
         s4g_db* rep = NULL;
-        int rc = s4g_db_create(&rep, card, codes.data(), off.data(), (uint32_t)databaseLen);
+        int rc = s4g_db_create_scattered(&rep, card, seqs.data(), lens.data(), (uint32_t)databaseLen);
         if (rc != S4G_OK)
             SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", card, s4g_last_error());
         db->replicas.push_back(rep);

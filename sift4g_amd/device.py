@@ -108,6 +108,22 @@ class Database(_SeqSet):
         return self
 
     @classmethod
+    def from_arrays(cls, seqs, device=0):
+        """seqs: list of separate uint8 code arrays, one per target (s4g_db_create_scattered: what chainDatabaseCreate passes)."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in seqs]
+        ptrs = (ctypes.c_void_p * max(len(arrs), 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = np.array([a.size for a in arrs], dtype=np.uint32)
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.device = device
+        check(lib.s4g_db_create_scattered(ctypes.byref(self._h), device, ptrs, _ptr(lens, c_u32p), len(arrs)), "s4g_db_create_scattered")
+        self.n = len(arrs)
+        self.codes = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8)
+        self.offsets = np.concatenate([[0], np.cumsum(lens, dtype=np.uint64)]).astype(np.uint64)
+        self.lengths = lens.astype(np.int64)
+        return self
+
+    @classmethod
     def from_device(cls, codes, offsets, tile_seqs=0):
         """codes: torch uint8 tensor on the GPU (one byte per residue, sequences back to back); offsets: torch int64 tensor
         [n+1] on the same GPU.  Only the offsets travel to the host; the codes are packed where they are."""

@@ -745,6 +745,41 @@ def test_database_from_device_resident_codes(s4g, oracle_mod, blosum62, scorer):
         s4g.Database.from_device(bad.cpu(), torch.tensor([0, 10], dtype=torch.int64))
 
 
+def test_database_from_separate_arrays(s4g, oracle_mod, blosum62, scorer):
+    """s4g_db_create_scattered (what chainDatabaseCreate passes: one code array per chain): same scores, pair scores and
+    alignments as the contiguous form, with empty sequences, for a small database (host-packed out of the arrays) and one
+    beyond the device-packing threshold; bad codes and NULL arguments are refused."""
+    MOVE = {0: 1, 1: 2, 2: 3}
+    rng = np.random.default_rng(52)
+    qs = rand_seqs(rng, 3, 40, 330, 26)
+    q = s4g.QuerySet(qs)
+    for nt, lo, hi in ((900, 0, 500), (1, 7, 7), (0, 0, 0), (9000, 900, 1100)):
+        ts = rand_seqs(rng, nt, lo, hi, 26) if nt else []
+        if nt > 2:
+            ts[2] = qs[1][5:].copy()
+        db = s4g.Database.from_arrays(ts)
+        assert db.n == nt and db.info()["residues"] == sum(len(t) for t in ts)
+        if nt == 0:
+            continue
+        ref = s4g.Database(ts)
+        exp = s4g.scan_host(ref, q, scorer, no_pairs=True)
+        if nt <= 900:
+            assert np.array_equal(exp, oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8))
+        for mode in (dict(no_pairs=True), dict()):
+            assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp), (nt, mode)
+        pt = rng.integers(0, nt, size=200).astype(np.uint32)
+        pq = rng.integers(0, 3, size=200).astype(np.uint32)
+        assert np.array_equal(s4g.score_pairs(db, q, scorer, pq, pt), exp[pq, pt])
+        if nt > 2:
+            r = s4g.traceback(db, q, scorer, [1], [2], [int(exp[1, 2])])[0]
+            o = oracle_mod.sw_align(qs[1], ts[2], blosum62, 10, 1)
+            assert r["score"] == o["score"] and r["path"].tolist() == [MOVE[m] for m in o["path"]]
+    bad = rand_seqs(rng, 10, 5, 50, 26)
+    bad[4][3] = 26
+    with pytest.raises(RuntimeError):
+        s4g.Database.from_arrays(bad)
+
+
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
     """sw_pair_scan_band: queries of 1025 .. 5000 residues (2 to 5 bands of 1024 rows, partial last bands of 1 row and of
     1023 rows), alignments that cross band boundaries, targets across window boundaries, three scorers, and the scan
