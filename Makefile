@@ -44,6 +44,16 @@ dropin: $(LIBDIR)/libswsharp.so
 	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -o build/dropin/sift4g $(REF)/sift4g/src/*.cpp \
 	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
+# The same with ONE source file of the reference replaced: its alignment wrapper (database_alignment.cpp: one scorer call per
+# query and chunk) by sift4g_amd/csrc/dropin/batched_database_alignment.cpp (one scoring and one traceback submission per
+# chunk for all queries).  Everything else -- main, prefilter, selection, SIFT -- is the reference's own code, unmodified.
+dropin-batched: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/batched_database_alignment.cpp
+	@test -d $(REF)/sift4g/src || { echo "no reference tree at $(REF): skipping drop-in build"; exit 0; }
+	@mkdir -p build/dropin
+	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -I$(REF)/sift4g/src -o build/dropin/sift4g_batched \
+	    $(filter-out %/database_alignment.cpp,$(wildcard $(REF)/sift4g/src/*.cpp)) sift4g_amd/csrc/dropin/batched_database_alignment.cpp \
+	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
 oracle:
 	$(MAKE) -s -C oracle
 
@@ -55,4 +65,4 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean dropin
+.PHONY: all oracle isa clean dropin dropin-batched

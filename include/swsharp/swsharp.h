@@ -97,6 +97,17 @@ void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int t
                      void* valueFunctionParam, double valueThreshold, int* indexes, int indexesLen,
                      int* cards, int cardsLen, Thread* thread);
 
+/* shotgunDatabase with one candidate list PER QUERY (new): candidates[i][0..candidatesLens[i]) index the ChainDatabase.
+ * For query i the result is what alignDatabase(query i, chainDatabaseCreate of exactly those chains, ...) returns -- same
+ * alignments, values and order -- except that dbAlignmentGetTargetIdx is the index into THIS ChainDatabase.  It collapses
+ * the wrapper's whole per-query loop (createFilteredDatabase + chainDatabaseCreate + alignDatabase per query,
+ * database_alignment.cpp:61-95) into one scoring launch and one traceback launch per database chunk while keeping the
+ * prefilter's semantics: only the candidates are scored.  A NULL or empty list gives that query no alignments. */
+void shotgunDatabaseCandidates(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                               ChainDatabase* chainDatabase, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
+                               void* valueFunctionParam, double valueThreshold, int** candidates, int* candidatesLens,
+                               int* cards, int cardsLen, Thread* thread);
+
 /* shotgunDatabase for the case sift4g actually runs -- valueFunction = eValues (database_alignment.cpp:129-134): the same
  * alignments, but the library knows the value function, so only the per-query top hits ever leave the device (a
  * conservative integer score cut per query + exact streaming top-k on the GPU, exact double e-values on the host with an

@@ -1,0 +1,135 @@
+// batched_database_alignment.cpp -- MI355X replacement for the reference's alignment wrapper.
+//
+// Defines the function `alignDatabase(...)` that sift4g's main.cpp:218 calls, with the signature the reference declares in
+// /root/reference/sift4g/src/database_alignment.hpp:18-23, so a maintainer swaps ONE source file: compile the reference's
+// sources without its database_alignment.cpp and with this file (Makefile target `dropin-batched`).
+//
+// What it keeps (reference database_alignment.cpp:21-127): the database is streamed in ~1 GB chunks; a query is aligned
+// only with its prefilter candidates (`indices[i]`, sorted ids, the consumed prefix is removed); per-chunk results are
+// merged with dbAlignmentsMerge; chains that appear in no alignment are deleted and their slots set to NULL; the
+// surviving `database` array is handed back.  Same banner and progress lines on stderr.
+//
+// What it changes: the reference builds a filtered database and calls the scorer once PER QUERY and chunk
+// (:61-95: createFilteredDatabase -> chainDatabaseCreate -> alignDatabase -> chainDatabaseDelete).  Here the candidates of
+// ALL queries inside a chunk form one ChainDatabase (each chain uploaded once, however many queries list it) and one
+// shotgunDatabaseCandidates call scores every (query, candidate) pair and traces every survivor back: two device
+// submissions per chunk instead of two per query.  The alignments are identical (tests/test_gpu_swsharp.py compares the
+// two builds' outputs byte for byte).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "utils.hpp"                   // the reference's own: databaseLog
+#include "database_alignment.hpp"      // the reference's own: the declaration this file implements
+
+namespace {
+
+const size_t kChunkBytes = 1000000000;      // ~1 GB of FASTA per part, as the reference reads it
+
+void evalue_callback(double* values, int* scores, Chain* query, Chain** database, int databaseLen, int* cards, int cardsLen,
+                     void* param) {
+    eValues(values, scores, query, database, databaseLen, cards, cardsLen, static_cast<EValueParams*>(param));
+}
+
+// The candidates of one chunk: the union of all queries' ids below `end`, and every query's list as positions in it.
+struct ChunkCandidates {
+    std::vector<uint32_t> ids;               // sorted, unique global ids
+    std::vector<std::vector<int>> lists;     // per query: positions into `ids`
+
+    ChunkCandidates(std::vector<std::vector<uint32_t>>& indices, uint32_t end) : lists(indices.size()) {
+        std::vector<size_t> taken(indices.size(), 0);
+        for (size_t q = 0; q < indices.size(); ++q) {
+            const std::vector<uint32_t>& v = indices[q];
+            size_t n = 0;
+            while (n < v.size() && v[n] < end) ++n;
+            taken[q] = n;
+            ids.insert(ids.end(), v.begin(), v.begin() + n);
+        }
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        for (size_t q = 0; q < indices.size(); ++q) {
+            std::vector<uint32_t>& v = indices[q];
+            lists[q].reserve(taken[q]);
+            for (size_t k = 0; k < taken[q]; ++k)
+                lists[q].push_back((int)(std::lower_bound(ids.begin(), ids.end(), v[k]) - ids.begin()));
+            v.erase(v.begin(), v.begin() + taken[q]);           // consumed, like the reference's createFilteredDatabase
+        }
+    }
+};
+
+}  // namespace
+
+void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain*** database_out, int32_t* database_length_out,
+                   const std::string& database_path, Chain** queries, int32_t queries_length,
+                   std::vector<std::vector<uint32_t>>& indices, int32_t algorithm, EValueParams* evalue_params, double max_evalue,
+                   uint32_t max_alignments, Scorer* scorer, int32_t* cards, int32_t cards_length) {
+    fprintf(stderr, "** Aligning queries with candidate sequences **\n");
+
+    Chain** database = nullptr;
+    int database_length = 0;
+    FILE* handle = nullptr;
+    int serialized = 0;
+    readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
+
+    const float part_gb = kChunkBytes / 1e9f;
+    int chunk_begin = 0;
+    for (uint32_t part = 1;; ++part) {
+        const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunkBytes);
+        databaseLog(part, part_gb, 0);
+
+        ChunkCandidates cand(indices, (uint32_t)database_length);
+        std::vector<Chain*> pool(cand.ids.size());
+        for (size_t k = 0; k < pool.size(); ++k) pool[k] = database[cand.ids[k]];
+
+        DbAlignment*** found = nullptr;
+        int* found_lengths = nullptr;
+        if (pool.empty()) {          // nothing to align in this part: empty lists, malloc domain like the library's
+            found = (DbAlignment***)calloc(queries_length ? queries_length : 1, sizeof(DbAlignment**));
+            found_lengths = (int*)calloc(queries_length ? queries_length : 1, sizeof(int));
+        } else {
+            ChainDatabase* chunk_db = chainDatabaseCreate(pool.data(), 0, (int)pool.size(), cards, cards_length);
+            std::vector<int*> list_ptrs(queries_length);
+            std::vector<int> list_lens(queries_length);
+            for (int32_t q = 0; q < queries_length; ++q) {
+                list_ptrs[q] = cand.lists[q].empty() ? nullptr : cand.lists[q].data();
+                list_lens[q] = (int)cand.lists[q].size();
+            }
+            databaseLog(part, part_gb, 50);
+            shotgunDatabaseCandidates(&found, &found_lengths, algorithm, queries, queries_length, chunk_db, scorer,
+                                      (int)max_alignments, evalue_callback, evalue_params, max_evalue, list_ptrs.data(),
+                                      list_lens.data(), cards, cards_length, nullptr);
+            chainDatabaseDelete(chunk_db);
+        }
+
+        // chains that carry an alignment stay alive (DbAlignment borrows them); the rest of this part goes
+        std::vector<char> in_use(pool.size(), 0);
+        for (int32_t q = 0; q < queries_length; ++q)
+            for (int k = 0; k < found_lengths[q]; ++k) in_use[dbAlignmentGetTargetIdx(found[q][k])] = 1;
+        std::vector<char> keep_chain((size_t)(database_length - chunk_begin), 0);
+        for (size_t k = 0; k < pool.size(); ++k)
+            if (in_use[k]) keep_chain[cand.ids[k] - (uint32_t)chunk_begin] = 1;
+
+        if (*alignments == nullptr) {
+            *alignments = found;
+            *alignments_lengths = found_lengths;
+        } else {
+            dbAlignmentsMerge(*alignments, *alignments_lengths, found, found_lengths, queries_length, (int)max_alignments);
+            deleteShotgunDatabase(found, found_lengths, queries_length);
+        }
+        for (int i = chunk_begin; i < database_length; ++i)
+            if (!keep_chain[i - chunk_begin] && database[i] != nullptr) {
+                chainDelete(database[i]);
+                database[i] = nullptr;
+            }
+
+        databaseLog(part, part_gb, 100);
+        if (!more) break;
+        chunk_begin = database_length;
+    }
+    fprintf(stderr, "\n\n");
+    fclose(handle);
+    *database_out = database;
+    *database_length_out = database_length;
+}

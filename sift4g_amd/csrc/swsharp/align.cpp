@@ -476,6 +476,124 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
     for (std::thread& w : workers) w.join();
 }
 
+// ------------------------------------------------------------------------------------------------ per-query candidate lists
+// Queries [q0, q1) on one card: all their (query, candidate) pairs in one device call per batch, selection per query on the
+// pool, one device traceback per batch.
+static void candidates_on_card(DbAlignment*** out_all, int* out_lens, Chain** all_queries, int q0, int q1, ChainDatabase* cdb,
+                               int card_slot, Scorer* scorer, int maxAlignments, ValueFunction valueFunction, void* valueFunctionParam,
+                               double valueThreshold, int** candidates, int* candidatesLens) {
+    Chain** queries = all_queries + q0;
+    const int queriesLen = q1 - q0;
+    if (queriesLen <= 0) return;
+    const int device = cdb->cards[card_slot];
+    s4g_db* ddb = cdb->replicas[card_slot];
+    std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
+    flatten(queries, queriesLen, qcodes, qoff);
+    s4g_queries* dq = NULL;
+    {
+        Phase ph(1);
+        if (s4g_queries_create(&dq, device, qcodes.data(), qoff.data(), (uint32_t)queriesLen) != S4G_OK)
+            SW_FATAL("cannot place the queries on MI355X device %d: %s", device, s4g_last_error());
+    }
+    auto n_cand = [&](int i) { return (candidates[q0 + i] && candidatesLens[q0 + i] > 0) ? candidatesLens[q0 + i] : 0; };
+    struct SelectJob {
+        Chain* query; std::vector<Chain*> targets; const int32_t* row; int maxAlignments;
+        ValueFunction vf; void* vfp; double thr; std::vector<Survivor> keep;
+    };
+    auto select_task = [](void* p) -> void* {
+        SelectJob* jb = (SelectJob*)p;
+        select_survivors(jb->keep, jb->query, jb->targets.data(), (int)jb->targets.size(), jb->row, jb->maxAlignments, jb->vf, jb->vfp, jb->thr);
+        return NULL;
+    };
+    const uint64_t kBatchPairs = 1ull << 25;          // bounds the host pair arrays to ~0.4 GB
+    std::vector<uint32_t> pq, pt;
+    std::vector<int32_t> scores;
+    for (int b = 0; b < queriesLen;) {
+        int e = b;
+        uint64_t pairs = 0;
+        while (e < queriesLen && (e == b || pairs + (uint64_t)n_cand(e) <= kBatchPairs)) pairs += (uint64_t)n_cand(e++);
+        const uint32_t cnt = (uint32_t)(e - b);
+        pq.resize(pairs); pt.resize(pairs); scores.resize(pairs ? pairs : 1);
+        std::vector<uint64_t> row0(cnt + 1, 0);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int n = n_cand(b + (int)i);
+            const int* list = candidates[q0 + b + (int)i];
+            for (int k = 0; k < n; ++k) {
+                SW_ASSERT(list[k] >= 0 && list[k] < cdb->length, "candidate index %d out of range", list[k]);
+                pq[row0[i] + k] = (uint32_t)b + i;
+                pt[row0[i] + k] = (uint32_t)list[k];
+            }
+            row0[i + 1] = row0[i] + (uint64_t)n;
+        }
+        if (pairs) {
+            Phase ph(2);
+            if (s4g_score_pairs_host(ddb, dq, scorer->dev, pairs, pq.data(), pt.data(), scores.data(), 0) != S4G_OK)
+                SW_FATAL("Smith-Waterman scoring failed on MI355X device %d: %s", device, s4g_last_error());
+        }
+        Phase* ph_sel = new Phase(3);
+        std::vector<SelectJob> sel(cnt);
+        std::vector<ThreadPoolTask*> tasks(cnt, NULL);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int n = n_cand(b + (int)i);
+            if (n == 0) continue;
+            const int* list = candidates[q0 + b + (int)i];
+            sel[i].query = queries[b + i]; sel[i].row = scores.data() + row0[i]; sel[i].maxAlignments = maxAlignments;
+            sel[i].vf = valueFunction; sel[i].vfp = valueFunctionParam; sel[i].thr = valueThreshold;
+            sel[i].targets.resize(n);
+            for (int k = 0; k < n; ++k) sel[i].targets[k] = cdb->chains[list[k]];
+            tasks[i] = threadPoolSubmit(select_task, &sel[i]);
+        }
+        std::vector<std::vector<Survivor>> keep(cnt);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            if (!tasks[i]) continue;
+            threadPoolTaskWait(tasks[i]);
+            threadPoolTaskDelete(tasks[i]);
+            keep[i].swap(sel[i].keep);
+            const int* list = candidates[q0 + b + (int)i];
+            for (Survivor& sv : keep[i]) sv.idx = list[sv.idx];        // position in the list -> index into the ChainDatabase
+        }
+        delete ph_sel;
+        trace_and_build(out_all + q0 + b, out_lens + q0 + b, queries + b, q0 + b, (uint32_t)b, cnt, keep, cdb, ddb, dq, device, scorer);
+        b = e;
+    }
+    s4g_queries_destroy(dq);
+}
+
+SW_API void shotgunDatabaseCandidates(DbAlignment**** dbAlignments, int** dbAlignmentsLens, int type, Chain** queries, int queriesLen,
+                                      ChainDatabase* cdb, Scorer* scorer, int maxAlignments, ValueFunction valueFunction,
+                                      void* valueFunctionParam, double valueThreshold, int** candidates, int* candidatesLens,
+                                      int* cards, int cardsLen, Thread* thread) {
+    (void)cards; (void)cardsLen; (void)thread;
+    SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
+    SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0 && (queriesLen == 0 || (candidates && candidatesLens)),
+              "shotgunDatabaseCandidates: invalid arguments");
+    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    if (queriesLen == 0 || cdb->length == 0) return;
+    // query-shard over the cards, balanced in (query residues x candidates)
+    const int n_cards = std::min<int>((int)cdb->cards.size(), queriesLen);
+    std::vector<int> cut(n_cards + 1, 0);
+    auto weight = [&](int i) { return (long long)chainGetLength(queries[i]) * (candidates[i] && candidatesLens[i] > 0 ? candidatesLens[i] : 0) + 1; };
+    long long total = 0, acc = 0;
+    for (int i = 0; i < queriesLen; ++i) total += weight(i);
+    for (int i = 0, c = 1; i < queriesLen && c < n_cards; ++i) {
+        acc += weight(i);
+        while (c < n_cards && acc * n_cards >= total * c) cut[c++] = i + 1;
+    }
+    cut[n_cards] = queriesLen;
+    for (int c = 1; c <= n_cards; ++c) cut[c] = std::max(cut[c], cut[c - 1]);
+    if (n_cards == 1) {
+        candidates_on_card(*dbAlignments, *dbAlignmentsLens, queries, 0, queriesLen, cdb, 0, scorer, maxAlignments, valueFunction,
+                           valueFunctionParam, valueThreshold, candidates, candidatesLens);
+        return;
+    }
+    std::vector<std::thread> workers;
+    for (int c = 0; c < n_cards; ++c)
+        workers.emplace_back(candidates_on_card, *dbAlignments, *dbAlignmentsLens, queries, cut[c], cut[c + 1], cdb, c, scorer,
+                             maxAlignments, valueFunction, valueFunctionParam, valueThreshold, candidates, candidatesLens);
+    for (std::thread& w : workers) w.join();
+}
+
 // ------------------------------------------------------------------------------------------------ e-value driven selection
 // shotgunDatabaseEValues: the same result as shotgunDatabase(..., valueFunction = eValues, param = eValueParams, ...), but
 // the library knows the value function, so nothing of size Q x N ever leaves the device:

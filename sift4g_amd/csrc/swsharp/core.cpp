@@ -29,26 +29,53 @@ static Chain* make_chain(ChainData* d, int start, int length, bool reverse) {
 SW_API char scorerEncode(char c) { return (char)(toupper((unsigned char)c) - 'A'); }
 SW_API char scorerDecode(char c) { return (char)(c + 'A'); }
 
-SW_API Chain* chainCreate(char* name, int nameLen, char* string, int stringLen) {
-    SW_ASSERT(name != NULL && string != NULL && nameLen >= 0 && stringLen >= 0, "chainCreate: invalid arguments");
-    ChainData* d = (ChainData*)calloc(1, sizeof(ChainData));
-    d->name = (char*)malloc(nameLen + 1);
+// ChainData, its name, its letters and its codes are ONE allocation (a database is millions of chains).
+// kResidueCode: letters (either case) -> 0..25, everything else (digits, '*', '-', blanks) -> 0xFF = dropped.
+namespace {
+struct ResidueTable {
+    unsigned char code[256];
+    ResidueTable() {
+        for (int c = 0; c < 256; ++c) code[c] = 0xFF;
+        for (int c = 'A'; c <= 'Z'; ++c) { code[c] = (unsigned char)(c - 'A'); code[c - 'A' + 'a'] = (unsigned char)(c - 'A'); }
+    }
+};
+const ResidueTable kResidue;
+
+ChainData* chain_data_alloc(const char* name, size_t nameLen, size_t seqCap) {
+    char* block = (char*)malloc(sizeof(ChainData) + nameLen + 1 + 2 * (seqCap + 1));
+    SW_ASSERT(block != NULL, "out of memory");
+    ChainData* d = (ChainData*)block;
+    d->name = block + sizeof(ChainData);
+    d->chars = d->name + nameLen + 1;
+    d->codes = d->chars + seqCap + 1;
+    d->length = 0; d->refs = 0;
     memcpy(d->name, name, nameLen);
     d->name[nameLen] = 0;
-    d->chars = (char*)malloc(stringLen + 1);
-    d->codes = (char*)malloc(stringLen + 1);
-    int n = 0;
-    for (int i = 0; i < stringLen; ++i) {          // letters only; everything else (digits, '*', '-', blanks) is dropped
-        unsigned char ch = (unsigned char)string[i];
-        if (isalpha(ch)) {
-            d->chars[n] = (char)toupper(ch);
-            d->codes[n] = (char)(toupper(ch) - 'A');
-            ++n;
-        }
+    return d;
+}
+
+// appends the residues among src[0, n) to d (capacity is the caller's business); returns how many were kept
+inline size_t chain_data_append(ChainData* d, const char* src, size_t n) {
+    char* chars = d->chars + d->length;
+    char* codes = d->codes + d->length;
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = kResidue.code[(unsigned char)src[i]];
+        chars[k] = (char)(c + 'A');
+        codes[k] = (char)c;
+        k += (c != 0xFF);
     }
-    d->chars[n] = 0;
-    d->length = n;
-    return make_chain(d, 0, n, false);
+    d->length += (int)k;
+    return k;
+}
+}  // namespace
+
+SW_API Chain* chainCreate(char* name, int nameLen, char* string, int stringLen) {
+    SW_ASSERT(name != NULL && string != NULL && nameLen >= 0 && stringLen >= 0, "chainCreate: invalid arguments");
+    ChainData* d = chain_data_alloc(name, (size_t)nameLen, (size_t)stringLen);
+    chain_data_append(d, string, (size_t)stringLen);
+    d->chars[d->length] = 0;
+    return make_chain(d, 0, d->length, false);
 }
 
 SW_API Chain* chainCreateView(Chain* chain, int start, int end, int reverse) {
@@ -66,7 +93,7 @@ SW_API void chainDelete(Chain* chain) {
     free(chain->rev_chars);
     free(chain->rev_codes);
     free(chain);
-    if (--d->refs == 0) { free(d->name); free(d->chars); free(d->codes); free(d); }
+    if (--d->refs == 0) free(d);          // name, letters and codes live in the same block
 }
 
 SW_API int chainGetLength(Chain* chain) { return chain->length; }
@@ -80,11 +107,16 @@ SW_API char chainGetCode(Chain* chain, int index) { return chainGetCodes(chain)[
 // ------------------------------------------------------------------------------------------------ FASTA
 namespace {
 
-struct FastaState {              // one per open handle; keeps the look-ahead header between parts
+struct FastaState {              // one per open handle; keeps the look-ahead header and the read buffer between parts
     FILE* fh;
     std::string pending_name;
     bool have_pending;
     bool eof;
+    bool at_line_start = true;   // the next unread byte begins a line
+    bool in_header = false;      // in the middle of a header line (it continued past the buffer)
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    std::vector<char> seq;       // raw sequence bytes of the pending record
 };
 std::vector<FastaState*> g_fasta;
 pthread_mutex_t g_fasta_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -114,38 +146,65 @@ void push_chain(Chain*** chains, int* len, int* cap, Chain* c) {
 }
 
 // Reads records until >= max_bytes of sequence were consumed (0 = unlimited) or EOF. Returns 1 if more remain.
+// Block reads (4 MB) scanned with memchr; a record's residues go through the lookup table once, straight into the
+// chain's own storage (121 MB of UniProt-style FASTA: 1.1 s with the former line-by-line reader).
 int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
     int cap = *len;
-    std::string seq, line;
     size_t consumed = 0;
-    char buf[1 << 16];
+    if (st->buf.empty()) st->buf.resize(4u << 20);
     auto flush = [&]() {
-        if (st->have_pending) {
-            push_chain(chains, len, &cap, chainCreate((char*)st->pending_name.data(), (int)st->pending_name.size(),
-                                                      (char*)seq.data(), (int)seq.size()));
-            consumed += seq.size();
-            seq.clear();
-            st->have_pending = false;
-        }
+        if (!st->have_pending) return;
+        ChainData* d = chain_data_alloc(st->pending_name.data(), st->pending_name.size(), st->seq.size());
+        chain_data_append(d, st->seq.data(), st->seq.size());
+        d->chars[d->length] = 0;
+        push_chain(chains, len, &cap, make_chain(d, 0, d->length, false));
+        consumed += st->seq.size();
+        st->seq.clear();
+        st->have_pending = false;
     };
-    while (!st->eof) {
-        if (!fgets(buf, sizeof buf, st->fh)) { st->eof = true; break; }
-        line.assign(buf);
-        while (!line.empty() && line.back() != '\n' && !feof(st->fh)) {     // long line: keep reading
-            if (!fgets(buf, sizeof buf, st->fh)) break;
-            line.append(buf);
+    bool stop = false;
+    while (!stop) {
+        if (st->pos == st->end) {
+            st->end = fread(st->buf.data(), 1, st->buf.size(), st->fh);
+            st->pos = 0;
+            if (st->end == 0) { st->eof = true; break; }
         }
-        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (!line.empty() && line[0] == '>') {
+        const char* p = st->buf.data() + st->pos;
+        const char* e = st->buf.data() + st->end;
+        if (st->at_line_start && !st->in_header && *p == '>') {        // a new record begins
             flush();
-            st->pending_name = line.substr(1);
-            st->have_pending = true;
-            if (max_bytes && consumed >= max_bytes) break;       // header of the next part is kept in pending_name
-        } else if (st->have_pending) {
-            seq.append(line);
+            st->pending_name.clear();
+            st->in_header = true;
+            st->at_line_start = false;
+            ++st->pos;
+            continue;
         }
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        const char* seg_end = nl ? nl : e;
+        if (st->in_header) {
+            st->pending_name.append(p, (size_t)(seg_end - p));
+            if (nl) {
+                while (!st->pending_name.empty() && st->pending_name.back() == '\r') st->pending_name.pop_back();
+                st->in_header = false;
+                st->have_pending = true;
+                if (max_bytes && consumed >= max_bytes) stop = true;       // this header opens the next part
+            }
+        } else if (st->have_pending) {
+            size_t n = (size_t)(seg_end - p);
+            if (nl && n && seg_end[-1] == '\r') --n;
+            st->seq.insert(st->seq.end(), p, p + n);
+        }
+        st->pos = nl ? (size_t)(nl + 1 - st->buf.data()) : st->end;
+        st->at_line_start = nl != NULL;
     }
-    if (st->eof) flush();
+    if (st->eof) {
+        if (st->in_header) {          // file ends inside a header line: a record without residues
+            while (!st->pending_name.empty() && st->pending_name.back() == '\r') st->pending_name.pop_back();
+            st->in_header = false;
+            st->have_pending = true;
+        }
+        flush();
+    }
     if (*len < cap) *chains = (Chain**)realloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
     return st->eof ? 0 : 1;
 }

@@ -42,3 +42,26 @@ def test_reference_cli_on_the_cpu_oracle_reproduces_the_gpu_alignments_of_a_synt
     want = open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
     assert got == want
     assert got.count(b"\n") == 250
+
+
+BATCHED = os.path.join(ROOT, "build", "dropin", "sift4g_batched")
+
+
+@pytest.mark.skipif(not os.path.exists(BATCHED), reason="batched drop-in not built (needs /root/reference at build time: make dropin-batched)")
+def test_batched_wrapper_on_the_cpu_oracle_reproduces_the_same_outputs(tmp_path):
+    """the reference CLI with its alignment wrapper replaced by sift4g_amd/csrc/dropin/batched_database_alignment.cpp (one
+    shotgunDatabaseCandidates call per chunk): identical files to the per-query flow, here on the oracle stand-in."""
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    files = os.path.join(GOLDEN, "test_files")
+    out = tmp_path / "fixture"
+    out.mkdir()
+    r = subprocess.run([BATCHED, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep,
+                        "-d", os.path.join(files, "sample_protein_database.fa"), "--cards", "0", "--out", str(out), "--sub-results"],
+                       env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+        assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    assert dropin_synth.run(BATCHED, str(syn), env=env) == open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()

@@ -159,3 +159,26 @@ def test_reference_cli_synthetic_set_matches_the_committed_run(tmp_path):
     import dropin_synth
     got = dropin_synth.run(DROPIN, str(tmp_path))
     assert got == open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+
+
+BATCHED = os.path.join(ROOT, "build", "dropin", "sift4g_batched")
+
+
+@pytest.mark.skipif(not os.path.exists(BATCHED), reason="batched drop-in not built (needs /root/reference at build time: make dropin-batched)")
+def test_batched_wrapper_gives_the_reference_flows_alignments(tmp_path):
+    """build/dropin/sift4g_batched = the reference CLI with ONE source file replaced (its alignment wrapper, by
+    sift4g_amd/csrc/dropin/batched_database_alignment.cpp: one shotgunDatabaseCandidates call per chunk instead of one
+    alignDatabase call per query).  Same alignments and predictions, byte for byte, on the fixture and on the synthetic set."""
+    import dropin_synth
+    tf = os.path.join(GOLDEN, "test_files")
+    out = tmp_path / "fixture"
+    out.mkdir()
+    r = subprocess.run([BATCHED, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d",
+                        os.path.join(tf, "sample_protein_database.fa"), "--out", str(out), "--cards", "0", "--sub-results"],
+                       capture_output=True, text=True, timeout=600, cwd=str(out))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+        assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    assert dropin_synth.run(BATCHED, str(syn)) == open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()

@@ -46,6 +46,65 @@ def test_read_fasta_in_parts(cfg1):
     L.deleteFastaChains(chains, n)
 
 
+def test_read_fasta_odd_files(tmp_path):
+    """the block reader (4 MB buffer, memchr): CRLF line ends, lower case, blank lines, junk before the first header, a
+    header and a sequence line that straddle the buffer boundary, one 5 MB line, a header at EOF without residues, no
+    final newline -- whole-file and in parts, against a plain Python parse."""
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdefgh", dtype=np.uint8)
+
+    def seq(n):
+        return bytes(letters[rng.integers(0, len(letters), n)])
+
+    recs = [(b"first one", seq(70)), (b"crlf rec", seq(130)), (b"empty", b""), (b"big single line", seq(5 * 1024 * 1024 + 17))]
+    body = b"junk line before any header\r\n\n"
+    body += b">" + recs[0][0] + b"\n" + recs[0][1][:30] + b"\n\n" + recs[0][1][30:] + b" 12*-\n"
+    body += b">" + recs[1][0] + b"\r\n" + recs[1][1][:60] + b"\r\n" + recs[1][1][60:] + b"\r\n"
+    body += b">" + recs[2][0] + b"\n"
+    body += b">" + recs[3][0] + b"\n" + recs[3][1] + b"\n"
+    # pad with records so that a header line and a sequence line cross the 4 MiB and 8 MiB buffer boundaries
+    k, size, pieces = 0, len(body), [body]
+    while size < 9 * 1024 * 1024:
+        near = 0 <= 8 * 1024 * 1024 - size < 500                 # this record's header is made to straddle the 8 MiB refill
+        name = b"filler_%d " % k + b"x" * (1000 if near else int(rng.integers(0, 90)))
+        sq = seq(int(rng.integers(1, 400)))
+        recs.append((name, sq))
+        pieces.append(b">" + name + b"\n" + b"\n".join(sq[i:i + 60] for i in range(0, len(sq), 60)) + b"\n")
+        size += len(pieces[-1])
+        k += 1
+    recs.append((b"header only at eof", b""))
+    pieces.append(b">" + recs[-1][0])                            # no newline at the end of the file
+    body = b"".join(pieces)
+    path = tmp_path / "odd.fa"
+    path.write_bytes(body)
+    want = [(n.decode(), (np.frombuffer(s.upper(), dtype=np.uint8) - 65).tolist()) for n, s in recs]
+
+    def check(chains, n):
+        assert n.value == len(want)
+        for i in list(range(6)) + list(range(6, len(want), 97)) + [len(want) - 1]:
+            assert L.chainGetName(chains[i]).decode() == want[i][0], i
+            assert L.chainGetLength(chains[i]) == len(want[i][1]), i
+            if len(want[i][1]) < 10000:
+                assert sw.chain_codes(chains[i]) == want[i][1], i
+        big = 3
+        codes = L.chainGetCodes(chains[big])
+        assert [codes[j] for j in (0, 1, 4 * 1024 * 1024 - 40, len(want[big][1]) - 1)] == [want[big][1][j] for j in (0, 1, 4 * 1024 * 1024 - 40, len(want[big][1]) - 1)]
+
+    chains, n = pvp(), ci()
+    L.readFastaChains(ctypes.byref(chains), ctypes.byref(n), str(path).encode())
+    check(chains, n)
+    L.deleteFastaChains(chains, n)
+    chains, n, fh, ser = pvp(), ci(), vp(), ci()
+    L.readFastaChainsPartInit(ctypes.byref(chains), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), str(path).encode())
+    parts = 0
+    while L.readFastaChainsPart(ctypes.byref(chains), ctypes.byref(n), fh, ser, 300000):
+        parts += 1
+    assert parts >= 10
+    check(chains, n)
+    sw.libc.fclose(fh)
+    L.deleteFastaChains(chains, n)
+
+
 def test_chain_create_filters_and_views():
     c = L.chainCreate(b"x y", 3, b"ac-d*e 1fG\n", 11)
     assert L.chainGetName(c) == b"x y" and L.chainGetLength(c) == 6

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs the drop-in reference CLI (build/dropin/sift4g) on a synthetic workload and reports wall time per pipeline stage
-(stage boundaries = the reference's own stderr banners).  usage: tools/time_dropin.py [n_queries] [n_targets] [extra cli args...]"""
+(stage boundaries = the reference's own stderr banners).  usage: tools/time_dropin.py [n_queries] [n_targets] [extra cli args...]
+S4G_DROPIN_BIN=sift4g_batched selects the build with the batched alignment wrapper (make dropin-batched)."""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +16,7 @@ c = synth.make_config(2, nq, nt)
 write_fasta(f"{tmp}/q.fa", [f"q{i}" for i in range(nq)], c["q_codes"], c["q_off"])
 write_fasta(f"{tmp}/db.fa", [f"t{i}" for i in range(nt)], c["t_codes"], c["t_off"])
 os.makedirs(f"{tmp}/out")
-p = subprocess.Popen([f"{ROOT}/build/dropin/sift4g", "-q", f"{tmp}/q.fa", "-d", f"{tmp}/db.fa", "--cards", "0", "--out", f"{tmp}/out"] + extra,
+p = subprocess.Popen([f"{ROOT}/build/dropin/{os.environ.get('S4G_DROPIN_BIN', 'sift4g')}", "-q", f"{tmp}/q.fa", "-d", f"{tmp}/db.fa", "--cards", "0", "--out", f"{tmp}/out"] + extra,
                      stderr=subprocess.PIPE, cwd=f"{tmp}/out")
 t0 = time.time(); last = t0; stage = "start"; buf = b""
 while True:
