@@ -81,10 +81,10 @@ def test_read_fasta_odd_files(tmp_path):
 
     def check(chains, n):
         assert n.value == len(want)
-        for i in list(range(6)) + list(range(6, len(want), 97)) + [len(want) - 1]:
+        for i in range(len(want)):
             assert L.chainGetName(chains[i]).decode() == want[i][0], i
             assert L.chainGetLength(chains[i]) == len(want[i][1]), i
-            if len(want[i][1]) < 10000:
+            if len(want[i][1]) < 10000 and (i < 6 or i % 7 == 0 or len(want[i][0]) > 500 or i == len(want) - 1):
                 assert sw.chain_codes(chains[i]) == want[i][1], i
         big = 3
         codes = L.chainGetCodes(chains[big])
