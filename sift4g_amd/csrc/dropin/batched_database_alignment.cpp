@@ -26,7 +26,13 @@
 
 namespace {
 
-const size_t kChunkBytes = 1000000000;      // ~1 GB of FASTA per part, as the reference reads it
+// ~1 GB of sequence per part, as the reference reads it; S4G_CHUNK_BYTES overrides it (the tests use it to run the
+// several-parts logic -- consumed candidate prefixes, merge, chain deletion -- on small inputs)
+size_t chunk_bytes() {
+    const char* v = getenv("S4G_CHUNK_BYTES");
+    const long long n = v ? atoll(v) : 0;
+    return n > 0 ? (size_t)n : (size_t)1000000000;
+}
 
 void evalue_callback(double* values, int* scores, Chain* query, Chain** database, int databaseLen, int* cards, int cardsLen,
                      void* param) {
@@ -73,6 +79,7 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
     int serialized = 0;
     readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
 
+    const size_t kChunkBytes = chunk_bytes();
     const float part_gb = kChunkBytes / 1e9f;
     int chunk_begin = 0;
     for (uint32_t part = 1;; ++part) {

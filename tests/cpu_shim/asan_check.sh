@@ -17,12 +17,19 @@ g++ $SAN -std=c++17 -fPIC -shared -Iinclude -o $B/lib/libs4g_hip.so tests/cpu_sh
 g++ $SAN -std=c++17 -fPIC -shared -Iinclude -o $B/lib/libswsharp.so sift4g_amd/csrc/swsharp/core.cpp sift4g_amd/csrc/swsharp/evalue.cpp \
     sift4g_amd/csrc/swsharp/align.cpp sift4g_amd/csrc/swsharp/output.cpp -L$B/lib -ls4g_hip -lpthread
 g++ $SAN -std=c++11 -w -Iinclude -o $B/sift4g $REF/sift4g/src/*.cpp -L$B/lib -lswsharp -ls4g_hip -lpthread -lm
+g++ $SAN -std=c++11 -w -Iinclude -I$REF/sift4g/src -o $B/sift4g_batched $(ls $REF/sift4g/src/*.cpp | grep -v /database_alignment.cpp) \
+    sift4g_amd/csrc/dropin/batched_database_alignment.cpp -L$B/lib -lswsharp -ls4g_hip -lpthread -lm
 g++ $SAN -std=c++17 -Iinclude -o $B/shotgun_demo tools/shotgun_demo.cpp -L$B/lib -lswsharp -ls4g_hip -lpthread
 F=tests/golden/test_files
-rm -f $B/out/*
+rm -rf $B/out/*
 LD_LIBRARY_PATH=$B/lib $B/sift4g -q $F/query.fasta --subst $F/ -d $F/sample_protein_database.fa --cards 0 --out $B/out --sub-results -t 4 \
     > $B/out/stdout.txt 2> $B/out/stderr.txt || [ "$MODE" = thread ]
 for f in LACI_ECOLI.SIFTprediction PURR_SALTY.SIFTprediction alignments.txt; do cmp $B/out/$f tests/golden/dropin_predictions/$f; done
+# the batched wrapper, database read in several parts
+mkdir -p $B/out/batched
+S4G_CHUNK_BYTES=1500 LD_LIBRARY_PATH=$B/lib $B/sift4g_batched -q $F/query.fasta --subst $F/ -d $F/sample_protein_database.fa --cards 0 \
+    --out $B/out/batched --sub-results -t 4 > $B/out/batched/stdout.txt 2>> $B/out/stderr.txt || [ "$MODE" = thread ]
+for f in LACI_ECOLI.SIFTprediction PURR_SALTY.SIFTprediction alignments.txt; do cmp $B/out/batched/$f tests/golden/dropin_predictions/$f; done
 for ev in 0 1; do      # the batched entry points: callback selection and e-value driven selection
     LD_LIBRARY_PATH=$B/lib $B/shotgun_demo $F/query.fasta $F/sample_protein_database.fa 400 1e-4 4 $ev > $B/out/shotgun_$ev.txt 2>> $B/out/stderr.txt
 done

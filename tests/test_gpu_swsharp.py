@@ -181,4 +181,8 @@ def test_batched_wrapper_gives_the_reference_flows_alignments(tmp_path):
         assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
     syn = tmp_path / "synth"
     syn.mkdir()
-    assert dropin_synth.run(BATCHED, str(syn)) == open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+    want = open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+    assert dropin_synth.run(BATCHED, str(syn)) == want
+    parts = tmp_path / "parts"                                  # the database in ~17 parts (merge across parts)
+    parts.mkdir()
+    assert dropin_synth.run(BATCHED, str(parts), env=dict(os.environ, S4G_CHUNK_BYTES="30000")) == want
