@@ -217,6 +217,7 @@ SW_API void readFastaChainsPartInit(Chain*** chains, int* chainsLen, FILE** hand
     *chains = NULL;
     *chainsLen = 0;
     *serialized = 0;          // no serialized-database cache in this implementation
+    fasta_forget(*handle);    // a caller that closed an earlier handle before EOF may get the same FILE* again
     fasta_state(*handle, true);
 }
 
