@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--force-i32", action="store_true", help="run every query through the int32 kernel")
     ap.add_argument("--no-f16", action="store_true", help="skip the maximum3-based tiers (plain packed int16 instead)")
     ap.add_argument("--no-drift", action="store_true", help="skip the drifting-frame kernel (maximum3 tier instead)")
+    ap.add_argument("--no-spec", action="store_true", help="tiers by score bound only: no speculative use of the drifting-frame kernel for long queries")
     ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard",
                     help="query-shard (default): DB replicated, --queries per GPU; db-shard: --targets per GPU, every GPU scans "
                          "all --queries with the streaming scan + running top-k, then all-gather + K-way merge")
@@ -144,11 +145,11 @@ def main():
         if i is not None:
             ev[i][0].record()
         if db_shard:
-            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift)    # scan + tile top-k + merge
+            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)    # scan + tile top-k + merge
             if i is not None:
                 ev[i][1].record()
             return shard.gather_db_shards(ids, sc, cnt, gids, TOPK)                          # RCCL all-gather + K-way merge
-        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift)
+        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)
         if i is not None:
             ev[i][1].record()
         ids, sc, cnt = s4g.topk_device(db, scores, TOPK, 1)                     # steps 2-3 on the device

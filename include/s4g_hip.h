@@ -136,11 +136,15 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 /* s4g_scan with options.  By default every query runs in the fastest kernel that is EXACT for it, decided from
  * its score bound sum_i max(0, max_b table[q_i][b]): packed int16 in a drifting frame (bound + bias + (rows +
  * columns) * extend <= 31743), packed int16 with v_pk_maximum3_f16 as integer max3 (bound + bias <= 31743), plain
- * packed int16 (bound <= 32767), else int32.  flags below. */
+ * packed int16 (bound <= 32767), else int32.  A query whose BOUND exceeds the drifting-frame window but whose frame fits it
+ * with room to spare (long queries: the bound grows by ~5.6 per residue, real scores rarely do) still runs in that kernel,
+ * speculatively: the kernel marks every result that came within one score step of the window's end, and an exact int32
+ * pass (one wave per marked pair) recomputes just those before anything reads the scores.  flags below. */
 #define S4G_SCAN_FORCE_I32 1u
 #define S4G_SCAN_NO_F16    2u   /* skip the v_pk_maximum3_f16 tier (those queries then run in the plain packed int16 kernel) */
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */
 #define S4G_SCAN_NO_PAIRS  16u  /* scan kernels only: no group goes to the one-wave-per-pair kernels; any other flag implies this */
+#define S4G_SCAN_NO_SPEC   32u  /* no speculative use of the drifting-frame kernel: tiers by score bound only */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,

@@ -105,7 +105,7 @@ struct DeviceCtx {
     uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0;
     uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t grid_pair_band = 0, grid_pair_trace_band = 0;
+    uint32_t grid_pair_band = 0, grid_pair_trace_band = 0, grid_pair_recheck = 0;
     char* d_band_ws = nullptr;          // boundary rows of sw_pair_scan_band, one slot per wave
     uint64_t band_ws_bytes = 0;
     // pair lists: pinned staging for the items of the current call, their device copy (+ host-route scores behind it)
@@ -167,6 +167,11 @@ uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uin
 bool scan_prefers_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);
 int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, hipStream_t stream, bool* done);
+// after a speculative sw_scan_pkd launch: recomputes the marked entries of scores[q_count][n_cols] (row stride `stride`) exactly;
+// d_col_ids maps a column to its target id (NULL: identity); max_lt = longest target behind those columns.  cx->d_mat holds the
+// scorer's table already (ensure_scratch).  Caller holds cx->mu.
+int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count,
+                   int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream);
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                     int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);

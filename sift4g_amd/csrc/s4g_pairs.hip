@@ -141,6 +141,39 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     return scratch_release(db, stream);
 }
 
+int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count,
+                   int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream) {
+    if (q_count == 0 || n_cols == 0) return S4G_OK;
+    static const bool skip = getenv("S4G_TEST_SKIP_RECHECK") != nullptr;     // test hook: leaves the marks visible (tests/test_gpu_parity.py)
+    if (skip) return S4G_OK;
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    if (cx->grid_pair_recheck == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_recheck<16>, 64, 0));
+        cx->grid_pair_recheck = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint64_t slabs = (((uint64_t)n_cols + 63) / 64) * q_count;
+    uint64_t slot = 0;
+    uint32_t grid = 0;
+    rc = ensure_band_ws(cx, max_lt, (uint32_t)std::min<uint64_t>(slabs, 0xFFFFFFFFu), cx->grid_pair_recheck, &grid, &slot);
+    if (rc) return rc;
+    RecheckArgs r;
+    PairArgs& a = r.b.p;
+    a.items = nullptr; a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+    a.scores = d_scores; a.counter = nullptr; a.n_pairs = 0;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    r.b.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); r.b.band_ws_slot = slot;
+    r.stride = stride; r.q_begin = q_begin; r.q_count = q_count; r.n_cols = n_cols; r.col_ids = d_col_ids;
+    hipLaunchKernelGGL(sw_pair_recheck<16>, dim3(grid), dim3(64), 0, stream, r);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
 // Explicit list -> host scores.  sel = indices into pair_q / pair_t.
 // Order inside a class: longest target first at 32-residue granularity (counting sort; a launch cannot end before its
 // longest pair does, so that one must not start last).

@@ -13,6 +13,8 @@ constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of 
 // Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
 // is EXACT for it (score bound = sum_i max(0, max_b M[q_i][b]); see sw_kernels.hip.h for each window):
 //   drift  sw_scan_pkd          bound + B + (rows + tile columns) * ext <= 0x7BFF      6.5 ops / pair of cells
+//          ... or speculatively: only the frame B + (rows + columns) * ext (+ a span) fits; the kernel marks results that
+//          came near the window's end and sw_pair_recheck recomputes those in int32 (Plan::speculative)
 //   m3     sw_scan_pk<I16M3>    bound + B <= 0x7BFF   (or ArithF16: bound <= 4096)     7.5
 //   pk     sw_scan_pk<I16>      bound <= 32767                                          9
 //   wide   sw_scan_i32          anything                                                7.5 per single cell
@@ -32,7 +34,10 @@ struct Plan {
     uint32_t grid_i32 = 0, grid_i16 = 0, grid_m3 = 0, grid_drift = 0;   // full persistent grids
     uint64_t ws_bytes = 0;          // workspace needed for the largest tile launch
     uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
+    bool speculative = false;       // some query runs in the drift tier on its frame alone: marked results need sw_pair_recheck
+    uint32_t spec_base = 0;         // 0x7BFF - bias - (max score + 2 ext)
 };
+constexpr uint64_t kSpecSpan = 6144;    // scores a speculative query can reach without a recheck, at least
 
 int device_props(DeviceCtx* cx) {
     if (!cx->have_prop) {
@@ -99,6 +104,9 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     const bool m3_gaps = p->f16_arith ? (sc->open <= 2048 && sc->ext <= 2048) : gaps16;
     const bool no_m3 = (flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16)) != 0;
     const bool no_drift = no_m3 || p->f16_arith || (flags & S4G_SCAN_NO_DRIFT) != 0;
+    const bool no_spec = (flags & S4G_SCAN_NO_SPEC) != 0;
+    const uint64_t step = (uint64_t)std::max(0, sc->max_score) + 2 * (uint64_t)sc->ext;      // the most one cell adds to a stored value
+    p->spec_base = (uint32_t)(cap > p->bias + step ? cap - p->bias - step : 0);
 
     std::vector<uint32_t> ids[4];
     auto add_pairs = [&](std::vector<uint32_t>& v, uint32_t* off, uint32_t* n) {
@@ -121,6 +129,10 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             const uint64_t rows = (uint64_t)q->len[id] + 2 * kStripRows16;          // padded rows of the pair's strips
             int tier;
             if (!no_drift && gaps16 && b + p->bias + (rows + cols) * (uint64_t)sc->ext <= cap) tier = 0;
+            else if (!no_drift && !no_spec && gaps16 && p->bias + step + (rows + cols) * (uint64_t)sc->ext + kSpecSpan <= cap) {
+                tier = 0;               // the frame fits with room to spare: run there, recheck what comes near the end
+                p->speculative = true;
+            }
             else if (!no_m3 && m3_gaps && b <= m3_window) tier = 1;
             else if (!(flags & S4G_SCAN_FORCE_I32) && gaps16 && b <= 32767) tier = 2;
             else tier = 3;
@@ -227,9 +239,11 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     a.ws = ws; a.ws_slot = ws_slot_elems(t);
     a.n_groups = n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+    a.spec_base = 0;
     if (w.n_drift) {
         a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
         a.floor_bits = p.bias | (p.bias << 16);
+        a.spec_base = p.speculative ? p.spec_base : 0;
         hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
@@ -410,6 +424,12 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         if (rc) return rc;
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
+    if (p.speculative) {        // exact int32 pass over the entries the speculative launches marked
+        uint32_t max_lt = 0;
+        for (const Tile& t : db->tiles) max_lt = std::max(max_lt, t.max_len4 * 4);
+        rc = recheck_marked(db, q, scorer, q_begin, q_count, d_scores, db->n_seqs, db->n_seqs, nullptr, max_lt, stream);
+        if (rc) return rc;
+    }
     return scratch_release(db, stream);
 }
 
@@ -722,6 +742,10 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
                 rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
             }
             if (rc) return rc;
+            if (p.speculative && t.n_seqs && g0 < t.n_groups) {
+                rc = recheck_marked(db, q, scorer, q_begin + b, cnt, d_buf, t.n_seqs, t.n_seqs, t.d_col_ids, t.max_len4 * 4, stream);
+                if (rc) return rc;
+            }
             hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
                                c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
             hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,

@@ -238,7 +238,11 @@ struct ScanArgs16 {
     uint32_t open, ext;                      // each < 2^15
     uint32_t floor_bits;                     // packed floor of the arithmetic policy (see Arith*)
     uint32_t prio_cost;                      // items with rows * len4 >= prio_cost run at raised wave priority (0 = never)
+    uint32_t spec_base;                      // sw_scan_pkd, speculative launch: 0x7BFF - B - (max score + 2 ext); 0 = exact launch
 };
+
+// Written by a speculative sw_scan_pkd launch instead of a score that may not be exact; sw_pair_recheck replaces it.
+constexpr int kScoreUnsure = (int)0x80000000;
 
 __device__ __forceinline__ v2s as_s(v2us x) { return __builtin_bit_cast(v2s, x); }
 __device__ __forceinline__ v2us as_u(v2s x) { return __builtin_bit_cast(v2us, x); }
@@ -635,10 +639,23 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
                 else pkd_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
             }
         }
+        int outA = (int)as_s(best)[0], outB = (int)as_s(best)[1];
+        if (a.spec_base) {
+            // Speculative launch: the host only guarantees that the FRAME fits the window (B + (rows + columns) e + one
+            // score step <= 0x7BFF - a span), not that bound + frame does.  Every intermediate value is at most some
+            // H~ = H + z <= H + zmax, and the first value to leave the window is a diag + s' whose diag was still exact,
+            // so its true H -- which `best` took in before anything went wrong -- exceeds limit = spec_base - zmax.  After
+            // that the halves may hold anything (inf / NaN patterns propagate through maximum3, negative patterns lose
+            // every max), but as an unsigned 16-bit value best stays > limit.  Hence: best <= limit => exact.
+            const unsigned zmax = (lq + 2u * R + len4 * 4u + 8u) * a.ext;
+            const unsigned limit = a.spec_base > zmax ? a.spec_base - zmax : 0u;
+            if (((unsigned)best & 0xFFFFu) > limit) outA = kScoreUnsure;
+            if (((unsigned)best >> 16) > limit) outB = kScoreUnsure;
+        }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) {
-            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = (int)as_s(best)[0];
-            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = (int)as_s(best)[1];
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = outA;
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = outB;
         }
     }
 }

@@ -223,22 +223,127 @@ struct PairBandArgs {
     uint64_t band_ws_slot;          // columns per wave slot (>= the longest target of the launch)
 };
 
+// LDS of one band wave: substitution table, lane profile, target window, boundary window
+constexpr int kPairBandLds = 1024 + 32 * 64 * 4 * 4 + kPairWindow + 192 + (kPairWindow + 64) * 8;
+
+// score of (query q, target tid) for the whole wave (every lane returns the maximum); ws = this wave's boundary slot
 template <int RPL>
-__global__ __launch_bounds__(64) void sw_pair_scan_band(const PairBandArgs b) {
+__device__ __forceinline__ int pair_band_score(const PairArgs& a, int2* ws, char* lds, unsigned q, unsigned tid, int lane) {
     static_assert(RPL == 16, "a band is 64 lanes x 16 rows");
     constexpr int NW = 4, BAND = 64 * RPL;
     constexpr int W = kPairWindow;
     typedef v4i vnw;
-    const PairArgs& a = b.p;
-    __shared__ __attribute__((aligned(16))) char lds[1024 + 32 * 64 * NW * 4 + W + 192 + (W + 64) * 8];
-    const int lane = threadIdx.x;
     const int* lmat4 = reinterpret_cast<const int*>(lds);
     char* prof = lds + 1024;
     char* stage = prof + 32 * 64 * NW * 4;
     int2* bnd = reinterpret_cast<int2*>(stage + W + 192);      // boundary of columns w0 .. of the current window
+    const unsigned open = a.open, ext = a.ext;
+    const unsigned lq = a.q_len[q];
+    const unsigned lt = a.seq_len[tid];
+    const uint32_t* res = reinterpret_cast<const uint32_t*>(a.seq_addr[tid]);
+    const int len4 = (int)((lt + 3) / 4);
+    const unsigned nbands = lt ? (lq + BAND - 1) / BAND : 0;       // an empty query or target: no band, score 0
+    int best = 0;
+    const char* prof_lane = prof + lane * (NW * 4);
+
+    for (unsigned band = 0; band < nbands; ++band) {
+        const unsigned row0 = band * BAND;
+        const unsigned rows = lq - row0 < (unsigned)BAND ? lq - row0 : (unsigned)BAND;
+        const bool last_band = band + 1 == nbands;
+        pair_build_profile<RPL, NW>(prof, lmat4, a.q_codes + a.q_off[q] + row0, rows, lane);
+        if (band) {     // the boundary written by this wave during the previous band must be what the loads below see
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const unsigned lanes_used = (rows + RPL - 1) / RPL;
+        const unsigned nsteps = lt + lanes_used - 1;
+        int H[RPL];
+        unsigned E[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
+        int hu_prev = 0;
+        unsigned f_out = 0;
+        auto step = [&](const vnw& sc, const int2 top) {
+            const int hu = __builtin_amdgcn_update_dpp(top.x, H[RPL - 1], 0x138, 0xf, 0xf, false);      // lane 0 <- boundary H
+            unsigned F = (unsigned)__builtin_amdgcn_update_dpp(top.y, (int)f_out, 0x138, 0xf, 0xf, false);
+            int d[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int w = pk_get(sc, r / 4);
+                const int s = (int)(signed char)(w >> (8 * (r % 4)));
+                d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
+            }
+            int hprev = 0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int h = imax(imax(d[r], (int)E[r]), (int)F);
+                if (r & 1) best = imax(imax(best, hprev), h); else hprev = h;
+                const unsigned hm = usub_sat((unsigned)h, open);
+                E[r] = umax_s(usub_sat(E[r], ext), hm);
+                F = umax_s(usub_sat(F, ext), hm);
+                H[r] = h;
+            }
+            f_out = F;
+            hu_prev = hu;
+        };
+
+        for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
+            const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
+            pair_stage_window(stage, res, len4, w0, kend, lane);
+            // boundary of columns w0 .. kend + 2 (lane 0's column at step k is k): zeros for the first band and past the target
+            for (unsigned e = lane; e < kend - w0 + 3; e += 64) {
+                int2 v = {0, 0};
+                if (band && w0 + e < lt) v = ws[w0 + e];
+                bnd[e] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned char* sa = reinterpret_cast<const unsigned char*>(stage) + 64 - lane;
+            const int2* ba = bnd;
+            unsigned tB = sa[0];
+            vnw scA = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+            int2 topA = ba[0];
+            tB = sa[1];
+            pin(tB);
+            pin(scA);
+            pin(topA.x); pin(topA.y);
+            for (unsigned k = w0; k < kend; k += 2) {
+                vnw scB = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
+                unsigned tC = sa[2];
+                int2 topB = ba[1];
+                __builtin_amdgcn_sched_barrier(0);
+                step(scA, topA);
+                if (!last_band && lane == 63 && k >= 63 && k - 63 < lt) ws[k - 63] = int2{H[RPL - 1], (int)f_out};
+                __builtin_amdgcn_sched_barrier(0);
+                pin(tC);
+                pin(scB);
+                pin(topB.x); pin(topB.y);
+                scA = *reinterpret_cast<const vnw*>(prof_lane + tC * (64 * NW * 4));
+                tB = sa[3];
+                topA = ba[2];
+                sa += 2;
+                ba += 2;
+                __builtin_amdgcn_sched_barrier(0);
+                step(scB, topB);
+                if (!last_band && lane == 63 && k + 1 >= 63 && k + 1 - 63 < lt) ws[k + 1 - 63] = int2{H[RPL - 1], (int)f_out};
+                __builtin_amdgcn_sched_barrier(0);
+                pin(tB);
+                pin(scA);
+                pin(topA.x); pin(topA.y);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = imax(best, __shfl_xor(best, off, 64));
+    return best;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(64) void sw_pair_scan_band(const PairBandArgs b) {
+    const PairArgs& a = b.p;
+    __shared__ __attribute__((aligned(16))) char lds[kPairBandLds];
+    const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     __builtin_amdgcn_wave_barrier();
-    const unsigned open = a.open, ext = a.ext;
     int2* ws = b.band_ws + (uint64_t)blockIdx.x * b.band_ws_slot;
 
     // canonical loop shape (fetch in the header, no break / continue inside): with the usual for (;;) + break form the
@@ -252,103 +357,47 @@ __global__ __launch_bounds__(64) void sw_pair_scan_band(const PairBandArgs b) {
         const unsigned q = a.items[item].q;
         const unsigned tid = a.items[item].t;
         const unsigned out = a.items[item].out;
-        const unsigned lq = a.q_len[q];
-        const unsigned lt = a.seq_len[tid];
-        const uint32_t* res = reinterpret_cast<const uint32_t*>(a.seq_addr[tid]);
-        const int len4 = (int)((lt + 3) / 4);
-        const unsigned nbands = lt ? (lq + BAND - 1) / BAND : 0;       // an empty query or target: no band, score 0
-        int best = 0;
-        const char* prof_lane = prof + lane * (NW * 4);
-
-        for (unsigned band = 0; band < nbands; ++band) {
-            const unsigned row0 = band * BAND;
-            const unsigned rows = lq - row0 < (unsigned)BAND ? lq - row0 : (unsigned)BAND;
-            const bool last_band = band + 1 == nbands;
-            pair_build_profile<RPL, NW>(prof, lmat4, a.q_codes + a.q_off[q] + row0, rows, lane);
-            if (band) {     // the boundary written by this wave during the previous band must be what the loads below see
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            const unsigned lanes_used = (rows + RPL - 1) / RPL;
-            const unsigned nsteps = lt + lanes_used - 1;
-            int H[RPL];
-            unsigned E[RPL];
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
-            int hu_prev = 0;
-            unsigned f_out = 0;
-            auto step = [&](const vnw& sc, const int2 top) {
-                const int hu = __builtin_amdgcn_update_dpp(top.x, H[RPL - 1], 0x138, 0xf, 0xf, false);      // lane 0 <- boundary H
-                unsigned F = (unsigned)__builtin_amdgcn_update_dpp(top.y, (int)f_out, 0x138, 0xf, 0xf, false);
-                int d[RPL];
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int w = pk_get(sc, r / 4);
-                    const int s = (int)(signed char)(w >> (8 * (r % 4)));
-                    d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
-                }
-                int hprev = 0;
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                    if (r & 1) best = imax(imax(best, hprev), h); else hprev = h;
-                    const unsigned hm = usub_sat((unsigned)h, open);
-                    E[r] = umax_s(usub_sat(E[r], ext), hm);
-                    F = umax_s(usub_sat(F, ext), hm);
-                    H[r] = h;
-                }
-                f_out = F;
-                hu_prev = hu;
-            };
-
-            for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
-                const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
-                pair_stage_window(stage, res, len4, w0, kend, lane);
-                // boundary of columns w0 .. kend + 2 (lane 0's column at step k is k): zeros for the first band and past the target
-                for (unsigned e = lane; e < kend - w0 + 3; e += 64) {
-                    int2 v = {0, 0};
-                    if (band && w0 + e < lt) v = ws[w0 + e];
-                    bnd[e] = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                const unsigned char* sa = reinterpret_cast<const unsigned char*>(stage) + 64 - lane;
-                const int2* ba = bnd;
-                unsigned tB = sa[0];
-                vnw scA = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
-                int2 topA = ba[0];
-                tB = sa[1];
-                pin(tB);
-                pin(scA);
-                pin(topA.x); pin(topA.y);
-                for (unsigned k = w0; k < kend; k += 2) {
-                    vnw scB = *reinterpret_cast<const vnw*>(prof_lane + tB * (64 * NW * 4));
-                    unsigned tC = sa[2];
-                    int2 topB = ba[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    step(scA, topA);
-                    if (!last_band && lane == 63 && k >= 63 && k - 63 < lt) ws[k - 63] = int2{H[RPL - 1], (int)f_out};
-                    __builtin_amdgcn_sched_barrier(0);
-                    pin(tC);
-                    pin(scB);
-                    pin(topB.x); pin(topB.y);
-                    scA = *reinterpret_cast<const vnw*>(prof_lane + tC * (64 * NW * 4));
-                    tB = sa[3];
-                    topA = ba[2];
-                    sa += 2;
-                    ba += 2;
-                    __builtin_amdgcn_sched_barrier(0);
-                    step(scB, topB);
-                    if (!last_band && lane == 63 && k + 1 >= 63 && k + 1 - 63 < lt) ws[k + 1 - 63] = int2{H[RPL - 1], (int)f_out};
-                    __builtin_amdgcn_sched_barrier(0);
-                    pin(tB);
-                    pin(scA);
-                    pin(topA.x); pin(topA.y);
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = imax(best, __shfl_xor(best, off, 64));
+        const int best = pair_band_score<RPL>(a, ws, lds, q, tid, lane);
         a.scores[out] = best;          // every lane holds the maximum; one address, no divergent branch
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Recheck pass of the speculative packed scan (sw_scan_pkd with ScanArgs16::spec_base != 0): that kernel runs queries
+// whose score BOUND does not fit its int16 window and writes kScoreUnsure (sw_kernels.hip.h) wherever a result came close enough to the
+// window's end that an intermediate value may have left it.  This kernel reads the score rows once (waves stride over
+// 64-column slabs) and recomputes every marked entry exactly, in int32, one wave per pair, band by band.
+
+struct RecheckArgs {
+    PairBandArgs b;                     // b.p.items / counter / n_pairs unused
+    uint64_t stride;                    // scores[row * stride + column]
+    uint32_t q_begin, q_count, n_cols;
+    const uint32_t* __restrict__ col_ids;   // column -> target id (NULL: the column IS the id)
+};
+
+template <int RPL>
+__global__ __launch_bounds__(64) void sw_pair_recheck(const RecheckArgs r) {
+    const PairArgs& a = r.b.p;
+    __shared__ __attribute__((aligned(16))) char lds[kPairBandLds];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __builtin_amdgcn_wave_barrier();
+    int2* ws = r.b.band_ws + (uint64_t)blockIdx.x * r.b.band_ws_slot;
+    const uint64_t slabs_per_row = ((uint64_t)r.n_cols + 63) / 64;
+    const uint64_t total = slabs_per_row * r.q_count;
+    for (uint64_t s = blockIdx.x; s < total; s += gridDim.x) {
+        const uint32_t row = (uint32_t)(s / slabs_per_row);
+        const uint32_t col0 = (uint32_t)(s - (uint64_t)row * slabs_per_row) * 64;
+        int32_t* line = a.scores + (uint64_t)row * r.stride;
+        const int v = col0 + lane < r.n_cols ? line[col0 + lane] : 0;
+        unsigned long long marked = __ballot(v == kScoreUnsure);
+        while (marked) {
+            const unsigned col = col0 + (unsigned)__builtin_ctzll(marked);
+            marked &= marked - 1;
+            const unsigned tid = r.col_ids ? r.col_ids[col] : col;
+            const int best = pair_band_score<RPL>(a, ws, lds, r.q_begin + row, tid, lane);
+            line[col] = best;
+        }
     }
 }
 

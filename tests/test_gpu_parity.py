@@ -1,8 +1,10 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact int32 scores."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import rand_seqs
+from conftest import ROOT, rand_seqs
 
 pytestmark = pytest.mark.gpu
 
@@ -778,6 +780,78 @@ def test_database_from_separate_arrays(s4g, oracle_mod, blosum62, scorer):
     bad[4][3] = 26
     with pytest.raises(RuntimeError):
         s4g.Database.from_arrays(bad)
+
+
+def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
+    """Queries whose score BOUND is beyond the drifting-frame window (here 2048 .. 5000 residues) still run in sw_scan_pkd,
+    speculatively: results that come near the window's end are marked by the kernel and recomputed in int32 by
+    sw_pair_recheck before anything reads them.  Targets: unrelated ones (far below the mark), whole copies and close
+    homologs of the queries (self-scores of 11k .. 27k: above and below the mark, in both halves of a packed pair), with the
+    default gaps and with extend = 2 (a frame that drifts twice as fast: lower mark).  Scan and streaming top-k, against
+    the oracle and against the tiers-by-bound routing (no_spec)."""
+    rng = np.random.default_rng(61)
+    qlens = [2500, 3300, 4100, 5000, 4999, 2048, 900]
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
+    ts = rand_seqs(rng, 150, 30, 900)
+    def mutate(src, frac, indel):
+        x = src.copy()
+        idx = rng.integers(0, len(x), size=int(len(x) * frac))
+        x[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]
+        if indel:
+            cut = int(rng.integers(100, len(x) - 100))
+            x = np.concatenate([x[:cut], rand_seqs(rng, 1, indel, indel)[0], x[cut + 7:]])
+        return x
+    ts[3] = qs[3].copy(); ts[9] = qs[4].copy(); ts[17] = qs[0].copy(); ts[30] = qs[2].copy(); ts[31] = qs[6].copy()
+    ts[40] = mutate(qs[3], 0.05, 0); ts[41] = mutate(qs[3], 0.15, 12); ts[42] = mutate(qs[1], 0.02, 5)
+    ts[50] = np.concatenate([rand_seqs(rng, 1, 300, 300)[0], qs[4][1000:4800], rand_seqs(rng, 1, 200, 200)[0]])
+    ts[51] = np.concatenate([qs[5], qs[5]])
+    q = s4g.QuerySet(qs)
+    for go, ge in ((10, 1), (11, 2)):
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        exp = oracle_mod.scan(qs, ts, blosum62, go, ge, threads=8)
+        assert exp.max() > 25000 and np.sort(exp[3])[-3] > 12000
+        for tile_seqs in (0, 64):
+            db = s4g.Database(ts, tile_seqs=tile_seqs)
+            for mode in (dict(no_pairs=True), dict(no_spec=True), dict()):
+                got = s4g.scan_host(db, q, sc, **mode)
+                bad = np.argwhere(got != exp)
+                assert bad.size == 0, (go, ge, tile_seqs, mode, bad[:5].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
+            ids, top, cnt = s4g.scan_topk(db, q, sc, 8, no_pairs=True)
+            ids, top, cnt = ids.cpu().numpy(), top.cpu().numpy(), cnt.cpu().numpy()
+            for i in range(len(qs)):
+                order = sorted(range(len(ts)), key=lambda t: (-int(exp[i, t]), t))[:8]
+                assert ids[i].tolist() == order and top[i].tolist() == [int(exp[i, t]) for t in order], (go, ge, tile_seqs, i)
+
+
+def test_speculative_launch_really_marks_results():
+    """the same kind of input with the recheck pass switched off by its test hook (own process: the hook is read once):
+    marks (INT32_MIN) must be present exactly where the true score is beyond the kernel's limit -- i.e. the test above
+    exercises the speculative path and the marks it relies on -- and everything unmarked must already be exact."""
+    import subprocess, sys, json
+    code = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import rand_seqs
+import oracle, sift4g_amd as s4g
+rng = np.random.default_rng(62)
+qs = [rand_seqs(rng, 1, l, l)[0] for l in (5000, 4200, 2600, 2500)]
+ts = rand_seqs(rng, 70, 30, 600)
+ts[5] = qs[0].copy(); ts[6] = qs[1].copy(); ts[7] = qs[2].copy(); ts[8] = qs[3][:2400].copy()
+sc = s4g.Scorer("BLOSUM_62", 10, 1)
+got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), sc, no_pairs=True)
+exp = oracle.scan(qs, ts, oracle.blosum62(), 10, 1, threads=8)
+marked = got == -2**31
+print(json.dumps(dict(marked=np.argwhere(marked).tolist(), exact_elsewhere=bool((got[~marked] == exp[~marked]).all()),
+                      marked_scores=exp[marked].tolist(), max_unmarked=int(exp[~marked].max()))))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, S4G_TEST_SKIP_RECHECK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["exact_elsewhere"]
+    # self hits of the 5000- and 4200-residue queries (29k, 24k) lie beyond the limit (31 666 - frame); 2600 / 2500 (15k, 14k) do not
+    assert [0, 5] in res["marked"] and [1, 6] in res["marked"] and [2, 7] not in res["marked"] and [3, 8] not in res["marked"]
+    assert min(res["marked_scores"]) > 15000 and res["max_unmarked"] < 24000
 
 
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
