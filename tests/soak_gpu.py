@@ -28,6 +28,15 @@ while time.time() < t_end:
     nq = int(rng.integers(1, 9)); nt = int(rng.integers(1, 260))
     qmax = int(rng.choice([40, 300, 700, 1100, 2600])); tmax = int(rng.choice([30, 300, 900, 2500, 5000]))
     qs = rand_seqs(rng, nq, 0, qmax, 26); ts = rand_seqs(rng, nt, 0, tmax, 26)
+    long_mode = rng.random() < 0.15         # long queries + copies of them: the speculative drift tier and its recheck pass
+    if long_mode:
+        nq = int(rng.integers(1, 4)); nt = int(rng.integers(8, 48)); qmax, tmax = 6000, 700
+        qs = rand_seqs(rng, nq, 1800, qmax, int(rng.choice([20, 26]))); ts = rand_seqs(rng, nt, 0, tmax, 26)
+        for k in range(nq):
+            src = qs[k]; a = int(rng.integers(0, len(src) // 3)); b = int(rng.integers(2 * len(src) // 3, len(src) + 1))
+            ts[2 * k] = src[a:b].copy()
+            x = src.copy(); x[rng.integers(0, len(x), size=len(x) // 12)] = rng.integers(0, 20, size=len(x) // 12)
+            ts[2 * k + 1] = x
     for k in range(0, nt, 7):                                   # related pairs
         src = qs[k % nq]
         if len(src) > 12 and len(ts[k]) > 4:
@@ -38,8 +47,15 @@ while time.time() < t_end:
     exp = oracle.scan(qs, ts, M, go, ge, threads=8)
     cells += sum(len(x) for x in qs) * sum(len(x) for x in ts)
     ctx = (it, go, ge, nq, nt, qmax, tmax)
-    for mode in (dict(), dict(no_pairs=True), dict(force_i32=True)):
+    for mode in (dict(), dict(no_pairs=True), dict(force_i32=True), dict(no_spec=True)):
         assert np.array_equal(s4g.scan_host(db, q, sc, **mode), exp), ("scan", mode, ctx)
+    if long_mode:
+        k = min(5, nt)
+        ids, top, cnt = s4g.scan_topk(db, q, sc, k, no_pairs=True)
+        ids, top = ids.cpu().numpy(), top.cpu().numpy()
+        for i in range(nq):
+            order = [t for t in sorted(range(nt), key=lambda t: (-int(exp[i, t]), t)) if exp[i, t] >= 1][:k]
+            assert ids[i, :len(order)].tolist() == order and top[i, :len(order)].tolist() == [int(exp[i, t]) for t in order], ("topk", ctx, i)
     n = int(rng.integers(1, 400)); pq = rng.integers(0, nq, size=n); pt = rng.integers(0, nt, size=n)
     for route in ("wave", "scan", None):
         assert np.array_equal(s4g.score_pairs(db, q, sc, pq, pt, route=route), exp[pq, pt]), ("pairs", route, ctx)
