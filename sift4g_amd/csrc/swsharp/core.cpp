@@ -167,7 +167,11 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
         if (st->pos == st->end) {
             st->end = fread(st->buf.data(), 1, st->buf.size(), st->fh);
             st->pos = 0;
-            if (st->end == 0) { st->eof = true; break; }
+            if (st->end == 0) {
+                SW_ASSERT(!ferror(st->fh), "read error in FASTA input");      // a short database must not pass for a complete one
+                st->eof = true;
+                break;
+            }
         }
         const char* p = st->buf.data() + st->pos;
         const char* e = st->buf.data() + st->end;
