@@ -41,6 +41,8 @@ SIG = {
     "alignDatabase": (None, [ctypes.POINTER(pvp), pi, ci, vp, vp, vp, ci, ValueFunction, vp, cd, pi, ci, pi, ci, vp]),
     "shotgunDatabase": (None, [ctypes.POINTER(ctypes.POINTER(pvp)), ctypes.POINTER(pi), ci, pvp, ci, vp, vp, ci,
                                ValueFunction, vp, cd, pi, ci, pi, ci, vp]),
+    "shotgunDatabaseCandidates": (None, [ctypes.POINTER(ctypes.POINTER(pvp)), ctypes.POINTER(pi), ci, pvp, ci, vp, vp, ci,
+                                         ValueFunction, vp, cd, ctypes.POINTER(pi), pi, pi, ci, vp]),
     "shotgunDatabaseEValues": (None, [ctypes.POINTER(ctypes.POINTER(pvp)), ctypes.POINTER(pi), ci, pvp, ci, vp, vp, ci, vp, cd, pi, ci, vp]),
     "dbAlignmentsFromScores": (None, [ctypes.POINTER(pvp), pi, ci, vp, pvp, ci, pi, vp, ci, ValueFunction, vp, cd]),
     "alignPair": (None, [pvp, ci, vp, vp, vp, pi, ci, vp]),

@@ -85,6 +85,53 @@ def test_shotgun_database_batch(oracle_mod, blosum62):
     L.deleteEValueParams(ev); L.scorerDelete(s)
 
 
+def test_shotgun_database_candidates(oracle_mod, blosum62):
+    """shotgunDatabaseCandidates: per-query candidate lists (sorted ids, different sizes, an empty one, a NULL one, one that is
+    the whole database) -> for every query exactly what alignDatabase on a database of just those chains gives, with target
+    indices into the big database; also with a multi-card list."""
+    rng = np.random.default_rng(33)
+    qs = rand_seqs(rng, 9, 60, 220)
+    ts = rand_seqs(rng, 300, 30, 260)
+    for k in range(45):
+        m = qs[k % 9].copy(); idx = rng.choice(len(m), size=len(m) // 3, replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]; ts[k * 6] = m
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    s = sw.scorer(10, 1)
+    tch = [sw.chain(f"t{i}", t) for i, t in enumerate(ts)]
+    qch = [sw.chain(f"q{i}", q) for i, q in enumerate(qs)]
+    tarr, qarr = sw.chain_array(tch), sw.chain_array(qch)
+    ev = L.createEValueParams(int(sum(len(t) for t in ts)), s)
+    cb = sw.evalue_callback()
+    lists = [sorted(rng.choice(len(ts), size=int(n), replace=False).tolist()) for n in (120, 7, 0, 299, 300, 64, 65, 1, 33)]
+    lists[4] = list(range(len(ts)))
+    arrs = [(ci * max(len(l), 1))(*l) for l in lists]
+    ptrs = (ctypes.POINTER(ci) * len(lists))(*[ctypes.cast(a, ctypes.POINTER(ci)) for a in arrs])
+    ptrs[7] = ctypes.cast(arrs[7], ctypes.POINTER(ci)); lens_in = (ci * len(lists))(*[len(l) for l in lists])
+    ptrs[2] = ctypes.POINTER(ci)()                      # NULL list: no alignments for that query
+    for cards in (None, (0, 0)):
+        carr = (ci * len(cards))(*cards) if cards else None
+        cdb = L.chainDatabaseCreate(tarr, 0, len(tch), carr, len(cards) if cards else 0)
+        outs, lens = ctypes.POINTER(pvp)(), ctypes.POINTER(ci)()
+        L.shotgunDatabaseCandidates(ctypes.byref(outs), ctypes.byref(lens), 0, qarr, len(qch), cdb, s, 10, cb, ev, 1e-3, ptrs, lens_in,
+                                    carr, len(cards) if cards else 0, None)
+        total = 0
+        for i, l in enumerate(lists):
+            if not l:
+                assert lens[i] == 0
+                continue
+            sub = sw.chain_array([tch[t] for t in l])
+            ref, nr = pvp(), ci()
+            sc = (ci * len(l))(*[int(exp[i, t]) for t in l])
+            L.dbAlignmentsFromScores(ctypes.byref(ref), ctypes.byref(nr), 0, qch[i], sub, len(l), sc, s, 10, cb, ev, 1e-3)
+            want = [(l[h[0]],) + tuple(h[1:]) for h in _hits(ref, nr.value)]     # list position -> index into the database
+            assert lens[i] == nr.value and _hits(outs[i], lens[i]) == want, i
+            total += lens[i]
+        assert total >= 10
+        L.deleteShotgunDatabase(outs, lens, len(qs))
+        L.chainDatabaseDelete(cdb)
+    L.deleteEValueParams(ev); L.scorerDelete(s)
+
+
 def test_evalue_driven_selection_equals_callback_path(oracle_mod, blosum62):
     """shotgunDatabaseEValues (score cut + streaming device top-k + exact host e-values + exactness check) returns exactly
     what shotgunDatabase returns with the reference's e-value callback -- including queries with more significant hits than
