@@ -167,12 +167,12 @@ SW_API void chainDatabaseDelete(ChainDatabase* db) {
 // ------------------------------------------------------------------------------------------------ DbAlignment / Alignment
 static DbAlignment* make_db_alignment(Chain* query, int query_idx, Chain* target, int target_idx, double value,
                                       Scorer* scorer, const swimpl::PairResult& r) {
-    DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
+    DbAlignment* a = (DbAlignment*)xcalloc(1, sizeof(DbAlignment));
     a->query = query; a->query_idx = query_idx; a->query_start = r.q_start; a->query_end = r.q_end;
     a->target = target; a->target_idx = target_idx; a->target_start = r.t_start; a->target_end = r.t_end;
     a->score = r.score; a->value = value; a->scorer = swimpl::scorer_retain(scorer);
     a->path_len = (int)r.path.size();
-    a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+    a->path = (char*)xmalloc(a->path_len ? a->path_len : 1);
     if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
     return a;
 }
@@ -194,11 +194,11 @@ SW_API void dbAlignmentCopyPath(DbAlignment* a, char* dest) { memcpy(dest, a->pa
 SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { swimpl::scorer_release(a->scorer); free(a->path); free(a); } }
 
 SW_API Alignment* dbAlignmentToAlignment(DbAlignment* d) {
-    Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
+    Alignment* a = (Alignment*)xcalloc(1, sizeof(Alignment));
     a->query = d->query; a->query_start = d->query_start; a->query_end = d->query_end;
     a->target = d->target; a->target_start = d->target_start; a->target_end = d->target_end;
     a->score = d->score; a->scorer = swimpl::scorer_retain(d->scorer); a->path_len = d->path_len;
-    a->path = (char*)malloc(d->path_len ? d->path_len : 1);
+    a->path = (char*)xmalloc(d->path_len ? d->path_len : 1);
     if (d->path_len) memcpy(a->path, d->path, d->path_len);
     return a;
 }
@@ -222,11 +222,11 @@ SW_API void alignPair(Alignment** alignment, int type, Chain* query, Chain* targ
     SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
     swimpl::PairResult r;
     swimpl::sw_traceback(chainGetCodes(query), chainGetLength(query), chainGetCodes(target), chainGetLength(target), scorer, &r);
-    Alignment* a = (Alignment*)calloc(1, sizeof(Alignment));
+    Alignment* a = (Alignment*)xcalloc(1, sizeof(Alignment));
     a->query = query; a->query_start = r.q_start; a->query_end = r.q_end;
     a->target = target; a->target_start = r.t_start; a->target_end = r.t_end;
     a->score = r.score; a->scorer = swimpl::scorer_retain(scorer); a->path_len = (int)r.path.size();
-    a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+    a->path = (char*)xmalloc(a->path_len ? a->path_len : 1);
     if (a->path_len) memcpy(a->path, r.path.data(), a->path_len);
     *alignment = a;
 }
@@ -293,7 +293,7 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
         jobs[k] = {query, database[keep[k].idx], keep[k].idx, keep[k].value, scorer, keep[k].score, NULL};
         tasks[k] = threadPoolSubmit(trace_task, &jobs[k]);
     }
-    DbAlignment** out = (DbAlignment**)malloc(sizeof(DbAlignment*) * n);   /* malloc domain: callers free() these arrays */
+    DbAlignment** out = (DbAlignment**)xmalloc(sizeof(DbAlignment*) * n);   /* malloc domain: callers free() these arrays */
     for (int k = 0; k < n; ++k) {
         threadPoolTaskWait(tasks[k]);
         threadPoolTaskDelete(tasks[k]);
@@ -332,17 +332,17 @@ static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** que
     uint32_t x = 0;
     for (uint32_t i = 0; i < cnt; ++i) {
         const int n = (int)keep[i].size();
-        DbAlignment** out = n ? (DbAlignment**)malloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
+        DbAlignment** out = n ? (DbAlignment**)xmalloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
         for (int k = 0; k < n; ++k, ++x) {
             const Survivor& sv = keep[i][k];
-            DbAlignment* a = (DbAlignment*)calloc(1, sizeof(DbAlignment));
+            DbAlignment* a = (DbAlignment*)xcalloc(1, sizeof(DbAlignment));
             a->query = queries[i]; a->query_idx = query_idx0 + (int)i;
             a->target = cdb->chains[sv.idx]; a->target_idx = sv.idx;
             a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
             a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
             a->score = sv.score; a->value = sv.value; a->scorer = swimpl::scorer_retain(scorer);
             a->path_len = out5[(size_t)x * 5 + 4];
-            a->path = (char*)malloc(a->path_len ? a->path_len : 1);
+            a->path = (char*)xmalloc(a->path_len ? a->path_len : 1);
             memcpy(a->path, paths.data() + path_off[x], a->path_len);
             out[k] = a;
         }
@@ -450,8 +450,8 @@ SW_API void shotgunDatabase(DbAlignment**** dbAlignments, int** dbAlignmentsLens
     (void)cards; (void)cardsLen; (void)thread;   // the ChainDatabase already lives on its cards
     SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
     SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0, "shotgunDatabase: invalid arguments");
-    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
-    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    *dbAlignments = (DbAlignment***)xcalloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)xcalloc(queriesLen ? queriesLen : 1, sizeof(int));
     if (queriesLen == 0 || cdb->length == 0) return;
     // query-shard over the cards, balanced in query residues; one host thread per card (upstream's multi-GPU model)
     const int n_cards = std::min<int>((int)cdb->cards.size(), queriesLen);
@@ -567,8 +567,8 @@ SW_API void shotgunDatabaseCandidates(DbAlignment**** dbAlignments, int** dbAlig
     SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
     SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0 && (queriesLen == 0 || (candidates && candidatesLens)),
               "shotgunDatabaseCandidates: invalid arguments");
-    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
-    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    *dbAlignments = (DbAlignment***)xcalloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)xcalloc(queriesLen ? queriesLen : 1, sizeof(int));
     if (queriesLen == 0 || cdb->length == 0) return;
     // query-shard over the cards, balanced in (query residues x candidates)
     const int n_cards = std::min<int>((int)cdb->cards.size(), queriesLen);
@@ -712,8 +712,8 @@ SW_API void shotgunDatabaseEValues(DbAlignment**** dbAlignments, int** dbAlignme
     (void)cards; (void)cardsLen; (void)thread;
     SW_ASSERT(type == SW_ALIGN, "alignment type %d is not supported (only SW_ALIGN, the mode sift4g runs)", type);
     SW_ASSERT(cdb != NULL && scorer != NULL && queries != NULL && queriesLen >= 0 && eValueParams != NULL, "shotgunDatabaseEValues: invalid arguments");
-    *dbAlignments = (DbAlignment***)calloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
-    *dbAlignmentsLens = (int*)calloc(queriesLen ? queriesLen : 1, sizeof(int));
+    *dbAlignments = (DbAlignment***)xcalloc(queriesLen ? queriesLen : 1, sizeof(DbAlignment**));
+    *dbAlignmentsLens = (int*)xcalloc(queriesLen ? queriesLen : 1, sizeof(int));
     if (queriesLen == 0 || cdb->length == 0) return;
     // one representative chain per distinct target length (the e-value depends on a target only through its length)
     std::vector<Chain*> reps;
@@ -766,7 +766,7 @@ SW_API void dbAlignmentsMerge(DbAlignment*** dst, int* dstLens, DbAlignment*** s
         if (b == 0) continue;
         const int total = a + b;
         const int keep = (maxAlignments >= 0 && total > maxAlignments) ? maxAlignments : total;
-        DbAlignment** merged = (DbAlignment**)malloc(sizeof(DbAlignment*) * (total ? total : 1));
+        DbAlignment** merged = (DbAlignment**)xmalloc(sizeof(DbAlignment*) * (total ? total : 1));
         int x = 0, y = 0, k = 0;
         while (x < a || y < b) {
             DbAlignment* pick;

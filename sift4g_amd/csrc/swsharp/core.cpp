@@ -12,12 +12,12 @@
 
 // ------------------------------------------------------------------------------------------------ Chain
 static Chain* make_chain(ChainData* d, int start, int length, bool reverse) {
-    Chain* c = (Chain*)calloc(1, sizeof(Chain));
+    Chain* c = (Chain*)xcalloc(1, sizeof(Chain));
     c->data = d; c->start = start; c->length = length; c->reverse = reverse;
     d->refs++;
     if (reverse && length > 0) {
-        c->rev_chars = (char*)malloc(length);
-        c->rev_codes = (char*)malloc(length);
+        c->rev_chars = (char*)xmalloc(length);
+        c->rev_codes = (char*)xmalloc(length);
         for (int i = 0; i < length; ++i) {
             c->rev_chars[i] = d->chars[start + length - 1 - i];
             c->rev_codes[i] = d->codes[start + length - 1 - i];
@@ -42,8 +42,7 @@ struct ResidueTable {
 const ResidueTable kResidue;
 
 ChainData* chain_data_alloc(const char* name, size_t nameLen, size_t seqCap) {
-    char* block = (char*)malloc(sizeof(ChainData) + nameLen + 1 + 2 * (seqCap + 1));
-    SW_ASSERT(block != NULL, "out of memory");
+    char* block = (char*)xmalloc(sizeof(ChainData) + nameLen + 1 + 2 * (seqCap + 1));
     ChainData* d = (ChainData*)block;
     d->name = block + sizeof(ChainData);
     d->chars = d->name + nameLen + 1;
@@ -140,7 +139,7 @@ void fasta_forget(FILE* fh) {
 void push_chain(Chain*** chains, int* len, int* cap, Chain* c) {
     if (*len == *cap) {
         *cap = *cap ? *cap * 2 : 1024;
-        *chains = (Chain**)realloc(*chains, sizeof(Chain*) * (size_t)*cap);
+        *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)*cap);
     }
     (*chains)[(*len)++] = c;
 }
@@ -209,7 +208,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
         }
         flush();
     }
-    if (*len < cap) *chains = (Chain**)realloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
+    if (*len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
     return st->eof ? 0 : 1;
 }
 
@@ -289,7 +288,7 @@ SW_API int scorerGetMaxScore(Scorer* s) { return s->max_score; }
 SW_API void cudaGetCards(int** cards, int* cardsLen) {
     int n = 0;
     if (s4g_device_count(&n) != S4G_OK) n = 0;
-    *cards = (int*)malloc(sizeof(int) * (n ? n : 1));
+    *cards = (int*)xmalloc(sizeof(int) * (n ? n : 1));
     for (int i = 0; i < n; ++i) (*cards)[i] = i;
     *cardsLen = n;
 }

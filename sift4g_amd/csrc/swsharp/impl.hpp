@@ -21,6 +21,12 @@
     } while (0)
 #define SW_ASSERT(expr, fmt, ...) do { if (!(expr)) SW_FATAL(fmt, ##__VA_ARGS__); } while (0)
 
+// malloc-domain allocations (callers free() what the API hands out) that fail the way the rest of the library does
+inline void* sw_alloc_check(void* p, size_t bytes) { if (!p && bytes) SW_FATAL("out of memory (%zu bytes)", bytes); return p; }
+inline void* xmalloc(size_t bytes) { return sw_alloc_check(malloc(bytes ? bytes : 1), bytes); }
+inline void* xcalloc(size_t n, size_t size) { return sw_alloc_check(calloc(n ? n : 1, size), n * size); }
+inline void* xrealloc(void* p, size_t bytes) { return sw_alloc_check(realloc(p, bytes ? bytes : 1), bytes); }
+
 struct ChainData {           // shared storage of a chain and its views
     char* name;
     char* chars;
