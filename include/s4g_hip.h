@@ -139,7 +139,8 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
  * packed int16 (bound <= 32767), else int32.  A query whose BOUND exceeds the drifting-frame window but whose frame fits it
  * with room to spare (long queries: the bound grows by ~5.6 per residue, real scores rarely do) still runs in that kernel,
  * speculatively: the kernel marks every result that came within one score step of the window's end, and an exact int32
- * pass (one wave per marked pair) recomputes just those before anything reads the scores.  flags below. */
+ * pass (one wave per marked pair) recomputes just those before anything reads the scores; when no drifting frame fits, the
+ * maximum3 tier does the same with its fixed window.  flags below. */
 #define S4G_SCAN_FORCE_I32 1u
 #define S4G_SCAN_NO_F16    2u   /* skip the v_pk_maximum3_f16 tier (those queries then run in the plain packed int16 kernel) */
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */

@@ -16,6 +16,7 @@ constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of 
 //          ... or speculatively: only the frame B + (rows + columns) * ext (+ a span) fits; the kernel marks results that
 //          came near the window's end and sw_pair_recheck recomputes those in int32 (Plan::speculative)
 //   m3     sw_scan_pk<I16M3>    bound + B <= 0x7BFF   (or ArithF16: bound <= 4096)     7.5
+//          ... or speculatively (I16M3 only) when no drift frame fits: results with best + B beyond 0x7BFF - max score are marked
 //   pk     sw_scan_pk<I16>      bound <= 32767                                          9
 //   wide   sw_scan_i32          anything                                                7.5 per single cell
 struct TileWork {
@@ -134,6 +135,10 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
                 p->speculative = true;
             }
             else if (!no_m3 && m3_gaps && b <= m3_window) tier = 1;
+            else if (!no_m3 && !no_spec && !p->f16_arith && m3_gaps && p->bias + step + kSpecSpan <= cap) {
+                tier = 1;               // the frame does not fit the drift window: same scheme in the fixed-frame maximum3 tier
+                p->speculative = true;
+            }
             else if (!(flags & S4G_SCAN_FORCE_I32) && gaps16 && b <= 32767) tier = 2;
             else tier = 3;
             ids[tier].push_back(id);
@@ -255,10 +260,12 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
             hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
         } else {
             a.floor_bits = p.bias | (p.bias << 16);
+            a.spec_base = p.speculative ? (uint32_t)(0x7BFF - std::max(0, scorer->max_score)) : 0;
             hipLaunchKernelGGL((sw_scan_pk<ArithI16M3, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
         }
         HIP_TRY(hipGetLastError());
     }
+    a.spec_base = 0;
     if (w.n_pk) {
         a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
         a.floor_bits = 0;

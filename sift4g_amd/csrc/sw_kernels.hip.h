@@ -26,6 +26,7 @@
 // add, max3, max(best), 3 saturating subs, 2 max  (8 VALU ops, int32).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace s4g {
@@ -461,10 +462,20 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
 #undef S4G_LAST_STRIP
             if (!done) pk_strip<A, R, R>(res, len4, prof, wsH, wsF, lane, first, last, best, open, ext, fl);   // full strip (or rr > 40)
         }
+        int outA = A::out(best, 0, fl), outB = A::out(best, 1, fl);
+        if constexpr (std::is_same<A, ArithI16M3>::value) {
+            // speculative launch of the fixed-frame maximum3 tier (see sw_scan_pkd for the argument; no frame term here):
+            // `best` is the biased H + B, and the first value to pass 0x7BFF is a diag + s whose diag was exact and
+            // already > spec_base = 0x7BFF - max score, so best <= spec_base => exact
+            if (a.spec_base) {
+                if (((unsigned)best & 0xFFFFu) > a.spec_base) outA = kScoreUnsure;
+                if (((unsigned)best >> 16) > a.spec_base) outB = kScoreUnsure;
+            }
+        }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) {
-            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = A::out(best, 0, fl);
-            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = A::out(best, 1, fl);
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = outA;
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = outB;
         }
     }
 }

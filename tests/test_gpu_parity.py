@@ -787,12 +787,14 @@ def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
     speculatively: results that come near the window's end are marked by the kernel and recomputed in int32 by
     sw_pair_recheck before anything reads them.  Targets: unrelated ones (far below the mark), whole copies and close
     homologs of the queries (self-scores of 11k .. 27k: above and below the mark, in both halves of a packed pair), with the
-    default gaps and with extend = 2 (a frame that drifts twice as fast: lower mark).  Scan and streaming top-k, against
+    default gaps, with extend = 2 (a frame that drifts twice as fast: lower mark) and with extend = 5 (no drift frame fits:
+    speculative maximum3 tier).  Scan and streaming top-k, against
     the oracle and against the tiers-by-bound routing (no_spec)."""
     rng = np.random.default_rng(61)
-    qlens = [2500, 3300, 4100, 5000, 4999, 2048, 900]
+    qlens = [2500, 3300, 4100, 5000, 4999, 2048, 900, 6000]
     qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
     ts = rand_seqs(rng, 150, 30, 900)
+    ts[60] = qs[7].copy()                          # self-score ~35 000: beyond int16 altogether, marked in every packed tier
     def mutate(src, frac, indel):
         x = src.copy()
         idx = rng.integers(0, len(x), size=int(len(x) * frac))
@@ -806,10 +808,11 @@ def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
     ts[50] = np.concatenate([rand_seqs(rng, 1, 300, 300)[0], qs[4][1000:4800], rand_seqs(rng, 1, 200, 200)[0]])
     ts[51] = np.concatenate([qs[5], qs[5]])
     q = s4g.QuerySet(qs)
-    for go, ge in ((10, 1), (11, 2)):
+    # (12, 5): a frame that no longer fits the drift window at these lengths -> the same scheme in the fixed-frame maximum3 tier
+    for go, ge in ((10, 1), (11, 2), (12, 5)):
         sc = s4g.Scorer("BLOSUM_62", go, ge)
         exp = oracle_mod.scan(qs, ts, blosum62, go, ge, threads=8)
-        assert exp.max() > 25000 and np.sort(exp[3])[-3] > 12000
+        assert exp.max() > 32767 and np.sort(exp[3])[-3] > 12000
         for tile_seqs in (0, 64):
             db = s4g.Database(ts, tile_seqs=tile_seqs)
             for mode in (dict(no_pairs=True), dict(no_spec=True), dict()):
@@ -842,8 +845,17 @@ sc = s4g.Scorer("BLOSUM_62", 10, 1)
 got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), sc, no_pairs=True)
 exp = oracle.scan(qs, ts, oracle.blosum62(), 10, 1, threads=8)
 marked = got == -2**31
-print(json.dumps(dict(marked=np.argwhere(marked).tolist(), exact_elsewhere=bool((got[~marked] == exp[~marked]).all()),
-                      marked_scores=exp[marked].tolist(), max_unmarked=int(exp[~marked].max()))))
+res = dict(marked=np.argwhere(marked).tolist(), exact_elsewhere=bool((got[~marked] == exp[~marked]).all()),
+           marked_scores=exp[marked].tolist(), max_unmarked=int(exp[~marked].max()))
+# extend = 5: no drift frame fits at these lengths -> the fixed-frame maximum3 tier, speculative for the long queries;
+# its window is on the score itself: only the 6000-residue self hit (~35 000) passes 0x7BFF - bias
+qs2 = qs[:2] + [rand_seqs(rng, 1, 6000, 6000)[0]]
+ts2 = ts[:20] + [qs2[2].copy()]
+got2 = s4g.scan_host(s4g.Database(ts2), s4g.QuerySet(qs2), s4g.Scorer("BLOSUM_62", 12, 5), no_pairs=True)
+exp2 = oracle.scan(qs2, ts2, oracle.blosum62(), 12, 5, threads=8)
+m2 = got2 == -2**31
+res.update(marked2=np.argwhere(m2).tolist(), exact_elsewhere2=bool((got2[~m2] == exp2[~m2]).all()), max_unmarked2=int(exp2[~m2].max()))
+print(json.dumps(res))
 """ % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, S4G_TEST_SKIP_RECHECK="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -852,6 +864,7 @@ print(json.dumps(dict(marked=np.argwhere(marked).tolist(), exact_elsewhere=bool(
     # self hits of the 5000- and 4200-residue queries (29k, 24k) lie beyond the limit (31 666 - frame); 2600 / 2500 (15k, 14k) do not
     assert [0, 5] in res["marked"] and [1, 6] in res["marked"] and [2, 7] not in res["marked"] and [3, 8] not in res["marked"]
     assert min(res["marked_scores"]) > 15000 and res["max_unmarked"] < 24000
+    assert res["marked2"] == [[2, 20]] and res["exact_elsewhere2"] and res["max_unmarked2"] > 28000      # 29 006 (query 0 vs its copy) stays exact
 
 
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
