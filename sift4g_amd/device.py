@@ -140,9 +140,16 @@ class Database(_SeqSet):
               "s4g_db_create_from_device")
         self.n = offsets.numel() - 1
         self.codes = None
-        self.offsets = offsets.cpu().numpy().astype(np.uint64)
-        self.lengths = np.diff(self.offsets).astype(np.uint32)
+        self._d_offsets = offsets           # host copies of offsets / lengths only when somebody asks (100 M targets: 1.6 GB)
         return self
+
+    def __getattr__(self, name):            # only reached for attributes that are not set: the lazy ones of from_device()
+        if name in ("offsets", "lengths") and "_d_offsets" in self.__dict__:
+            off = self.__dict__["_d_offsets"].cpu().numpy().view(np.uint64)
+            self.offsets = off
+            self.lengths = np.diff(off).astype(np.uint32)
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def tiles(self):
         n = ctypes.c_uint32()
