@@ -497,7 +497,12 @@ __device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned
     *above = acc;
 }
 
-__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n, uint32_t k, uint32_t kpad,
+// Grid (rows, segments): block (r, s) works on columns [s * seg_len, (s + 1) * seg_len) of row r and writes list number
+// s * rows + r.  With few rows one block per row leaves the chip idle while it reads a million scores four times over;
+// the caller then cuts the rows into segments and merges the segment lists (merge_rows keys on (score, id), so the
+// result is the same exact top-k).
+__global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n_cols, uint32_t seg_len,
+                                                        uint32_t k, uint32_t kpad,
                                                         int32_t min_score, uint32_t* __restrict__ out_ids,
                                                         int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
                                                         const uint32_t* __restrict__ col_ids,
@@ -507,7 +512,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
     __shared__ int s_hi, s_cut;
     __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
     const int tid = threadIdx.x;
-    const int32_t* row = scores + (uint64_t)blockIdx.x * n;
+    const uint32_t c0 = blockIdx.y * seg_len;
+    const uint32_t n = c0 < n_cols ? (n_cols - c0 < seg_len ? n_cols - c0 : seg_len) : 0;
+    const int32_t* row = scores + (uint64_t)blockIdx.x * n_cols + c0;
+    const uint64_t slot = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (row_min_scores) min_score = row_min_scores[blockIdx.x];       // per-query cut (e-value driven)
     if (min_score < 0) min_score = 0;
 
@@ -585,10 +593,10 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
     for (unsigned i = tid; i < k; i += kTopkBlock) {
         const unsigned long long key = keys[i];
         const bool valid = i < m;
-        out_ids[(uint64_t)blockIdx.x * k + i] = valid ? (col_ids ? col_ids[(uint32_t)key] : (uint32_t)key) : 0xFFFFFFFFu;
-        out_scores[(uint64_t)blockIdx.x * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+        out_ids[slot * k + i] = valid ? (col_ids ? col_ids[c0 + (uint32_t)key] : c0 + (uint32_t)key) : 0xFFFFFFFFu;
+        out_scores[slot * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
     }
-    if (tid == 0) out_counts[blockIdx.x] = m;
+    if (tid == 0) out_counts[slot] = m;
 }
 
 // running[q] <- best k of (running[q] U cand[q]) under (score desc, id asc); both inputs hold global ids.
@@ -638,7 +646,7 @@ S4G_API int s4g_topk(const s4g_db* db, const int32_t* d_scores, uint32_t q_count
     DeviceGuard guard(db->device);
     uint32_t kpad = 2;
     while (kpad < k) kpad <<= 1;
-    hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, k, kpad,
+    hipLaunchKernelGGL(topk_rows, dim3(q_count), dim3(kTopkBlock), 0, (hipStream_t)stream_, d_scores, db->n_seqs, db->n_seqs, k, kpad,
                        min_score, d_ids, d_top_scores, d_counts, (const uint32_t*)nullptr, (const int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return S4G_OK;
@@ -702,7 +710,9 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     ensure_bounds(q, scorer);
     const uint64_t cols = db->max_tile_seqs;
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
-    const uint64_t need = (uint64_t)batch * cols * 4 + (uint64_t)batch * k * 8 + (uint64_t)batch * 4;
+    // candidate lists of one tile: one per (row, segment); few rows are cut into up to 16 segments (<= 256 lists)
+    const uint64_t lists_max = std::max<uint64_t>(batch, 256);
+    const uint64_t need = (uint64_t)batch * cols * 4 + lists_max * k * 8 + lists_max * 4;
     if (cx->tile_scores_bytes < need) {
         if (cx->d_tile_scores) HIP_TRY(hipFree(cx->d_tile_scores));
         cx->d_tile_scores = nullptr; cx->tile_scores_bytes = 0;
@@ -711,8 +721,8 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     }
     int32_t* d_buf = cx->d_tile_scores;
     uint32_t* c_ids = reinterpret_cast<uint32_t*>(d_buf + (uint64_t)batch * cols);
-    int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + (uint64_t)batch * k);
-    uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + (uint64_t)batch * k);
+    int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + lists_max * k);
+    uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + lists_max * k);
     uint32_t kpad = 2, kpad2;
     while (kpad < k) kpad <<= 1;
     kpad2 = kpad * 2;
@@ -753,10 +763,15 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
                 rc = recheck_marked(db, q, scorer, q_begin + b, cnt, d_buf, t.n_seqs, t.n_seqs, t.d_col_ids, t.max_len4 * 4, stream);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(topk_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, k, kpad, min_score, c_ids,
+            // segments: enough blocks to fill the chip when the batch is small, and no segment shorter than 16k columns
+            const uint32_t segs = std::max(1u, std::min(std::min(16u, 256u / std::max(1u, cnt)), (t.n_seqs + 16383u) / 16384u));
+            const uint32_t seg_len = ((t.n_seqs + segs - 1) / segs + 255u) / 256u * 256u;
+            hipLaunchKernelGGL(topk_rows, dim3(cnt, segs), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, seg_len, k, kpad, min_score, c_ids,
                                c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
-            hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
-                               d_top_scores + (uint64_t)b * k, d_counts + b, c_ids, c_sc, c_cnt, k, kpad2);
+            for (uint32_t sgm = 0; sgm < segs; ++sgm)
+                hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
+                                   d_top_scores + (uint64_t)b * k, d_counts + b, c_ids + (uint64_t)sgm * cnt * k,
+                                   c_sc + (uint64_t)sgm * cnt * k, c_cnt + (uint64_t)sgm * cnt, k, kpad2);
             HIP_TRY(hipGetLastError());
         }
     }

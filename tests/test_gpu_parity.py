@@ -366,6 +366,35 @@ def test_streaming_scan_topk_equals_full_matrix_topk(s4g, oracle_mod, blosum62, 
         assert np.array_equal(sub[0].cpu().numpy(), s4g.scan_topk(db, q, scorer, 10, 1)[0][4:7].cpu().numpy())
 
 
+def test_streaming_topk_segments_for_small_batches(s4g, scorer):
+    """few queries x a wide tile: the tile's top-k runs as several column segments per row whose lists are merged.  70 000
+    short targets (scores in a narrow range: thousands of ties at every cut, across segment borders), 1 .. 5 queries,
+    k from 1 to 1500, also tiled -- the same lists as the top-k of the full score matrix."""
+    import torch
+    rng = np.random.default_rng(71)
+    qs = rand_seqs(rng, 5, 40, 90)
+    ts = rand_seqs(rng, 70000, 8, 40)
+    for j in range(0, 70000, 997):
+        ts[j] = qs[j % 5][:30].copy()
+    q = s4g.QuerySet(qs)
+    for tile_seqs in (0, 40000):
+        db = s4g.Database(ts, tile_seqs=tile_seqs)
+        full = torch.empty((len(qs), len(ts)), dtype=torch.int32, device="cuda:0")
+        s4g.scan(db, q, scorer, full)
+        for nq in (1, 2, 5):
+            for k, ms in ((1, 1), (400, 1), (1500, 12)):
+                want = s4g.topk(db, full[:nq].contiguous(), k, ms)
+                ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms, q_begin=0, q_count=nq)
+                torch.cuda.synchronize()
+                assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), want[2]), (tile_seqs, nq, k)
+                assert np.array_equal(sc.cpu().numpy(), want[1]), (tile_seqs, nq, k)
+                assert np.array_equal(ids.cpu().numpy().astype(np.uint32), want[0]), (tile_seqs, nq, k)
+        row = full[0].cpu().numpy()                      # and one row against numpy directly
+        order = sorted(range(len(ts)), key=lambda j: (-int(row[j]), j))[:400]
+        got = s4g.scan_topk(db, q, scorer, 400, 1, q_begin=0, q_count=1)[0][0].cpu().tolist()
+        assert got == order
+
+
 def test_device_traceback_equals_oracle(s4g, oracle_mod, blosum62, scorer):
     """s4g_traceback_host: end cell, start cell and the whole move string of every pair equal the oracle's traceback
     (same tie rules as the host traceback in libswsharp)."""
