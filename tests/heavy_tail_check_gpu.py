@@ -1,5 +1,12 @@
+#!/usr/bin/env python3
+"""Test infrastructure (it checks against the CPU oracle, so it lives under tests/): 200 queries x 200 000 targets plus six
+titin-sized outliers (15k .. 35k residues, one holding a planted copy of query 0) -- tiles, the long-sequence tile's pair
+route, spot checks of the scan against the oracle, streaming top-k against the top-k of the full matrix.
+usage: python tests/heavy_tail_check_gpu.py"""
+import os
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import sift4g_amd as s4g, oracle
 from sift4g_amd import synth
 cfg = synth.make_config(2, n_queries=200, n_targets=200000)
