@@ -8,10 +8,11 @@
 // S4G_PROFILE=1: cumulative host time of the database-creation phases, printed at exit (diagnostic only)
 struct CreateClock {
     double t[4] = {0, 0, 0, 0};
+    double ranks = 0;          // per-tile id ranks (bitmap + prefix counts)
     long n = 0;
     bool on = getenv("S4G_PROFILE") != nullptr;
     ~CreateClock() {
-        if (on && n) fprintf(stderr, "[s4g profile] s4g_db_create x%ld: lengths+sort %.3f s, host pack %.3f s, tile upload (+ device pack) %.3f s, raw codes upload %.3f s\n", n, t[0], t[1], t[2], t[3]);
+        if (on && n) fprintf(stderr, "[s4g profile] s4g_db_create x%ld: lengths+sort %.3f s, host pack %.3f s, tile upload (+ device pack) %.3f s, raw codes upload %.3f s, tile id ranks %.3f s\n", n, t[0], t[1], t[2], t[3], ranks);
     }
 } g_create_clock;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -129,6 +130,7 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
                       const uint8_t* codes, const uint64_t* offsets, std::string* err, uint64_t extra_bytes = 0,
                       uint64_t* extra_off = nullptr, const uint8_t* d_raw = nullptr, int* d_bad = nullptr,
                       const uint8_t* const* seq_ptrs = nullptr) {
+    const double t_enter = now_s();
     const uint32_t n = (uint32_t)(p1 - p0);
     const uint32_t G = (n + 63) / 64;
     t.n_seqs = n; t.n_groups = G;
@@ -166,6 +168,7 @@ hipError_t build_tile(s4g_db* db, Tile& t, const std::vector<uint32_t>& order, s
         return whole ? id : before[id >> 6] + (uint32_t)__builtin_popcountll(member[id >> 6] & ((1ull << (id & 63)) - 1));
     };
     std::vector<uint32_t> perm_g((size_t)G * 64, 0xFFFFFFFFu), perm_l((size_t)G * 64, 0xFFFFFFFFu);
+    g_create_clock.ranks += now_s() - t_enter;
     if (d_raw) {
         const double t_pack0 = now_s();
         std::vector<uint64_t> src_off((size_t)G * 64, 0);
@@ -384,9 +387,13 @@ S4G_API int s4g_db_create_from_device(s4g_db** out, int device, const uint8_t* d
     if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
     if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
     DeviceGuard guard(device);
+    const double t0 = now_s();
     std::vector<uint64_t> offsets((size_t)n_seqs + 1);
     HIP_TRY(hipMemcpy(offsets.data(), d_offsets, offsets.size() * 8, hipMemcpyDeviceToHost));    // only the lengths come to the host
-    return db_create_impl(out, device, nullptr, d_codes, offsets.data(), n_seqs, max_tile_seqs);
+    const double t1 = now_s();
+    const int rc = db_create_impl(out, device, nullptr, d_codes, offsets.data(), n_seqs, max_tile_seqs);
+    if (g_create_clock.on) fprintf(stderr, "[s4g profile] s4g_db_create_from_device: offsets to host %.3f s, create %.3f s\n", t1 - t0, now_s() - t1);
+    return rc;
 }
 
 int db_create_impl(s4g_db** out, int device, const uint8_t* codes, const uint8_t* d_codes, const uint64_t* offsets, uint32_t n_seqs,
