@@ -118,6 +118,7 @@ struct DeviceCtx {
     // main tiles instead of as a tail-dominated launch of their own
     hipStream_t side_stream = nullptr;
     hipEvent_t side_fork = nullptr, side_join = nullptr;
+    hipEvent_t merge_done[2] = {nullptr, nullptr};          // s4g_scan_topk with alternating tiles: the running lists are merged in tile order
     int32_t* d_ws_side = nullptr;
     uint64_t ws_side_bytes = 0;
     std::vector<std::pair<char*, uint64_t>> block_cache;    // freed small-tile blocks, reused by the next s4g_db_create

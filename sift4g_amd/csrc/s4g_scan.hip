@@ -712,7 +712,11 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
     // candidate lists of one tile: one per (row, segment); few rows are cut into up to 16 segments (<= 256 lists)
     const uint64_t lists_max = std::max<uint64_t>(batch, 256);
-    const uint64_t need = (uint64_t)batch * cols * 4 + lists_max * k * 8 + lists_max * 4;
+    // with three or more tiles, consecutive tiles alternate between two score buffers, two workspaces and two streams, so that
+    // a tile's launch tail and its top-k run underneath the next tile's scan
+    const bool two_sets = db->tiles.size() >= 3;
+    const uint64_t set_bytes = ((uint64_t)batch * cols * 4 + lists_max * k * 8 + lists_max * 4 + 255) / 256 * 256;
+    const uint64_t need = set_bytes * (two_sets ? 2 : 1);
     if (cx->tile_scores_bytes < need) {
         if (cx->d_tile_scores) HIP_TRY(hipFree(cx->d_tile_scores));
         cx->d_tile_scores = nullptr; cx->tile_scores_bytes = 0;
@@ -734,11 +738,69 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         if (rc) return rc;
         rc = ensure_scratch(db, scorer, p, stream);
         if (rc) return rc;
+        std::vector<uint32_t> g0s(db->tiles.size(), 0);
+        bool plain = two_sets && !p.speculative;       // every tile entirely on the scan kernels, nothing to recheck
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            const Tile& t = db->tiles[ti];
+            g0s[ti] = (uint64_t)cnt * t.n_seqs <= 0xFFFFFFFFull ? split_groups(db, t, q, q_begin + b, cnt, flags) : 0;
+            plain = plain && g0s[ti] == 0;
+        }
+        auto tile_topk = [&](const Tile& t, int32_t* buf, uint32_t* l_ids, int32_t* l_sc, uint32_t* l_cnt, hipStream_t st, hipEvent_t after) -> int {
+            // segments: enough blocks to fill the chip when the batch is small, and no segment shorter than 16k columns
+            const uint32_t segs = std::max(1u, std::min(std::min(16u, 256u / std::max(1u, cnt)), (t.n_seqs + 16383u) / 16384u));
+            const uint32_t seg_len = ((t.n_seqs + segs - 1) / segs + 255u) / 256u * 256u;
+            hipLaunchKernelGGL(topk_rows, dim3(cnt, segs), dim3(kTopkBlock), 0, st, buf, t.n_seqs, seg_len, k, kpad, min_score, l_ids,
+                               l_sc, l_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
+            if (after) HIP_TRY(hipStreamWaitEvent(st, after, 0));        // the running lists are merged in tile order
+            for (uint32_t sgm = 0; sgm < segs; ++sgm)
+                hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, st, d_ids + (uint64_t)b * k,
+                                   d_top_scores + (uint64_t)b * k, d_counts + b, l_ids + (uint64_t)sgm * cnt * k,
+                                   l_sc + (uint64_t)sgm * cnt * k, l_cnt + (uint64_t)sgm * cnt, k, kpad2);
+            HIP_TRY(hipGetLastError());
+            return S4G_OK;
+        };
+        if (plain) {
+            if (!cx->side_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+            }
+            for (hipEvent_t& e : cx->merge_done)
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            if (cx->ws_side_bytes < p.ws_bytes) {
+                if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
+                cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&cx->d_ws_side, p.ws_bytes));
+                cx->ws_side_bytes = p.ws_bytes;
+            }
+            HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after this batch's uploads
+            HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+            int last = -1;
+            for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+                const Tile& t = db->tiles[ti];
+                if (t.n_seqs == 0) continue;
+                const int par = (int)(ti & 1);
+                hipStream_t st = par ? cx->side_stream : stream;
+                char* set = reinterpret_cast<char*>(cx->d_tile_scores) + (uint64_t)par * set_bytes;
+                int32_t* buf = reinterpret_cast<int32_t*>(set);
+                uint32_t* l_ids = reinterpret_cast<uint32_t*>(buf + (uint64_t)batch * cols);
+                int32_t* l_sc = reinterpret_cast<int32_t*>(l_ids + lists_max * k);
+                uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_sc + lists_max * k);
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, buf, t.n_seqs, t.d_perm_local, st, par != 0);
+                if (rc) return rc;
+                rc = tile_topk(t, buf, l_ids, l_sc, l_cnt, st, last >= 0 && last != par ? cx->merge_done[last] : nullptr);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(cx->merge_done[par], st));
+                last = par;
+            }
+            if (last == 1) HIP_TRY(hipStreamWaitEvent(stream, cx->merge_done[1], 0));
+            continue;
+        }
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
             // same routing as s4g_scan (split_groups): the tile's longest groups to one wave per pair (on the side stream
             // when the scan kernels take the rest), joined before the tile's top-k
-            const uint32_t g0 = (uint64_t)cnt * t.n_seqs <= 0xFFFFFFFFull ? split_groups(db, t, q, q_begin + b, cnt, flags) : 0;
+            const uint32_t g0 = g0s[ti];
             if (g0 >= t.n_groups && t.n_seqs) {
                 rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream, t.n_seqs);
             } else if (g0) {
@@ -763,16 +825,9 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
                 rc = recheck_marked(db, q, scorer, q_begin + b, cnt, d_buf, t.n_seqs, t.n_seqs, t.d_col_ids, t.max_len4 * 4, stream);
                 if (rc) return rc;
             }
-            // segments: enough blocks to fill the chip when the batch is small, and no segment shorter than 16k columns
-            const uint32_t segs = std::max(1u, std::min(std::min(16u, 256u / std::max(1u, cnt)), (t.n_seqs + 16383u) / 16384u));
-            const uint32_t seg_len = ((t.n_seqs + segs - 1) / segs + 255u) / 256u * 256u;
-            hipLaunchKernelGGL(topk_rows, dim3(cnt, segs), dim3(kTopkBlock), 0, stream, d_buf, t.n_seqs, seg_len, k, kpad, min_score, c_ids,
-                               c_sc, c_cnt, (const uint32_t*)t.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
-            for (uint32_t sgm = 0; sgm < segs; ++sgm)
-                hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
-                                   d_top_scores + (uint64_t)b * k, d_counts + b, c_ids + (uint64_t)sgm * cnt * k,
-                                   c_sc + (uint64_t)sgm * cnt * k, c_cnt + (uint64_t)sgm * cnt, k, kpad2);
-            HIP_TRY(hipGetLastError());
+            if (t.n_seqs == 0) continue;
+            rc = tile_topk(t, d_buf, c_ids, c_sc, c_cnt, stream, nullptr);
+            if (rc) return rc;
         }
     }
     return scratch_release(db, stream);

@@ -354,11 +354,14 @@ def test_streaming_scan_topk_equals_full_matrix_topk(s4g, oracle_mod, blosum62, 
         s4g.scan(db, q, scorer, full)
         for k, ms in ((1, 1), (25, 1), (400, 20), (1500, 1)):
             want = s4g.topk(db, full, k, ms)
+            # scan kernels only: with three or more tiles consecutive tiles alternate between two streams / buffers / workspaces
+            alt = s4g.scan_topk(db, q, scorer, k, ms, no_pairs=True)
             ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms)
             torch.cuda.synchronize()
             assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), want[2])
             assert np.array_equal(sc.cpu().numpy(), want[1])
             assert np.array_equal(ids.cpu().numpy().astype(np.uint32), want[0])
+            assert all(np.array_equal(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(alt, (ids, sc, cnt))), (tile_seqs, k)
             for i in range(len(qs)):                   # and against the oracle directly
                 order = sorted((j for j in range(len(ts)) if exp[i, j] >= ms), key=lambda j: (-exp[i, j], j))[:k]
                 assert ids[i, :len(order)].cpu().tolist() == order
@@ -377,14 +380,14 @@ def test_streaming_topk_segments_for_small_batches(s4g, scorer):
     for j in range(0, 70000, 997):
         ts[j] = qs[j % 5][:30].copy()
     q = s4g.QuerySet(qs)
-    for tile_seqs in (0, 40000):
+    for tile_seqs in (0, 40000, 16384):              # 16384: five tiles, scan kernels only -> alternating tiles
         db = s4g.Database(ts, tile_seqs=tile_seqs)
         full = torch.empty((len(qs), len(ts)), dtype=torch.int32, device="cuda:0")
         s4g.scan(db, q, scorer, full)
         for nq in (1, 2, 5):
             for k, ms in ((1, 1), (400, 1), (1500, 12)):
                 want = s4g.topk(db, full[:nq].contiguous(), k, ms)
-                ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms, q_begin=0, q_count=nq)
+                ids, sc, cnt = s4g.scan_topk(db, q, scorer, k, ms, q_begin=0, q_count=nq, no_pairs=(tile_seqs == 16384))
                 torch.cuda.synchronize()
                 assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), want[2]), (tile_seqs, nq, k)
                 assert np.array_equal(sc.cpu().numpy(), want[1]), (tile_seqs, nq, k)
