@@ -49,13 +49,13 @@ while time.time() < t_end:
     ctx = (it, go, ge, nq, nt, qmax, tmax)
     for mode in (dict(), dict(no_pairs=True), dict(force_i32=True), dict(no_spec=True)):
         assert np.array_equal(s4g.scan_host(db, q, sc, **mode), exp), ("scan", mode, ctx)
-    if long_mode:
-        k = min(5, nt)
-        ids, top, cnt = s4g.scan_topk(db, q, sc, k, no_pairs=True)
+    k = int(rng.integers(1, min(nt, 40) + 1))               # streaming top-k: tiles (alternating when >= 3), segments, both routings
+    for mode in (dict(no_pairs=True), dict()):
+        ids, top, cnt = s4g.scan_topk(db, q, sc, k, **mode)
         ids, top = ids.cpu().numpy(), top.cpu().numpy()
         for i in range(nq):
             order = [t for t in sorted(range(nt), key=lambda t: (-int(exp[i, t]), t)) if exp[i, t] >= 1][:k]
-            assert ids[i, :len(order)].tolist() == order and top[i, :len(order)].tolist() == [int(exp[i, t]) for t in order], ("topk", ctx, i)
+            assert ids[i, :len(order)].tolist() == order and top[i, :len(order)].tolist() == [int(exp[i, t]) for t in order], ("topk", mode, ctx, i)
     n = int(rng.integers(1, 400)); pq = rng.integers(0, nq, size=n); pt = rng.integers(0, nt, size=n)
     for route in ("wave", "scan", None):
         assert np.array_equal(s4g.score_pairs(db, q, sc, pq, pt, route=route), exp[pq, pt]), ("pairs", route, ctx)
