@@ -64,6 +64,7 @@ struct Tile {
     uint32_t* d_perm_local = nullptr;   // [G*64] column in the tile's own score buffer = rank of the id inside the tile
     uint32_t* d_col_ids = nullptr;      // [n_seqs] tile column -> original target id (ascending)
     std::vector<uint64_t> h_grp_off;    // host copy (traceback addresses lanes of arbitrary targets)
+    mutable std::vector<uint32_t> h_col_of_pos;     // tile column (rank of the id) of the sequence at tile position p; built on first use (tile_as_pairs)
     char* d_block = nullptr;            // small tiles: every array above lives in this one allocation (recycled through
     uint64_t block_bytes = 0;           // DeviceCtx::block_cache: sift4g creates a candidate database per query)
     uint64_t pos0 = 0;                  // position of the tile's first sequence in the global length-sorted order
@@ -97,7 +98,9 @@ struct DeviceCtx {
     int32_t* d_ws = nullptr;
     uint64_t ws_bytes = 0;
     unsigned* d_counter = nullptr;
-    int8_t* d_mat = nullptr;
+    int8_t* d_mat = nullptr;                // the substitution table the kernels read; see ensure_mat
+    uint64_t mat_serial = 0;                // s4g_scorer::serial of the table d_mat holds (0: none)
+    hipEvent_t mat_ready = nullptr;         // its upload
     uint32_t* d_qlist = nullptr;     // query-id lists of the current call (pairs for the packed tiers, singles for int32)
     uint64_t qlist_cap = 0;
     int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
@@ -171,6 +174,11 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
 // after a speculative sw_scan_pkd launch: recomputes the marked entries of scores[q_count][n_cols] (row stride `stride`) exactly;
 // d_col_ids maps a column to its target id (NULL: identity); max_lt = longest target behind those columns.  cx->d_mat holds the
 // scorer's table already (ensure_scratch).  Caller holds cx->mu.
+// d_mat <- the scorer's table, on `stream`, unless it is there already (then `stream` only waits for that upload).  The table
+// sits in pageable host memory, so an upload blocks the HOST until everything queued on `stream` before it is done -- which is
+// what made a pairs submission on the side stream serialise the caller behind the side stream's earlier kernels.  Callers have
+// passed scratch_acquire (no launch of another scorer is still reading d_mat).  Caller holds cx->mu.
+int ensure_mat(DeviceCtx* cx, const s4g_scorer* scorer, hipStream_t stream);
 int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count,
                    int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream);
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,

@@ -213,7 +213,7 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
         HIP_TRY(hipMalloc((void**)&cx->d_qlist, need * 4));
         cx->qlist_cap = need;
     }
-    HIP_TRY(hipMemcpyAsync(cx->d_mat, sc->mat32, 1024, hipMemcpyHostToDevice, stream));
+    { const int rcm = ensure_mat(cx, sc, stream); if (rcm) return rcm; }
     if (need) HIP_TRY(hipMemcpyAsync(cx->d_qlist, p.flat.data(), need * 4, hipMemcpyHostToDevice, stream));
     return S4G_OK;
 }
@@ -291,6 +291,16 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
 
 // The scratch buffers (workspace, work-queue counter, query lists) are shared by all launches on this database:
 // a launch on another stream must not start before the previous one has finished with them.
+int ensure_mat(DeviceCtx* cx, const s4g_scorer* scorer, hipStream_t stream) {
+    if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
+    if (!cx->mat_ready) HIP_TRY(hipEventCreateWithFlags(&cx->mat_ready, hipEventDisableTiming));
+    if (cx->mat_serial == scorer->serial && scorer->serial != 0) return hipStreamWaitEvent(stream, cx->mat_ready, 0) == hipSuccess ? S4G_OK : fail(S4G_ERR_HIP, "hipStreamWaitEvent failed");
+    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(cx->mat_ready, stream));
+    cx->mat_serial = scorer->serial;
+    return S4G_OK;
+}
+
 int scratch_acquire(const s4g_db* db, hipStream_t stream) {
     DeviceCtx* cx = device_ctx(db->device);
     if (!cx->last_use) HIP_TRY(hipEventCreateWithFlags(&cx->last_use, hipEventDisableTiming));
@@ -712,9 +722,10 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
     // candidate lists of one tile: one per (row, segment); few rows are cut into up to 16 segments (<= 256 lists)
     const uint64_t lists_max = std::max<uint64_t>(batch, 256);
-    // with three or more tiles, consecutive tiles alternate between two score buffers, two workspaces and two streams, so that
-    // a tile's launch tail and its top-k run underneath the next tile's scan
-    const bool two_sets = db->tiles.size() >= 3;
+    // with several tiles, two sets of score buffers / candidate lists (and two streams): consecutive scan tiles alternate between
+    // them, so that a tile's launch tail and its top-k run underneath the next tile's scan; a tile that goes to the pair kernels
+    // as a whole (the long-sequence tile of a real database) runs on the second set beside the first scan tile
+    const bool two_sets = db->tiles.size() >= 2;
     const uint64_t set_bytes = ((uint64_t)batch * cols * 4 + lists_max * k * 8 + lists_max * 4 + 255) / 256 * 256;
     const uint64_t need = set_bytes * (two_sets ? 2 : 1);
     if (cx->tile_scores_bytes < need) {
@@ -723,10 +734,6 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         HIP_TRY(hipMalloc((void**)&cx->d_tile_scores, need));
         cx->tile_scores_bytes = need;
     }
-    int32_t* d_buf = cx->d_tile_scores;
-    uint32_t* c_ids = reinterpret_cast<uint32_t*>(d_buf + (uint64_t)batch * cols);
-    int32_t* c_sc = reinterpret_cast<int32_t*>(c_ids + lists_max * k);
-    uint32_t* c_cnt = reinterpret_cast<uint32_t*>(c_sc + lists_max * k);
     uint32_t kpad = 2, kpad2;
     while (kpad < k) kpad <<= 1;
     kpad2 = kpad * 2;
@@ -738,13 +745,23 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         if (rc) return rc;
         rc = ensure_scratch(db, scorer, p, stream);
         if (rc) return rc;
+        // Kinds of tile: entirely on the scan kernels (g0 = 0), entirely on the pair kernels (the long-sequence tile of a real
+        // database), or split (its longest groups as pairs on the side stream, the rest on the scan kernels).  With two sets:
+        //   * a pair tile runs on the side stream with the second set, beside the scan tiles;
+        //   * if every tile is a scan tile (and there are three or more), consecutive tiles alternate between the sets;
+        //   * everything else runs on the caller's stream with the first set.
+        // The running lists are merged in tile order whatever stream a tile ran on (events).  A speculative plan keeps to
+        // one set: the recheck pass has one boundary workspace.
         std::vector<uint32_t> g0s(db->tiles.size(), 0);
-        bool plain = two_sets && !p.speculative;       // every tile entirely on the scan kernels, nothing to recheck
+        size_t n_scan_tiles = 0, n_other_tiles = 0;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
             g0s[ti] = (uint64_t)cnt * t.n_seqs <= 0xFFFFFFFFull ? split_groups(db, t, q, q_begin + b, cnt, flags) : 0;
-            plain = plain && g0s[ti] == 0;
+            if (t.n_seqs == 0) continue;
+            if (g0s[ti] == 0) ++n_scan_tiles; else ++n_other_tiles;
         }
+        const bool overlap = two_sets && !p.speculative;
+        const bool alternate = overlap && n_other_tiles == 0 && n_scan_tiles >= 3;
         auto tile_topk = [&](const Tile& t, int32_t* buf, uint32_t* l_ids, int32_t* l_sc, uint32_t* l_cnt, hipStream_t st, hipEvent_t after) -> int {
             // segments: enough blocks to fill the chip when the batch is small, and no segment shorter than 16k columns
             const uint32_t segs = std::max(1u, std::min(std::min(16u, 256u / std::max(1u, cnt)), (t.n_seqs + 16383u) / 16384u));
@@ -759,7 +776,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             HIP_TRY(hipGetLastError());
             return S4G_OK;
         };
-        if (plain) {
+        if (overlap || n_other_tiles) {
             if (!cx->side_stream) {
                 HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
@@ -767,68 +784,54 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             }
             for (hipEvent_t& e : cx->merge_done)
                 if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            if (cx->ws_side_bytes < p.ws_bytes) {
-                if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
-                cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
-                HIP_TRY(hipMalloc((void**)&cx->d_ws_side, p.ws_bytes));
-                cx->ws_side_bytes = p.ws_bytes;
-            }
             HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after this batch's uploads
             HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
-            int last = -1;
-            for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
-                const Tile& t = db->tiles[ti];
-                if (t.n_seqs == 0) continue;
-                const int par = (int)(ti & 1);
-                hipStream_t st = par ? cx->side_stream : stream;
-                char* set = reinterpret_cast<char*>(cx->d_tile_scores) + (uint64_t)par * set_bytes;
-                int32_t* buf = reinterpret_cast<int32_t*>(set);
-                uint32_t* l_ids = reinterpret_cast<uint32_t*>(buf + (uint64_t)batch * cols);
-                int32_t* l_sc = reinterpret_cast<int32_t*>(l_ids + lists_max * k);
-                uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_sc + lists_max * k);
-                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, buf, t.n_seqs, t.d_perm_local, st, par != 0);
-                if (rc) return rc;
-                rc = tile_topk(t, buf, l_ids, l_sc, l_cnt, st, last >= 0 && last != par ? cx->merge_done[last] : nullptr);
-                if (rc) return rc;
-                HIP_TRY(hipEventRecord(cx->merge_done[par], st));
-                last = par;
-            }
-            if (last == 1) HIP_TRY(hipStreamWaitEvent(stream, cx->merge_done[1], 0));
-            continue;
         }
+        if (alternate && cx->ws_side_bytes < p.ws_bytes) {
+            if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
+            cx->d_ws_side = nullptr; cx->ws_side_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&cx->d_ws_side, p.ws_bytes));
+            cx->ws_side_bytes = p.ws_bytes;
+        }
+        int last = -1;          // set / stream of the previous tile's merge
+        size_t scan_seen = 0;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            // same routing as s4g_scan (split_groups): the tile's longest groups to one wave per pair (on the side stream
-            // when the scan kernels take the rest), joined before the tile's top-k
+            if (t.n_seqs == 0) continue;
             const uint32_t g0 = g0s[ti];
-            if (g0 >= t.n_groups && t.n_seqs) {
-                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, stream, t.n_seqs);
-            } else if (g0) {
-                if (!cx->side_stream) {
-                    HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
-                    HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
-                    HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
-                }
+            const bool as_pairs = g0 >= t.n_groups;
+            const int par = !overlap ? 0 : as_pairs ? 1 : (alternate ? (int)(scan_seen++ & 1) : 0);
+            hipStream_t st = par ? cx->side_stream : stream;
+            char* set = reinterpret_cast<char*>(cx->d_tile_scores) + (uint64_t)par * set_bytes;
+            int32_t* buf = reinterpret_cast<int32_t*>(set);
+            uint32_t* l_ids = reinterpret_cast<uint32_t*>(buf + (uint64_t)batch * cols);
+            int32_t* l_sc = reinterpret_cast<int32_t*>(l_ids + lists_max * k);
+            uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_sc + lists_max * k);
+            if (as_pairs) {
+                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, buf, t.n_seqs, true, st, t.n_seqs);
+            } else if (g0) {        // split tile (always on the caller's stream): its longest groups as pairs on the side stream
                 HIP_TRY(hipEventRecord(cx->side_fork, stream));
-                HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
-                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, d_buf, t.n_seqs, true, cx->side_stream, g0 * 64);
+                HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));       // the buffer's previous reader (top-k) is done
+                rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, buf, t.n_seqs, true, cx->side_stream, g0 * 64);
                 if (rc) return rc;
                 HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
-                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream, false, g0);
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, buf, t.n_seqs, t.d_perm_local, stream, false, g0);
                 if (rc) return rc;
                 HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
             } else {
-                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, d_buf, t.n_seqs, t.d_perm_local, stream);
+                rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin + b, buf, t.n_seqs, t.d_perm_local, st, par != 0);
             }
             if (rc) return rc;
-            if (p.speculative && t.n_seqs && g0 < t.n_groups) {
-                rc = recheck_marked(db, q, scorer, q_begin + b, cnt, d_buf, t.n_seqs, t.n_seqs, t.d_col_ids, t.max_len4 * 4, stream);
+            if (p.speculative && !as_pairs) {
+                rc = recheck_marked(db, q, scorer, q_begin + b, cnt, buf, t.n_seqs, t.n_seqs, t.d_col_ids, t.max_len4 * 4, st);
                 if (rc) return rc;
             }
-            if (t.n_seqs == 0) continue;
-            rc = tile_topk(t, d_buf, c_ids, c_sc, c_cnt, stream, nullptr);
+            rc = tile_topk(t, buf, l_ids, l_sc, l_cnt, st, last >= 0 && last != par ? cx->merge_done[last] : nullptr);
             if (rc) return rc;
+            if (overlap) HIP_TRY(hipEventRecord(cx->merge_done[par], st));
+            last = par;
         }
+        if (last == 1) HIP_TRY(hipStreamWaitEvent(stream, cx->merge_done[1], 0));
     }
     return scratch_release(db, stream);
 }

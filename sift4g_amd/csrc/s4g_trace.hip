@@ -69,7 +69,7 @@ int traceback_groups(const s4g_db* db, const s4g_queries* q, const s4g_scorer* s
     if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
     if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
     if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));      // a scan on another stream may still read d_mat
-    HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
+    { const int rcm = ensure_mat(cx, scorer, stream); if (rcm) return rcm; }
     struct { int8_t* p; } d_mat = {cx->d_mat};
     struct { unsigned* p; } d_counter = {cx->d_counter + 16};
 
