@@ -20,7 +20,7 @@ constexpr uint64_t kBandWsBudget = 4ull << 30;  // boundary workspace of the ban
 // the cells per second ONE wave makes on one pair, against the scan's chip rate and the cells per second of one
 // inter-sequence lane (which bounds a scan launch from below: one wave walks a whole (query pair, group) DP).
 constexpr double kPairChipRate = 2.5e12, kPairWaveRate = 2.4e9 / 0.7, kPairCallOverhead = 60e-6;
-constexpr double kScanChipRate = 10e12, kScanLaneRate = 2.4e9 / 37.0;
+constexpr double kScanChipRate = 11e12, kScanLaneRate = 2.4e9 / 37.0;
 
 // boundary workspace of the banded kernels: one slot of `slot` columns per resident wave; the grid shrinks if the longest
 // target of the launch would push it over the budget (caller holds cx->mu)
@@ -254,8 +254,14 @@ uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uin
         const double res_pairs = g0 < G ? (double)t.h_grp_off[g0] * 4.0 : (double)t.residues;
         const double lat_pairs = g0 ? lq_max * len_of(0) / kPairWaveRate + kPairCallOverhead : 0.0;
         const double lat_scan = g0 < G ? lq_max * len_of(g0) / kScanLaneRate : 0.0;
-        const double work = rows * res_pairs / kPairChipRate + rows * res_scan / kScanChipRate;
-        return std::max(std::max(lat_pairs, lat_scan), work);
+        // A scan launch whose longest item (alone: lat_scan) is comparable to its whole chip time does not end at the larger
+        // of the two: the long items share their SIMDs until the bulk is through and finish alone.  Fitted on 8 / 16 / 32
+        // queries x 100k targets (21.5 / 23.8 / 34.9 ms without a split; 9.6 / 17.8 ms with the best one):
+        // time = max(work, lat + 0.32 work) once lat >= work, fading to max(work, lat) as lat falls to half the work.
+        const double work_scan = rows * res_scan / kScanChipRate;
+        const double x = work_scan > 0 ? std::min(1.0, std::max(0.0, (lat_scan - 0.5 * work_scan) / (0.5 * work_scan))) : 0.0;
+        const double t_scan = std::max(work_scan, lat_scan + 0.32 * work_scan * x);
+        return std::max(std::max(lat_pairs, t_scan), work_scan + rows * res_pairs / kPairChipRate);    // both parts share the chip
     };
     double best = cost(0);
     uint32_t best_g0 = 0;
