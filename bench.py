@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- GCUPS of the query x database Smith-Waterman scan (BASELINE.json metric) on N MI355X.
+"""bench.py -- GCUPS of the query x database Smith-Waterman scan (BASELINE.json metric) on N MI355X of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its N ranks itself, before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one full pass of the hot path over the workload held in HBM: every query of the rank's shard
-scored against the whole resident database (s4g_scan), the per-query top-400 selection, and for N > 1 the
-RCCL all-gather of the per-query top-hit lists.  Workload = BASELINE.json configs[1]
-(1k synthetic queries len U[300,400] x 100k-sequence synthetic DB, BLOSUM62, gap 10/1) per GPU:
-queries are sharded across ranks and the DB is replicated (SURVEY.md 8e query-shard mode), so per-GPU work is
-fixed as N grows ("weak").  Rank 0 prints ONE JSON line.
+A step = one full pass of the hot path over the workload held in HBM: every query of the rank's shard scored against the
+resident database (s4g_scan), the per-query top-400 selection on the device, and for N > 1 the RCCL all-gather of the
+per-query top-hit lists.  Workloads (BASELINE.json `configs`, generator of SURVEY.md 8d):
+
+  N = 1   configs[1]: 1000 synthetic queries U[300,400] x 100k-sequence synthetic DB, BLOSUM62 gap 10/1     (the metric's config)
+  N > 1   configs[2]: the same 1000 queries in total x 570k sequences (Swiss-Prot scale), DB replicated in every GPU's HBM,
+          queries split over the ranks: total work is fixed as N grows ("strong"); --workload configs2 runs it on one GPU
+  --mode db-shard   configs[3]: a database shard GENERATED ON EACH DEVICE (--targets per GPU, default 150M/8), every rank scans
+          the same query batch with the streaming scan + running top-k, all-gather + K-way merge; time-boxed: a batch of
+          --queries per step out of the config's 10 000, wall time of the full config extrapolated
+  --workload configs4   long-query stress: 64 queries U[2000,5000] x the configs[1] database
+
+Rank 0 prints ONE JSON line (the last line of stdout).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +34,46 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E column model, 2 int32 loads + 2 stores per cell
 TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
-VALU_PEAK_T = 39.3             # T lane-ops/s: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (integer / packed VALU issue, measured 4 clk per wave64 op)
+LANES_PER_CLK_PER_SIMD = 16    # a wave64 vector instruction occupies its SIMD for 4 clocks (profiles/r01_valu_rates.txt)
+# algorithmic vector ops per DP cell of each scan kernel (counted from the recurrence, not from the ISA)
 VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75, "sw_scan_pk<ArithF16,32>": 3.75,
-                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5}   # algorithmic vector ops per DP cell
+                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5}
+WORKLOADS = {
+    "configs1": dict(cfg=2, queries=1000, targets=100_000, qlen=(300, 400), label="BASELINE configs[1]"),
+    "configs2": dict(cfg=3, queries=1000, targets=570_000, qlen=(300, 400), label="BASELINE configs[2] (Swiss-Prot scale)"),
+    "configs4": dict(cfg=5, queries=64, targets=100_000, qlen=(2000, 5000), label="BASELINE configs[4] (long queries)"),
+}
+CONFIGS3_TARGETS, CONFIGS3_QUERIES = 150_000_000, 10_000
+
+
+def log(msg):
+    print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run), relay rank 0's JSON
+    line.  Nothing in this process has touched the GPU (a process that has initialised HIP must not spawn-and-replace)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"spawning {args.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for l in p.stdout.splitlines():
+        t = l.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        log(f"ranks exited with code {p.returncode}" + ("" if line else " and printed no result line"))
+        sys.exit(p.returncode or 1)
+    print(line, flush=True)
+    sys.exit(0)
 
 
 def cpu_baseline(cfg, n_threads, target_seconds=12.0):
@@ -62,98 +108,190 @@ def cpu_baseline(cfg, n_threads, target_seconds=12.0):
                        f"{impl}, {n_threads} pthreads")
 
 
+def oracle_selfcheck(q_codes, q_off, fetch_target, pairs, gpu_scores, n_threads):
+    """Re-score (query, target) pairs with the CPU oracle (outside the timed region) and compare with what the GPU reported."""
+    import oracle
+    pq = np.asarray([p[0] for p in pairs], dtype=np.uint32)
+    uniq, inv = np.unique(np.asarray([p[1] for p in pairs], dtype=np.int64), return_inverse=True)
+    seqs = [fetch_target(int(t)) for t in uniq]
+    t_off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    t_off[1:] = np.cumsum([len(s) for s in seqs]).astype(np.uint64)
+    t_codes = np.ascontiguousarray(np.concatenate(seqs)) if seqs else np.zeros(1, np.uint8)
+    t0 = time.perf_counter()
+    want = oracle.pairs_flat(np.ascontiguousarray(q_codes), np.ascontiguousarray(q_off), t_codes, t_off, pq, inv.astype(np.uint32),
+                             oracle.blosum62(), 10, 1, n_threads)
+    bad = int((want != np.asarray(gpu_scores, dtype=np.int32)).sum())
+    return bad, time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=1000, help="queries per GPU")
-    ap.add_argument("--targets", type=int, default=100000)
-    ap.add_argument("--qlen", type=int, nargs=2, default=[300, 400], help="query length range (configs[4]: 2000 5000)")
+    ap.add_argument("--workload", choices=["auto"] + sorted(WORKLOADS), default="auto",
+                    help="auto: configs1 at --gpus 1, configs2 (strong scaling) at --gpus > 1")
+    ap.add_argument("--queries", type=int, default=None, help="queries in TOTAL (query-shard) / per step (db-shard); default: the workload's")
+    ap.add_argument("--targets", type=int, default=None, help="database sequences (db-shard: per GPU); default: the workload's")
+    ap.add_argument("--qlen", type=int, nargs=2, default=None, help="query length range; default: the workload's")
     ap.add_argument("--force-i32", action="store_true", help="run every query through the int32 kernel")
     ap.add_argument("--no-f16", action="store_true", help="skip the maximum3-based tiers (plain packed int16 instead)")
     ap.add_argument("--no-drift", action="store_true", help="skip the drifting-frame kernel (maximum3 tier instead)")
     ap.add_argument("--no-spec", action="store_true", help="tiers by score bound only: no speculative use of the drifting-frame kernel for long queries")
-    ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard",
-                    help="query-shard (default): DB replicated, --queries per GPU; db-shard: --targets per GPU, every GPU scans "
-                         "all --queries with the streaming scan + running top-k, then all-gather + K-way merge")
+    ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-tiers", action="store_true", help="skip the two extra int32-only steps after the timed region")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)       # does not return
 
     import torch
     import torch.distributed as dist
-    import sift4g_amd as s4g
-    from sift4g_amd import synth, shard
-    from sift4g_amd.device import scan_cells, scan_plan
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+            log(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        sys.exit(2)
+    # S4G_BENCH_SHARE_GPU=1: ranks may share devices (a 1-GPU test box running the N-rank job): rendezvous and gather go through
+    # gloo, since RCCL refuses two ranks on one device.  Reported in the JSON ("emulated"); never a scaling measurement.
+    share = os.environ.get("S4G_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (n_dev < world and not share):
+        if rank == 0:
+            log(f"{world} ranks but {n_dev} GPU(s) visible (set S4G_BENCH_SHARE_GPU=1 to emulate the N-rank job on fewer devices)")
+        sys.exit(2)
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    import sift4g_amd as s4g
+    from sift4g_amd import synth, shard
+    from sift4g_amd import device as s4gd
+
     use_dist = world > 1 or os.environ.get("S4G_BENCH_FORCE_DIST") == "1"     # the latter exercises the RCCL path on one GPU
+    backend = None
+    rccl_ranks = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = "gloo" if (share and n_dev < world) else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, dtype=torch.int32, device=dev)
+        else:
+            dist.init_process_group("gloo")
+            ones = torch.ones(1, dtype=torch.int32)
+        dist.all_reduce(ones)                       # how many ranks really joined the collective
+        rccl_ranks = int(ones.item())
 
-    # ---- workload: identical generator on every rank ----
     db_shard = args.mode == "db-shard"
+    flags = dict(force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t_gen = time.perf_counter()
-    if db_shard:      # DB grows with N (each GPU holds --targets of it), every GPU scans all --queries
-        cfg = synth.make_config(2, n_queries=args.queries, n_targets=args.targets * world, q_len=tuple(args.qlen))
-        lengths = np.diff(cfg["t_off"].astype(np.int64))
-        mine = shard.balanced_db_shards(lengths, world)[rank].numpy()
-        my_off = np.zeros(len(mine) + 1, dtype=np.uint64)
-        my_off[1:] = np.cumsum(lengths[mine]).astype(np.uint64)
-        my_codes = np.concatenate([cfg["t_codes"][int(cfg["t_off"][i]):int(cfg["t_off"][i + 1])] for i in mine])
-        t_codes, t_off = my_codes, my_off
-    else:             # DB replicated, queries sharded: --queries per GPU
-        cfg = synth.make_config(2, n_queries=args.queries * world, n_targets=args.targets, q_len=tuple(args.qlen),
-                                homologs_per_query=max(1, 50 // world))     # same number of planted homologs in the DB at every N
-        t_codes, t_off = cfg["t_codes"], cfg["t_off"]
-    t_up = time.perf_counter()
-    db = s4g.Database(codes=t_codes, offsets=t_off, device=local_rank)
-    allq = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"], device=local_rank)
+    cfg = None
+
+    if db_shard:
+        # ---- configs[3]: this rank's shard of a UniRef90-scale database, generated where it will be scanned ----
+        n_per = args.targets if args.targets is not None else CONFIGS3_TARGETS // 8
+        nq = args.queries if args.queries is not None else 32
+        qlen = tuple(args.qlen) if args.qlen else (300, 400)
+        wl_label = "BASELINE configs[3] (UniRef90 scale, DB sharded)"
+        qseed = synth.SEED_BASE + 4
+        ql = synth.query_lengths(qseed + 0x100, nq, *qlen)
+        q_codes, q_off = synth.random_set(qseed + 0x200, ql)
+        codes_d, offsets_d = synth.device_database(n_per, synth.SEED_BASE + 4 + 0x1000 * (rank + 1), dev)
+        # one full-length copy of every query planted in exactly one rank's shard (query i -> rank i % world), at the head of a
+        # target that is long enough; the owners tell everybody where (rank 0 checks the merged lists)
+        lens_h = (offsets_d[1:] - offsets_d[:-1]).cpu().numpy()
+        where = torch.zeros(nq, dtype=torch.int64)
+        taken = set()
+        for i in range(nq):
+            if i % world != rank:
+                continue
+            p = (i + 1) * (n_per // (nq + 1))
+            while lens_h[p] < ql[i] or p in taken:
+                p += 1
+            taken.add(p)
+            where[i] = p
+            o = int(offsets_d[p])
+            codes_d[o:o + int(ql[i])] = torch.from_numpy(q_codes[int(q_off[i]):int(q_off[i + 1])].copy()).to(dev)
+        if use_dist:
+            if backend == "nccl":
+                where = where.to(dev)
+            dist.all_reduce(where)
+        planted = {i: int(where[i]) for i in range(nq)}
+        torch.cuda.synchronize()
+        t_up = time.perf_counter()
+        db = s4g.Database.from_device(codes_d, offsets_d)
+        allq = s4g.QuerySet(codes=q_codes, offsets=q_off, device=dev_index)
+        q_begin, q_count = 0, nq
+        residues_rank = int(offsets_d[-1])
+        n_targets_total = n_per * world
+        if world == 1 and not args.no_cpu_baseline:     # the CPU baseline's bounded sample: the shard's first sequences, on the host
+            m = min(n_per, 1 << 18)
+            cfg = dict(q_codes=q_codes, q_off=q_off, t_codes=codes_d[:int(offsets_d[m])].cpu().numpy(),
+                       t_off=offsets_d[:m + 1].cpu().numpy().astype(np.uint64))
+    else:
+        # ---- configs[1] / [2] / [4]: DB replicated, the queries split over the ranks ----
+        wl_name = args.workload if args.workload != "auto" else ("configs1" if world == 1 else "configs2")
+        wl = WORKLOADS[wl_name]
+        wl_label = wl["label"]
+        nq = args.queries if args.queries is not None else wl["queries"]
+        nt = args.targets if args.targets is not None else wl["targets"]
+        qlen = tuple(args.qlen) if args.qlen else wl["qlen"]
+        cfg = synth.make_config(wl["cfg"], n_queries=nq, n_targets=nt, q_len=qlen)
+        q_codes, q_off = cfg["q_codes"], cfg["q_off"]
+        t_up = time.perf_counter()
+        db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"], device=dev_index)
+        allq = s4g.QuerySet(codes=q_codes, offsets=q_off, device=dev_index)
+        bounds = shard.shard_bounds(nq, world)
+        q_begin, q_count = bounds[rank], bounds[rank + 1] - bounds[rank]
+        residues_rank = int(cfg["t_off"][-1])
+        n_targets_total = nt
     torch.cuda.synchronize()
     t_ready = time.perf_counter()
     if rank == 0:
-        print(f"bench.py: generate {t_up - t_gen:.1f} s; pack+upload DB ({int(t_off[-1])} residues) and queries "
-              f"{t_ready - t_up:.2f} s (host packing + PCIe, outside the timed region)", file=sys.stderr)
-    q_begin, q_count = (0, args.queries) if db_shard else (rank * args.queries, args.queries)
-    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
-    cells_rank = scan_cells(db, allq, q_begin, q_count)
-    plan = scan_plan(db, allq, scorer)
+        log(f"generate {t_up - t_gen:.1f} s; pack DB ({residues_rank} residues) + queries into HBM {t_ready - t_up:.2f} s "
+            f"(outside the timed region)")
+
+    cells_rank = s4gd.scan_cells(db, allq, q_begin, q_count) if q_count else 0
+    plan = s4gd.scan_plan(db, allq, scorer)
     if args.force_i32:
         plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
     elif args.no_f16 and ("M3" in plan["kernel"] or "pkd" in plan["kernel"]):
         plan["kernel"] = "sw_scan_pk<ArithI16,32>"
     elif args.no_drift and "pkd" in plan["kernel"]:
         plan["kernel"] = "sw_scan_pk<ArithI16M3,32>"
-    scores = None if db_shard else torch.empty((q_count, db.n), dtype=torch.int32, device=dev)
-    gids = torch.from_numpy(mine.astype(np.int64)).to(dev) if db_shard else None
+    scores = None if db_shard else torch.empty((max(q_count, 1), db.n), dtype=torch.int32, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gather_group = None
 
-    def step(i=None):
+    def step(i=None, fl=flags):
         if i is not None:
             ev[i][0].record()
         if db_shard:
-            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)    # scan + tile top-k + merge
+            ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, **fl)             # streaming scan + tile top-k + merge
             if i is not None:
                 ev[i][1].record()
-            return shard.gather_db_shards(ids, sc, cnt, gids, TOPK)                          # RCCL all-gather + K-way merge
-        s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)
+            return (ids, sc, cnt), shard.gather_db_shards(ids, sc, cnt, rank * n_per, TOPK, gather_group)   # all-gather + K-way merge
+        if q_count:
+            s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, **fl)
         if i is not None:
             ev[i][1].record()
-        ids, sc, cnt = s4g.topk_device(db, scores, TOPK, 1)                     # steps 2-3 on the device
-        return shard.gather_query_shards(ids, sc, cnt, allq.n)                  # RCCL all-gather of the hit lists (N > 1)
+        if q_count:
+            ids, sc, cnt = s4g.topk_device(db, scores[:q_count], TOPK, 1)             # steps 2-3 on the device
+        else:
+            ids = torch.full((0, TOPK), -1, dtype=torch.int32, device=dev)
+            sc = torch.zeros((0, TOPK), dtype=torch.int32, device=dev)
+            cnt = torch.zeros((0,), dtype=torch.int32, device=dev)
+        return (ids, sc, cnt), shard.gather_query_shards(ids, sc, cnt, allq.n, gather_group)        # all-gather of the hit lists (N > 1)
 
     def fence():
         if use_dist:
@@ -164,60 +302,149 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
+    last = None
     for i in range(args.steps):
-        step(i)
+        last = step(i)
     fence()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    stats = s4gd.scan_stats(dev_index)
 
-    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
-    c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=dev)
+    red_dev = dev if backend != "gloo" else torch.device("cpu")
+    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=red_dev)
+    c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=red_dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    dt, kern_ms = float(t[0]), float(t[1])
+    dt, kern_ms_max = float(t[0]), float(t[1])
     cells_total = float(c[0])
 
+    line = None
     if rank == 0:
         gcups = cells_total * args.steps / dt / 1e9
         kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        achieved = kern_gcups * BYTES_PER_CELL            # GB/s of ALGORITHMIC bytes moved by the scan kernel
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes, if collected
+        ops = VALU_OPS_PER_CELL.get(plan["kernel"], 0.0)
+        # ---- the roof that binds: vector-ALU issue, priced at the clock the chip runs at under load ----
+        probe = s4gd.clock_probe(dev_index)
+        clock_mhz = probe["shader_mhz"] or probe["nominal_mhz"]
+        valu_peak = probe["cus"] * 4 * LANES_PER_CLK_PER_SIMD * clock_mhz * 1e6 / 1e12          # T lane-ops/s
+        valu_achieved = kern_gcups * ops / 1e3
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes of this command
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
                 if pj.get("kernel") == plan["kernel"] and pj.get("workload_cells") == cells_rank:
-                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic, traffic_src = pj.get("hbm_bytes_per_launch"), pj.get("source")
             except Exception:
                 traffic = None
+        hbm_achieved = kern_gcups * BYTES_PER_CELL
+        tier = "int32" if plan["kernel"].startswith("sw_scan_i32") else ("f16" if "F16" in plan["kernel"] else "int16")
         out = {
             "metric": "GCUPS (SW cell updates/s) on query x DB scan",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16" if ("I16" in plan["kernel"] or "pkd" in plan["kernel"]) else ("f16" if "F16" in plan["kernel"] else "int32"), "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] generator: {args.queries} synthetic queries/GPU len U[{args.qlen[0]},{args.qlen[1]}] x "
-                                   f"{args.targets} synthetic targets lognormal(5.68,0.55) clip[30,3000] + planted homologs, "
-                                   f"BLOSUM62 gap 10/1, full scan + top-{TOPK}",
-                       "cells_per_step": cells_total, "parallelism": (f"db-shard x{world}: {args.targets} targets/GPU, all queries on every GPU, all-gather + merge"
-                                       if db_shard else f"query-shard x{world}, DB replicated"),
-                       "kernel": plan["kernel"], "grid_blocks": plan["grid_blocks"], "strip_rows": plan["strip_rows"]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
-                         "algorithmic_bytes_per_cell": BYTES_PER_CELL,
-                         "note": "register-tiled kernel moves ~8/R B per cell, so frac exceeds 1 by construction; the binding limit is VALU issue",
-                         # the limit that actually binds: vector-ALU issue.  algorithmic ops per cell of the dispatched kernel x cells/s
-                         # against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (tools/valu_rates.hip, profiles/r01_valu_rates.txt)
-                         "valu": {"ops_per_cell": VALU_OPS_PER_CELL.get(plan["kernel"]), "peak_T_lane_ops_per_s": VALU_PEAK_T,
-                                  "achieved_T_lane_ops_per_s": round(kern_gcups * VALU_OPS_PER_CELL.get(plan["kernel"], 0) / 1e3, 2),
-                                  "frac": round(kern_gcups * VALU_OPS_PER_CELL.get(plan["kernel"], 0) / 1e3 / VALU_PEAK_T, 4)}},
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if db_shard else "strong",
+            "vs_baseline": None, "dtype": tier, "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "backend": ("RCCL (nccl)" if backend == "nccl" else backend), "emulated": bool(share and n_dev < world),
+            "config": {
+                "workload": (f"{wl_label}: {nq} synthetic queries per step len U[{qlen[0]},{qlen[1]}] x {n_per} device-generated targets per GPU "
+                             f"({n_targets_total} in total) lognormal(5.68,0.55) clip[30,3000], BLOSUM62 gap 10/1, streaming scan + running top-{TOPK}"
+                             if db_shard else
+                             f"{wl_label}: {nq} synthetic queries len U[{qlen[0]},{qlen[1]}] x {n_targets_total} synthetic targets "
+                             f"lognormal(5.68,0.55) clip[30,3000] + planted homologs, BLOSUM62 gap 10/1, full scan + top-{TOPK}"),
+                "cells_per_step": cells_total,
+                "parallelism": (f"db-shard x{world}: every GPU scans all queries against its own {n_per} targets, all-gather + K-way merge" if db_shard
+                                else f"query-shard x{world}: DB replicated, {nq} queries split over the ranks, all-gather of the hit lists"),
+                "kernel": plan["kernel"], "grid_blocks": plan["grid_blocks"], "strip_rows": plan["strip_rows"]},
+            "roofline": {
+                "bound": "valu", "achieved": round(valu_achieved, 3), "peak": round(valu_peak, 3), "unit": "T lane-ops/s",
+                "frac": round(valu_achieved / valu_peak, 4) if valu_peak else None, "traffic": traffic,
+                "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
+                "ops_per_cell": ops,
+                "peak_basis": (f"{probe['cus']} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {clock_mhz:.0f} MHz "
+                               + ("(shader clock measured under a vector-ALU load by s4g_clock_probe in this run)" if probe["shader_mhz"]
+                                  else "(nominal clock: the part's cycle counter does not follow the shader clock)")),
+                "measured_pk_add_rate": round(probe["pk_add_T_lane_ops"], 2),
+                "traffic_source": traffic_src,
+                "note": "a register-tiled kernel moves ~8/R bytes per cell, so it sits far above the HBM contract roofline by construction; "
+                        "vector-ALU issue is the limit that binds (achieved = algorithmic ops per cell x measured cells/s)",
+                # the contract figure of SURVEY.md 8d / BASELINE.md: 16 algorithmic bytes per cell against 8 TB/s
+                "hbm": {"bound": "hbm", "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                        "traffic": traffic,
+                        "traffic_frac_of_peak": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kern_ms else None)}},
+            "speculative": {"queries": stats["speculative"], "rechecked": stats["rechecked"]},
+            "routing": {k: stats[k] for k in ("tier_drift", "tier_m3", "tier_i16", "tier_i32", "pair_items")},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if db_shard:
+            full_cells = float(CONFIGS3_QUERIES) * (cells_total / nq)
+            full_cells *= CONFIGS3_TARGETS / float(n_targets_total)
+            out["config"]["extrapolated"] = {"full_config": f"{CONFIGS3_QUERIES} queries x {CONFIGS3_TARGETS} targets on 8 GPUs",
+                                             "cells": full_cells, "wall_s_at_this_rate_per_gpu_x8": round(full_cells / (gcups / world * 8 * 1e9), 1)}
+
+        # ---- outside the timed region: tie the number to correctness and to the int32 kernel ----
+        (l_ids, l_sc, l_cnt), (g_ids, g_sc, g_cnt) = last
+        if not args.no_selfcheck and args.steps and q_count:
+            rng = np.random.default_rng(12345)
+            ids_h, sc_h, cnt_h = l_ids.cpu().numpy(), l_sc.cpu().numpy(), l_cnt.cpu().numpy()
+            pairs, got = [], []
+            for qi in np.linspace(0, q_count - 1, num=min(8, q_count)).astype(int):     # every entry of 8 queries' top lists
+                for j in range(int(cnt_h[qi])):
+                    pairs.append((q_begin + int(qi), int(ids_h[qi, j]))); got.append(int(sc_h[qi, j]))
+            n_list = len(pairs)
+            if not db_shard:                                                            # + random entries of the score matrix
+                rq = rng.integers(0, q_count, 2000)
+                rt = rng.integers(0, db.n, 2000)
+                vals = scores[torch.from_numpy(rq).to(dev), torch.from_numpy(rt).to(dev)].cpu().numpy()
+                pairs += [(q_begin + int(a), int(b)) for a, b in zip(rq, rt)]
+                got += [int(v) for v in vals]
+                fetch = lambda tid: cfg["t_codes"][int(cfg["t_off"][tid]):int(cfg["t_off"][tid + 1])]
+            else:
+                rq = rng.integers(0, q_count, 2000)
+                rt = rng.integers(0, db.n, 2000)
+                vals = s4g.score_pairs(db, allq, scorer, rq.astype(np.uint32), rt.astype(np.uint32), route="wave")
+                pairs += [(int(a), int(b)) for a, b in zip(rq, rt)]
+                got += [int(v) for v in vals]
+                off_h = offsets_d.cpu().numpy()
+                fetch = lambda tid: codes_d[int(off_h[tid]):int(off_h[tid + 1])].cpu().numpy()
+            bad, secs = oracle_selfcheck(q_codes, q_off, fetch, pairs, got, n_cpu)
+            chk = {"pairs": len(pairs), "mismatches": bad, "top_list_entries": n_list, "random_pairs": len(pairs) - n_list,
+                   "against": "oracle/sw_oracle.c (scalar CPU restatement)", "seconds": round(secs, 2)}
+            if db_shard:            # every planted copy must lead the MERGED list of its query with the query's self-score
+                M = s4gd.matrix_by_name("BLOSUM_62")
+                gi, gs = g_ids.cpu().numpy(), g_sc.cpu().numpy()
+                miss = 0
+                for i in range(nq):
+                    qc = q_codes[int(q_off[i]):int(q_off[i + 1])]
+                    if gi[i, 0] != (i % world) * n_per + planted[i] or gs[i, 0] != int(M[qc, qc].sum()):
+                        miss += 1
+                chk["planted_copies"] = nq
+                chk["planted_not_first"] = miss
+                chk["mismatches"] += miss
+            out["selfcheck"] = chk
+            if chk["mismatches"]:
+                log(f"SELFCHECK FAILED: {chk}")
+        if world == 1 and not db_shard and not args.no_tiers and not args.force_i32 and args.steps:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            step(None, dict(force_i32=True))
+            ms32 = []
+            for _ in range(2):
+                e0.record()
+                s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, force_i32=True)
+                e1.record()
+                torch.cuda.synchronize()
+                ms32.append(e0.elapsed_time(e1))
+            k32 = float(np.mean(ms32))
+            g32 = cells_rank / (k32 * 1e-3) / 1e9
+            out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32<32>", "steps": 2,
+                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
+                            tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
+        if world == 1 and not args.no_cpu_baseline and cfg is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
         line = json.dumps(out)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit, AFTER the JSON:
@@ -228,6 +455,8 @@ def main():
         except OSError:
             pass
         print(line, flush=True)
+        if json.loads(line).get("selfcheck", {}).get("mismatches"):
+            sys.exit(3)
 
 
 if __name__ == "__main__":

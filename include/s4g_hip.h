@@ -36,6 +36,8 @@
  *       createFilteredDatabase, database_alignment.cpp:136-162)
  *   s4g_traceback_host
  *       step 4 of swsharp alignDatabase: traceback of the survivors
+ *   s4g_scan_stats / s4g_clock_probe / s4g_scan_plan / s4g_scan_cells
+ *       measurement only (bench.py); no counterpart in the reference, which prints no throughput figures
  *   s4g_topk / s4g_topk_host / s4g_scan_topk / s4g_scan_topk_host
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
@@ -221,6 +223,19 @@ int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, const s4g_s
 int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer,
                   char* kernel_name, size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
                   uint32_t* strip_rows, uint64_t* workspace_bytes);
+
+/* What the last s4g_scan* / s4g_scan_topk* call on `device` did (measurement; synchronises the device):
+ * out[0..3] = queries routed to the drifting-frame / maximum3 / plain int16 / int32 kernels (summed over database tiles and
+ * query batches), out[4] = of those, (query, tile) combinations that ran speculatively, out[5] = score entries the
+ * speculative launches marked and the exact int32 pass recomputed, out[6] = (query, target) pairs given to the
+ * one-wave-per-pair kernels, out[7] = 0.  cap >= 8. */
+int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
+
+/* Shader clock under a full vector-ALU load and the measured issue rate of packed-int16 vector instructions: what bench.py
+ * prices the scan kernels' VALU-issue roofline with.  out[0] = shader clock in MHz (0 if the part's cycle counter does not
+ * follow the shader clock), out[1] = measured T lane-ops/s of v_pk_add_u16 at 8 waves per SIMD, out[2] = compute units,
+ * out[3] = the runtime's nominal clock in MHz, out[4] = duration of the probe kernel in ms.  cap >= 5.  ~50 ms. */
+int s4g_clock_probe(int device, double* out, uint32_t cap);
 
 #ifdef __cplusplus
 }

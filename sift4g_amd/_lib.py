@@ -74,6 +74,8 @@ SIGNATURES = {
                                           c_i32p, c_i32p, c_u64p, c_u8p]),
     "s4g_traceback_host_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,
                                           c_i32p, c_i32p, c_u64p, c_u8p, ctypes.c_uint32]),
+    "s4g_scan_stats": (ctypes.c_int, [ctypes.c_int, c_u64p, ctypes.c_uint32]),
+    "s4g_clock_probe": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_u64p]),
 }
@@ -93,6 +95,10 @@ if not os.path.exists(LIB_PATH):
         "sift4g_amd has no CPU fallback.")
 
 lib = ctypes.CDLL(LIB_PATH)
+if hasattr(lib, "s4g_is_shim"):
+    # tests/cpu_shim/lib/libs4g_hip.so answers the device ABI from the CPU oracle and carries the product library's file name;
+    # it marks itself with this symbol so that no S4G_LIB / LD_LIBRARY_PATH setting can put it under the product path
+    raise ImportError(f"{LIB_PATH} is the test-only CPU stand-in (tests/cpu_shim), not the HIP library: refusing to load it")
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)   # AttributeError here = the .so is stale or broken: fail loudly
     _fn.restype = _res

@@ -1,0 +1,87 @@
+// s4g_diag.hip -- C ABI: measurement helpers for bench.py (nothing on the scoring path).
+//   s4g_clock_probe: the shader clock the chip actually runs at under a full vector-ALU load, and the rate at which it then
+//   issues packed-int16 vector instructions -- the two numbers the VALU-issue roofline of the scan kernels is priced against
+//   (256 CU x 4 SIMD x 16 lanes per clock; a wave64 instruction occupies its SIMD for 4 clocks).
+#include "s4g_internal.hpp"
+
+constexpr int kProbeChains = 8;        // independent dependency chains per lane
+constexpr int kProbeInner = 64;        // packed adds per chain and outer iteration
+
+// Every wave of a full-occupancy grid runs dependent chains of v_pk_add_u16; lane 0 of every block samples the shader-clock
+// counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around the loop.
+__global__ __launch_bounds__(256) void clock_probe(unsigned long long* __restrict__ out, unsigned* __restrict__ sink, unsigned outer, unsigned seed) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    unsigned v[kProbeChains];
+#pragma unroll
+    for (int c = 0; c < kProbeChains; ++c) v[c] = seed + threadIdx.x * 7u + c;
+    const us2 inc = __builtin_bit_cast(us2, seed | 0x00010001u);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned o = 0; o < outer; ++o) {
+#pragma unroll
+        for (int i = 0; i < kProbeInner; ++i) {
+#pragma unroll
+            for (int c = 0; c < kProbeChains; ++c) {
+                us2 x = __builtin_bit_cast(us2, v[c]);
+                x = x + inc;
+                v[c] = __builtin_bit_cast(unsigned, x);
+                asm volatile("" : "+v"(v[c]));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned s = 0;
+#pragma unroll
+    for (int c = 0; c < kProbeChains; ++c) s ^= v[c];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// out[0] = shader clock in MHz under load as seen by s_memtime / s_memrealtime (0 if s_memtime does not count shader clocks on
+//          this part, i.e. the two counters advance at the same rate)
+// out[1] = measured issue rate of packed-int16 adds, T lane-ops/s (64 lanes per wave instruction), grid at 8 waves per SIMD
+// out[2] = compute units, out[3] = the runtime's nominal (maximum) clock in MHz, out[4] = wall time of the probe in ms
+S4G_API int s4g_clock_probe(int device, double* out, uint32_t cap) {
+    if (!out || cap < 5) return fail(S4G_ERR_INVALID, "need room for 5 values");
+    if (device < 0 || device >= 64 || device >= device_count_raw()) return fail(S4G_ERR_NO_DEVICE, "no HIP device %d", device);
+    DeviceGuard guard(device);
+    DeviceCtx* cx = device_ctx(device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    int rc = device_props(cx);
+    if (rc) return rc;
+    const int cus = cx->prop.multiProcessorCount;
+    const unsigned blocks = (unsigned)cus * 8;          // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    DevBuf<unsigned long long> d_t;
+    DevBuf<unsigned> d_sink;
+    HIP_TRY(d_t.alloc((size_t)blocks * 2));
+    HIP_TRY(d_sink.alloc((size_t)blocks * 256));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const unsigned outer = 2048;                        // 2048 x 64 x 8 = 1.05 M wave instructions per wave: ~15 ms
+    hipLaunchKernelGGL(clock_probe, dim3(blocks), dim3(256), 0, nullptr, d_t.p, d_sink.p, outer / 8, 3u);     // warm-up: clocks ramp
+    hipLaunchKernelGGL(clock_probe, dim3(blocks), dim3(256), 0, nullptr, d_t.p, d_sink.p, outer, 3u);
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(clock_probe, dim3(blocks), dim3(256), 0, nullptr, d_t.p, d_sink.p, outer, 5u);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::vector<unsigned long long> h((size_t)blocks * 2);
+    HIP_TRY(hipMemcpy(h.data(), d_t.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double sum_ratio = 0;
+    unsigned used = 0;
+    for (unsigned b = 0; b < blocks; ++b)
+        if (h[2 * b + 1] > 1000) { sum_ratio += (double)h[2 * b] / (double)h[2 * b + 1]; ++used; }
+    const double ratio = used ? sum_ratio / used : 0.0;
+    out[0] = ratio > 1.5 ? ratio * 100.0 : 0.0;         // s_memrealtime is 100 MHz
+    const double lane_ops = (double)blocks * 256.0 * outer * kProbeInner * kProbeChains;
+    out[1] = lane_ops / ((double)ms * 1e-3) / 1e12;
+    out[2] = cus;
+    out[3] = cx->prop.clockRate / 1000.0;
+    out[4] = ms;
+    return S4G_OK;
+}

@@ -127,7 +127,13 @@ struct DeviceCtx {
     std::vector<std::pair<char*, uint64_t>> block_cache;    // freed small-tile blocks, reused by the next s4g_db_create
     char* arena = nullptr;              // traceback temporaries
     uint64_t arena_bytes = 0;
+    // what the last s4g_scan / s4g_scan_topk call on this device did (s4g_scan_stats): queries per tier summed over tiles and
+    // batches, queries that ran speculatively, pairs handed to the one-wave-per-pair kernels; the number of marked entries the
+    // recheck pass recomputed is counted on the device (d_counter + kStatRechecked)
+    uint64_t stat_tier[4] = {0, 0, 0, 0};
+    uint64_t stat_spec_queries = 0, stat_pair_items = 0;
 };
+constexpr int kStatRechecked = 40;      // index into DeviceCtx::d_counter
 
 DeviceCtx* device_ctx(int device);
 
@@ -164,6 +170,28 @@ struct DevBuf {          // scoped device allocation for the non-hot paths
 int device_props(DeviceCtx* cx);
 int scratch_acquire(const s4g_db* db, hipStream_t stream);
 int scratch_release(const s4g_db* db, hipStream_t stream);
+// Every exit of a call that holds the scratch buffers -- the error exits too -- must leave `last_use` recorded behind all of
+// its launches, side stream included: s4g_db_destroy and the block cache order themselves on that event, and a failure
+// halfway (a hipMalloc that runs out of memory in ensure_scratch, say) would otherwise leave side-stream kernels in flight
+// behind a stale event.  release() is the normal exit; the destructor covers the others.
+struct ScratchScope {
+    const s4g_db* db;
+    hipStream_t stream;
+    bool armed = false, forked = false;
+    ScratchScope(const s4g_db* d, hipStream_t s) : db(d), stream(s) {}
+    int acquire() { const int rc = scratch_acquire(db, stream); armed = rc == S4G_OK; return rc; }
+    int release() { armed = false; return scratch_release(db, stream); }
+    ~ScratchScope() {
+        if (!armed) return;
+        DeviceCtx* cx = device_ctx(db->device);
+        if (forked && cx->side_stream && cx->side_join) {
+            (void)hipEventRecord(cx->side_join, cx->side_stream);
+            (void)hipStreamWaitEvent(stream, cx->side_join, 0);
+        }
+        if (cx->last_use) (void)hipEventRecord(cx->last_use, stream);
+    }
+};
+
 // s4g_pairs.hip
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);

@@ -98,7 +98,8 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     if (rc) return rc;
     if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
     if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
-    rc = scratch_acquire(db, stream);
+    ScratchScope scope(db, stream);
+    rc = scope.acquire();
     if (rc) return rc;
     { const int rcm = ensure_mat(cx, scorer, stream); if (rcm) return rcm; }
     HIP_TRY(hipMemcpyAsync(cx->d_items, cx->h_items, (size_t)n * sizeof(PairItem), hipMemcpyHostToDevice, stream));
@@ -138,14 +139,12 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
         }
         if (rc) return rc;
     }
-    return scratch_release(db, stream);
+    return scope.release();
 }
 
 int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count,
                    int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream) {
     if (q_count == 0 || n_cols == 0) return S4G_OK;
-    static const bool skip = getenv("S4G_TEST_SKIP_RECHECK") != nullptr;     // test hook: leaves the marks visible (tests/test_gpu_parity.py)
-    if (skip) return S4G_OK;
     DeviceCtx* cx = device_ctx(db->device);
     int rc = device_props(cx);
     if (rc) return rc;
@@ -165,7 +164,7 @@ int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sco
     PairArgs& a = r.b.p;
     a.items = nullptr; a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
-    a.scores = d_scores; a.counter = nullptr; a.n_pairs = 0;
+    a.scores = d_scores; a.counter = cx->d_counter + kStatRechecked; a.n_pairs = 0;     // counts the entries it recomputes (s4g_scan_stats)
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     r.b.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); r.b.band_ws_slot = slot;
     r.stride = stride; r.q_begin = q_begin; r.q_count = q_count; r.n_cols = n_cols; r.col_ids = d_col_ids;

@@ -36,6 +36,7 @@ struct Plan {
     uint64_t ws_bytes = 0;          // workspace needed for the largest tile launch
     uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
     bool speculative = false;       // some query runs in the drift tier on its frame alone: marked results need sw_pair_recheck
+    uint64_t n_spec = 0;            // (query, tile) combinations routed speculatively (reporting)
     uint32_t spec_base = 0;         // 0x7BFF - bias - (max score + 2 ext)
 };
 constexpr uint64_t kSpecSpan = 6144;    // scores a speculative query can reach without a recheck, at least
@@ -133,11 +134,13 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             else if (!no_drift && !no_spec && gaps16 && p->bias + step + (rows + cols) * (uint64_t)sc->ext + kSpecSpan <= cap) {
                 tier = 0;               // the frame fits with room to spare: run there, recheck what comes near the end
                 p->speculative = true;
+                p->n_spec++;
             }
             else if (!no_m3 && m3_gaps && b <= m3_window) tier = 1;
             else if (!no_m3 && !no_spec && !p->f16_arith && m3_gaps && p->bias + step + kSpecSpan <= cap) {
                 tier = 1;               // the frame does not fit the drift window: same scheme in the fixed-frame maximum3 tier
                 p->speculative = true;
+                p->n_spec++;
             }
             else if (!(flags & S4G_SCAN_FORCE_I32) && gaps16 && b <= 32767) tier = 2;
             else tier = 3;
@@ -313,6 +316,35 @@ int scratch_release(const s4g_db* db, hipStream_t stream) {
     return S4G_OK;
 }
 
+// s4g_scan_stats: what the call did (host part; the recheck pass counts on the device)
+static int stats_begin(DeviceCtx* cx, hipStream_t stream) {
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    HIP_TRY(hipMemsetAsync(cx->d_counter + kStatRechecked, 0, 4, stream));
+    for (auto& v : cx->stat_tier) v = 0;
+    cx->stat_spec_queries = cx->stat_pair_items = 0;
+    return S4G_OK;
+}
+static void stats_add(DeviceCtx* cx, const Plan& p) {
+    for (int k = 0; k < 4; ++k) cx->stat_tier[k] += p.n_by_tier[k];
+    cx->stat_spec_queries += p.n_spec;
+}
+
+S4G_API int s4g_scan_stats(int device, uint64_t* out, uint32_t cap) {
+    if (!out || cap < 8) return fail(S4G_ERR_INVALID, "need room for 8 counters");
+    if (device < 0 || device >= 64) return fail(S4G_ERR_INVALID, "bad device %d", device);
+    DeviceGuard guard(device);
+    DeviceCtx* cx = device_ctx(device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    unsigned rechecked = 0;
+    if (cx->d_counter) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&rechecked, cx->d_counter + kStatRechecked, 4, hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < 4; ++k) out[k] = cx->stat_tier[k];
+    out[4] = cx->stat_spec_queries; out[5] = rechecked; out[6] = cx->stat_pair_items; out[7] = 0;
+    return S4G_OK;
+}
+
 int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
@@ -378,7 +410,15 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         all_pairs = all_pairs && (t.n_seqs == 0 || g0s[ti] >= t.n_groups);
         any_pairs = any_pairs || g0s[ti] != 0;
     }
+    ScratchScope scope(db, stream);
     if (all_pairs && any_pairs) {       // nothing for the scan kernels: one submission, no plan, no strip workspace
+        rc = scope.acquire();
+        if (rc) return rc;
+        rc = stats_begin(cx, stream);
+        if (rc) return rc;
+        cx->stat_pair_items = (uint64_t)q_count * db->n_seqs;
+        rc = scope.release();
+        if (rc) return rc;
         bool done = false;
         return scan_as_pairs(db, q, q_begin, q_count, scorer, d_scores, stream, &done);
     }
@@ -386,8 +426,11 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     Plan p;
     rc = make_plan(db, q, q_begin, q_count, scorer, flags, &p);
     if (rc) return rc;
-    rc = scratch_acquire(db, stream);
+    rc = scope.acquire();
     if (rc) return rc;
+    rc = stats_begin(cx, stream);
+    if (rc) return rc;
+    stats_add(cx, p);
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
     // The side stream carries (a) the pair parts and (b) the scan launches of long-sequence tiles (own workspace): their
@@ -420,9 +463,11 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         }
         HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after the uploads of this call
         HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+        scope.forked = true;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
             if (g0s[ti]) {
+                cx->stat_pair_items += (uint64_t)q_count * std::min<uint64_t>(t.n_seqs, (uint64_t)g0s[ti] * 64);
                 rc = tile_as_pairs(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, false, cx->side_stream,
                                    (uint32_t)std::min<uint64_t>(t.n_seqs, (uint64_t)g0s[ti] * 64));
                 if (rc) return rc;
@@ -447,7 +492,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         rc = recheck_marked(db, q, scorer, q_begin, q_count, d_scores, db->n_seqs, db->n_seqs, nullptr, max_lt, stream);
         if (rc) return rc;
     }
-    return scratch_release(db, stream);
+    return scope.release();
 }
 
 S4G_API int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,
@@ -481,8 +526,9 @@ S4G_API int s4g_scan_host_flags(const s4g_db* db, const s4g_queries* q, uint32_t
 
 // ---------------------------------------------------------------------------
 // top-k (steps 2-3 of alignDatabase on the device): one 256-thread block per query row.
-//   1. two-level radix select on the int32 score (high 12 bits of a 24-bit score, then low 12 bits) finds the cut
-//      score exactly: the k-th largest score >= min_score;
+//   1. radix select on the int32 score (high 12 bits of a 24-bit score, then low 12 bits; rows holding scores beyond
+//      2^24 - 1 shift the digits up and resolve the remaining low bits in a third level) finds the cut score exactly:
+//      the k-th largest score >= min_score;
 //   2. everything above the cut is kept; among the ties AT the cut the smallest target ids are kept (ordered
 //      block scan), so the result is the exact, deterministic top-k under (score desc, id asc);
 //   3. bitonic sort of the <= k survivors in LDS on the 64-bit key (~score << 32 | id).
@@ -519,7 +565,7 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
                                                         const int32_t* __restrict__ row_min_scores) {
     __shared__ unsigned hist[kBins];
     __shared__ unsigned long long keys[kTopkMax];
-    __shared__ int s_hi, s_cut;
+    __shared__ int s_hi, s_cut, s_max;
     __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
     const int tid = threadIdx.x;
     const uint32_t c0 = blockIdx.y * seg_len;
@@ -529,12 +575,24 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
     if (row_min_scores) min_score = row_min_scores[blockIdx.x];       // per-query cut (e-value driven)
     if (min_score < 0) min_score = 0;
 
+    // ---- range of the row: scores beyond 2^24 - 1 (a query of a million residues) shift the radix digits up, and a third
+    //      level then resolves the bits shifted out, so the cut is exact over the whole non-negative int32 range ----
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    {
+        int m = 0;
+        for (uint32_t i = tid; i < n; i += kTopkBlock) m = max(m, row[i]);
+        if (m > kScoreCap) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    const int shift = s_max > kScoreCap ? (32 - __clz(s_max)) - 24 : 0;       // 0 .. 7
+
     // ---- level 1: high 12 bits ----
     for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += kTopkBlock) {
         const int v = row[i];
-        if (v >= min_score) atomicAdd(&hist[clampi(v, 0, kScoreCap) >> 12], 1u);
+        if (v >= min_score) atomicAdd(&hist[(v >> shift) >> 12], 1u);
     }
     __syncthreads();
     if (tid == 0) { int b; unsigned a; find_bin(hist, k, &b, &a); s_hi = b; s_above = a; }
@@ -544,21 +602,42 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
         // fewer than k entries pass min_score: keep them all
         if (tid == 0) { s_cut = min_score; s_quota = 0xFFFFFFFFu; }
     } else {
-        // ---- level 2: low 12 bits inside the high bin ----
+        // ---- level 2: the next 12 bits inside the high bin ----
         const unsigned above_hi = s_above;
         __syncthreads();
         for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += kTopkBlock) {
             const int v = row[i];
-            if (v >= min_score && (clampi(v, 0, kScoreCap) >> 12) == hi) atomicAdd(&hist[clampi(v, 0, kScoreCap) & (kBins - 1)], 1u);
+            if (v >= min_score && ((v >> shift) >> 12) == hi) atomicAdd(&hist[(v >> shift) & (kBins - 1)], 1u);
         }
         __syncthreads();
         if (tid == 0) {
             int b; unsigned a;
             find_bin(hist, k - above_hi, &b, &a);
-            s_cut = (hi << 12) | b;                       // exact cut score (scores are < 2^24)
-            s_quota = k - (above_hi + a);                 // ties at the cut to keep (smallest ids)
+            s_cut = (hi << 12) | b;                       // cut >> shift, exact
+            s_above = above_hi + a;                       // entries strictly above it
+            s_quota = k - (above_hi + a);                 // shift == 0: ties at the cut to keep (smallest ids)
+        }
+        if (shift) {
+            // ---- level 3: the `shift` low bits among the entries whose upper 24 bits equal the cut's ----
+            __syncthreads();
+            const int cut24 = s_cut;
+            const unsigned above24 = s_above;
+            __syncthreads();
+            for (int i = tid; i < kBins; i += kTopkBlock) hist[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kTopkBlock) {
+                const int v = row[i];
+                if (v >= min_score && (v >> shift) == cut24) atomicAdd(&hist[v & ((1 << shift) - 1)], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int b; unsigned a;
+                find_bin(hist, k - above24, &b, &a);
+                s_cut = (cut24 << shift) | b;
+                s_quota = k - (above24 + a);
+            }
         }
     }
     if (tid == 0) { s_nout = 0; s_tie_base = 0; }
@@ -711,12 +790,15 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
-    rc = scratch_acquire(db, stream);
+    ScratchScope scope(db, stream);
+    rc = scope.acquire();
+    if (rc) return rc;
+    rc = stats_begin(cx, stream);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_ids, 0xFF, (size_t)q_count * k * 4, stream));
     HIP_TRY(hipMemsetAsync(d_top_scores, 0, (size_t)q_count * k * 4, stream));
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)q_count * 4, stream));
-    if (db->n_seqs == 0) return scratch_release(db, stream);
+    if (db->n_seqs == 0) return scope.release();
     ensure_bounds(q, scorer);
     const uint64_t cols = db->max_tile_seqs;
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_count, kTileScoreBudget / (cols * 4)));
@@ -743,6 +825,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         Plan p;
         rc = make_plan(db, q, q_begin + b, cnt, scorer, flags, &p);
         if (rc) return rc;
+        stats_add(cx, p);
         rc = ensure_scratch(db, scorer, p, stream);
         if (rc) return rc;
         // Kinds of tile: entirely on the scan kernels (g0 = 0), entirely on the pair kernels (the long-sequence tile of a real
@@ -786,6 +869,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
                 if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(cx->side_fork, stream));                 // after this batch's uploads
             HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+            scope.forked = true;
         }
         if (alternate && cx->ws_side_bytes < p.ws_bytes) {
             if (cx->d_ws_side) HIP_TRY(hipFree(cx->d_ws_side));
@@ -807,6 +891,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
             uint32_t* l_ids = reinterpret_cast<uint32_t*>(buf + (uint64_t)batch * cols);
             int32_t* l_sc = reinterpret_cast<int32_t*>(l_ids + lists_max * k);
             uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_sc + lists_max * k);
+            if (g0) cx->stat_pair_items += (uint64_t)cnt * std::min<uint64_t>(t.n_seqs, (uint64_t)g0 * 64);
             if (as_pairs) {
                 rc = tile_as_pairs(db, t, q, q_begin + b, cnt, scorer, buf, t.n_seqs, true, st, t.n_seqs);
             } else if (g0) {        // split tile (always on the caller's stream): its longest groups as pairs on the side stream
@@ -833,7 +918,7 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         }
         if (last == 1) HIP_TRY(hipStreamWaitEvent(stream, cx->merge_done[1], 0));
     }
-    return scratch_release(db, stream);
+    return scope.release();
 }
 
 S4G_API int s4g_topk_host(const s4g_db* db, const int32_t* d_scores, uint32_t q_count, uint32_t k, int32_t min_score,

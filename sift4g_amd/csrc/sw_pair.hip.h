@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void sw_pair_scan_band(const PairBandArgs b) {
 // 64-column slabs) and recomputes every marked entry exactly, in int32, one wave per pair, band by band.
 
 struct RecheckArgs {
-    PairBandArgs b;                     // b.p.items / counter / n_pairs unused
+    PairBandArgs b;                     // b.p.items / n_pairs unused; b.p.counter (may be NULL) counts the recomputed entries
     uint64_t stride;                    // scores[row * stride + column]
     uint32_t q_begin, q_count, n_cols;
     const uint32_t* __restrict__ col_ids;   // column -> target id (NULL: the column IS the id)
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64) void sw_pair_recheck(const RecheckArgs r) {
         int32_t* line = a.scores + (uint64_t)row * r.stride;
         const int v = col0 + lane < r.n_cols ? line[col0 + lane] : 0;
         unsigned long long marked = __ballot(v == kScoreUnsure);
+        if (marked && a.counter && lane == 0) atomicAdd(a.counter, (unsigned)__popcll(marked));
         while (marked) {
             const unsigned col = col0 + (unsigned)__builtin_ctzll(marked);
             marked &= marked - 1;

@@ -185,6 +185,21 @@ def scan_plan(db, queries, scorer):
                 workspace_bytes=w.value)
 
 
+def scan_stats(device=0):
+    """what the last scan call on `device` did (s4g_scan_stats): queries per tier, speculative routing, rechecked entries, pairs"""
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib.s4g_scan_stats(device, _ptr(out, c_u64p), 8), "s4g_scan_stats")
+    return dict(tier_drift=int(out[0]), tier_m3=int(out[1]), tier_i16=int(out[2]), tier_i32=int(out[3]),
+                speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]))
+
+
+def clock_probe(device=0):
+    """shader clock under vector-ALU load and the measured packed-int16 issue rate (s4g_clock_probe)"""
+    out = (ctypes.c_double * 5)()
+    check(lib.s4g_clock_probe(device, out, 5), "s4g_clock_probe")
+    return dict(shader_mhz=out[0], pk_add_T_lane_ops=out[1], cus=int(out[2]), nominal_mhz=out[3], probe_ms=out[4])
+
+
 def _flags(force_i32=False, no_f16=False, f16_arith=False, no_drift=False, no_pairs=False, no_spec=False):
     return ((_lib.S4G_SCAN_FORCE_I32 if force_i32 else 0) | (_lib.S4G_SCAN_NO_F16 if no_f16 else 0) |
             (_lib.S4G_SCAN_F16_ARITH if f16_arith else 0) | (_lib.S4G_SCAN_NO_DRIFT if no_drift else 0) |

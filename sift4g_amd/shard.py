@@ -81,12 +81,16 @@ def merge_topk(ids, scores, k):
 
 def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None):
     """DB-shard mode: every rank holds, for ALL queries, its local top-k (ids index the rank's own shard).
-    global_ids: int tensor mapping local target id -> global id for this rank.  Returns the merged global top-k on
-    every rank.  One all-gather of 2K int32 per query per rank, then a K-way merge."""
+    global_ids: int tensor mapping local target id -> global id for this rank, or a plain int = the global id of the
+    rank's local target 0 (contiguous shards).  Returns the merged global top-k on every rank.  One all-gather of 2K int32
+    per query per rank, then a K-way merge."""
     world = _world(group)
     valid = local_ids >= 0
-    gid = torch.where(valid, global_ids.to(local_ids.device)[local_ids.clamp(min=0).long()].to(torch.int32),
-                      torch.full_like(local_ids, -1))
+    if isinstance(global_ids, int):
+        gid = torch.where(valid, local_ids + global_ids, torch.full_like(local_ids, -1))
+    else:
+        gid = torch.where(valid, global_ids.to(local_ids.device)[local_ids.clamp(min=0).long()].to(torch.int32),
+                          torch.full_like(local_ids, -1))
     if world == 1 and not dist.is_initialized():
         return merge_topk(gid, scores, k)
     q, kk = gid.shape

@@ -122,3 +122,24 @@ def make_config(cfg=2, n_queries=1000, n_targets=100000, homologs_per_query=50, 
     for t, seq in hom.items():
         t_codes[int(t_off[t]):int(t_off[t + 1])] = seq
     return dict(q_codes=q_codes, q_off=q_off, t_codes=t_codes, t_off=t_off, planted=planted)
+
+
+def device_database(n_targets, seed, device, mu=5.68, sigma=0.55, lo=30, hi=3000, chunk=1 << 28):
+    """BASELINE configs[3]: a database shard generated ON THE DEVICE (150M sequences never visit the host).
+    Same length law and residue frequencies as make_config, torch's device generator seeded with `seed`.
+    -> (codes uint8 [total] , offsets int64 [n+1]) torch tensors on `device`."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    z = torch.randn(n_targets, device=device, generator=g)
+    lengths = torch.exp(z * sigma + mu).floor_().clamp_(lo, hi).to(torch.int64)
+    offsets = torch.zeros(n_targets + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lengths, 0, out=offsets[1:])
+    total = int(offsets[-1])
+    cum = torch.from_numpy(_CUM[:-1].astype(np.float32)).to(device)       # letter = number of cumulative bounds <= u
+    codes = torch.empty(total, dtype=torch.uint8, device=device)
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        u = torch.rand(b - a, device=device, generator=g)
+        codes[a:b] = torch.bucketize(u, cum, right=True).clamp_(0, 25).to(torch.uint8)
+    return codes, offsets

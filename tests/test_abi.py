@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/s4g_hip.h but not exported by libs4g_hip.so"
     assert sorted(_lib.SIGNATURES) == declared, "sift4g_amd/_lib.py SIGNATURES out of sync with include/s4g_hip.h"
-    assert _lib.lib.s4g_abi_version() == 1
+    assert _lib.lib.s4g_abi_version() == 2
 
 
 def test_header_cites_reference_interfaces():
@@ -80,3 +80,16 @@ def test_product_never_touches_the_oracle():
                     bad.append(os.path.join(base, f))
     assert not bad, bad
 
+
+
+def test_the_cpu_stand_in_cannot_be_loaded_as_the_product_library():
+    """tests/cpu_shim/lib/libs4g_hip.so answers the device ABI from the oracle under the product library's file name; the
+    Python face refuses it (s4g_is_shim), whatever S4G_LIB says."""
+    import subprocess, sys
+    shim = os.path.join(ROOT, "tests", "cpu_shim")
+    subprocess.run(["make", "-s", "-C", shim], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", "import sift4g_amd"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, S4G_LIB=os.path.join(shim, "lib", "libs4g_hip.so")))
+    assert r.returncode != 0 and "stand-in" in r.stderr
+    raw = ctypes.CDLL(os.path.join(ROOT, "sift4g_amd", "lib", "libs4g_hip.so"))
+    assert not hasattr(raw, "s4g_is_shim")
