@@ -1,6 +1,7 @@
 # Builds every native artefact in-tree (the .so files travel to the GPU box with the snapshot).
 #   make            -> sift4g_amd/lib/libs4g_hip.so (HIP, gfx950), sift4g_amd/lib/libswsharp.so (C++ host API),
 #                      oracle/libsw_oracle.so (test infrastructure)
+#   make dropin-batched / dropin-fullscan -> the same CLI with one / two of the reference's source files replaced (see below)
 #   make dropin     -> build/sift4g : the reference's own sift4g sources compiled IN PLACE from /root/reference
 #                      against include/swsharp/*.h and linked with our libraries (only where /root/reference exists)
 HIPCC   ?= /opt/rocm/bin/hipcc
@@ -33,8 +34,8 @@ $(LIBDIR)/libs4g_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIPOBJ)
 
-$(LIBDIR)/libswsharp.so: $(SWSRC) $(CSRC)/swsharp/impl.hpp $(CSRC)/matrices.h include/swsharp/swsharp.h include/swsharp/evalue.h $(LIBDIR)/libs4g_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(SWSRC) -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/libswsharp.so: $(SWSRC) $(CSRC)/swsharp/impl.hpp $(CSRC)/matrices.h $(CSRC)/swsharp/libswsharp.map include/swsharp/swsharp.h include/swsharp/evalue.h $(LIBDIR)/libs4g_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(SWSRC) -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,--version-script=$(CSRC)/swsharp/libswsharp.map
 
 # Drop-in link test: the reference's own, unmodified sift4g sources compiled where they lie, against OUR
 # swsharp-compatible headers and libraries.  Not an oracle (it runs our scorer); needs a GPU to run.
@@ -54,6 +55,17 @@ dropin-batched: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/batched_database_
 	    $(filter-out %/database_alignment.cpp,$(wildcard $(REF)/sift4g/src/*.cpp)) sift4g_amd/csrc/dropin/batched_database_alignment.cpp \
 	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
+# The full-scan build: TWO source files of the reference replaced -- the k-mer prefilter by a pass that only
+# counts the database's residues (count_database_search.cpp) and the alignment wrapper by one shotgunDatabaseEValues call per
+# chunk over ALL its sequences (fullscan_database_alignment.cpp).  main, selection and SIFT are the reference's own code.
+dropin-fullscan: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/fullscan_database_alignment.cpp sift4g_amd/csrc/dropin/count_database_search.cpp
+	@test -d $(REF)/sift4g/src || { echo "no reference tree at $(REF): skipping drop-in build"; exit 0; }
+	@mkdir -p build/dropin
+	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -I$(REF)/sift4g/src -o build/dropin/sift4g_fullscan \
+	    $(filter-out %/database_alignment.cpp %/database_search.cpp,$(wildcard $(REF)/sift4g/src/*.cpp)) \
+	    sift4g_amd/csrc/dropin/fullscan_database_alignment.cpp sift4g_amd/csrc/dropin/count_database_search.cpp \
+	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
 oracle:
 	$(MAKE) -s -C oracle
 
@@ -65,4 +77,4 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean dropin dropin-batched
+.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan

@@ -68,7 +68,7 @@ S4G_API int s4g_device_check(const int* cards, int n) {
 
 S4G_API int s4g_matrix_by_name(const char* name, int32_t* table26x26) {
     if (!name || !table26x26) return fail(S4G_ERR_INVALID, "NULL argument");
-    if (!matrix_by_name(name, table26x26)) return fail(S4G_ERR_INVALID, "unknown substitution matrix '%s' (available: BLOSUM_62)", name);
+    if (!matrix_by_name(name, table26x26)) return fail(S4G_ERR_INVALID, "unknown substitution matrix '%s' (available: %s)", name, kMatrixNames);
     return S4G_OK;
 }
 

@@ -257,8 +257,8 @@ SW_API void scorerCreateMatrix(Scorer** scorer, char* name, int gapOpen, int gap
     Scorer* s = new Scorer();
     s->name = name ? name : "";
     s->gap_open = gapOpen; s->gap_extend = gapExtend; s->dev = NULL;
-    SW_ASSERT(s4g::matrix_by_name(s->name.c_str(), s->table), "unknown or unsupported similarity matrix '%s' (available: BLOSUM_62)",
-              s->name.c_str());
+    SW_ASSERT(s4g::matrix_by_name(s->name.c_str(), s->table), "unknown similarity matrix '%s' (available: %s)",
+              s->name.c_str(), s4g::kMatrixNames);
     scorer_finish(s);
     *scorer = s;
 }

@@ -89,9 +89,9 @@ def chain_codes(c):
     return [p[i] for i in range(n)]
 
 
-def scorer(go=10, ge=1):
+def scorer(go=10, ge=1, name="BLOSUM_62"):
     s = vp()
-    L.scorerCreateMatrix(ctypes.byref(s), b"BLOSUM_62", go, ge)
+    L.scorerCreateMatrix(ctypes.byref(s), name.encode(), go, ge)
     return s
 
 

@@ -93,3 +93,16 @@ def test_the_cpu_stand_in_cannot_be_loaded_as_the_product_library():
     assert r.returncode != 0 and "stand-in" in r.stderr
     raw = ctypes.CDLL(os.path.join(ROOT, "sift4g_amd", "lib", "libs4g_hip.so"))
     assert not hasattr(raw, "s4g_is_shim")
+
+
+def test_libswsharp_exports_only_its_c_api():
+    """the host library exports the swsharp-compatible C API (version script libswsharp.map) and no C++ runtime instantiations
+    (round 1 leaked std::thread state objects and vector bases into the dynamic symbol table)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "sift4g_amd", "lib", "libswsharp.so")],
+                         capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and not [n for n in names if n.startswith("_Z")]
+    for must in ("alignDatabase", "chainCreate", "scorerCreateMatrix", "createEValueParams", "eValues", "dbAlignmentsMerge",
+                 "shotgunDatabaseEValues", "readFastaChainsPart", "threadPoolSubmit", "cudaCheckCards"):
+        assert must in names, must

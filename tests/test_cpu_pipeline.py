@@ -70,3 +70,42 @@ def test_batched_wrapper_on_the_cpu_oracle_reproduces_the_same_outputs(tmp_path)
     parts = tmp_path / "parts"
     parts.mkdir()
     assert dropin_synth.run(BATCHED, str(parts), env=dict(env, S4G_CHUNK_BYTES="30000")) == want
+
+
+FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
+
+
+def hit_lines(data):
+    return [l for l in data.splitlines() if l and not l.startswith(b"#")]
+
+
+@pytest.mark.skipif(not os.path.exists(FULLSCAN), reason="full-scan drop-in not built (needs /root/reference at build time: make dropin-fullscan)")
+def test_fullscan_build_on_the_cpu_oracle(tmp_path):
+    """the reference CLI with the k-mer prefilter and the alignment wrapper replaced (make dropin-fullscan: every query against
+    every sequence of every chunk through shotgunDatabaseEValues), here on the oracle stand-in: reproduces
+    tests/golden/dropin_fullscan/ (which the MI355X run must also reproduce), and every hit of the prefiltered builds is in it
+    unchanged -- same score, e-value, coordinates, identity and gap counts -- next to the homologs the prefilter missed."""
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    files = os.path.join(GOLDEN, "test_files")
+    out = tmp_path / "fixture"
+    out.mkdir()
+    r = subprocess.run([FULLSCAN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep,
+                        "-d", os.path.join(files, "sample_protein_database.fa"), "--cards", "0", "--out", str(out), "--sub-results"],
+                       env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    gold = os.path.join(GOLDEN, "dropin_fullscan")
+    for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+        assert (out / n).read_bytes() == open(os.path.join(gold, n), "rb").read(), n
+    full = set(hit_lines((out / "alignments.txt").read_bytes()))
+    pre = set(hit_lines(open(os.path.join(GOLDEN, "dropin_predictions", "alignments.txt"), "rb").read()))
+    assert pre < full and len(full - pre) == 5
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    got = dropin_synth.run(FULLSCAN, str(syn), env=env)
+    assert got == open(os.path.join(gold, "synth_alignments.txt"), "rb").read()
+    pre = set(hit_lines(open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()))
+    assert pre <= set(hit_lines(got)) and len(hit_lines(got)) == len(pre) + 6
+    parts = tmp_path / "parts"                     # the database in ~17 parts: dbAlignmentsMerge across parts, chain deletion
+    parts.mkdir()
+    assert dropin_synth.run(FULLSCAN, str(parts), env=dict(env, S4G_CHUNK_BYTES="30000")) == got

@@ -209,6 +209,28 @@ def test_custom_matrix(s4g, oracle_mod):
     _check(s4g, oracle_mod, M, rand_seqs(rng, 5, 20, 150, 26), rand_seqs(rng, 90, 5, 200, 26), sc, 7, 2)
 
 
+@pytest.mark.parametrize("name,go,ge", [("BLOSUM_45", 14, 2), ("BLOSUM_50", 13, 2), ("BLOSUM_80", 10, 1), ("BLOSUM_90", 10, 1),
+                                        ("PAM_30", 9, 1), ("PAM_70", 10, 1), ("PAM_250", 14, 2), ("BLOSUM_250", 10, 1)])
+def test_every_builtin_matrix(s4g, oracle_mod, name, go, ge):
+    """the other tables scorerCreateMatrix knows (main.cpp:304-314), each with BLAST's default penalties for it: every tier
+    against the oracle on all 26 codes (B / Z / X columns, J / O / U as X), with planted homologs.  PAM_30's -17 .. 13 range
+    and BLOSUM_45's 15 move the bias and the score bounds the tier routing works from."""
+    from sift4g_amd.device import matrix_by_name
+    M = matrix_by_name(name)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    qs = rand_seqs(rng, 11, 40, 420, 26)
+    ts = rand_seqs(rng, 520, 1, 500, 26)
+    for k in range(40):
+        src = qs[k % len(qs)]
+        m = src.copy()
+        idx = rng.choice(len(m), size=max(1, len(m) // 5), replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]
+        cut = int(rng.integers(1, len(m)))
+        ts[k * 7] = np.concatenate([m[:cut], rand_seqs(rng, 1, 3, 3)[0], m[cut:]])
+    got = _check(s4g, oracle_mod, M, qs, ts, s4g.Scorer(name, go, ge), go, ge)
+    assert got.max() > 300
+
+
 def test_query_ranges_and_device_tensor(s4g, oracle_mod, blosum62, scorer):
     """s4g_scan into a torch device buffer on torch's current stream, by query sub-range."""
     import torch

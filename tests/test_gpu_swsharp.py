@@ -152,6 +152,9 @@ def test_evalue_driven_selection_equals_callback_path(oracle_mod, blosum62):
     cells = int(sum(len(t) for t in ts))
     ev = L.createEValueParams(cells, s)
     cb = sw.evalue_callback()
+    from oracle import evalue_ref as er
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    P = er.gumbel_parameters("BLOSUM_62", 10, 1, "swsharp")
     for cards in (None, (0, 0)):
         carr = (ci * len(cards))(*cards) if cards else None
         cdb = L.chainDatabaseCreate(tarr, 0, len(tch), carr, len(cards) if cards else 0)
@@ -163,6 +166,15 @@ def test_evalue_driven_selection_equals_callback_path(oracle_mod, blosum62):
             for i in range(len(qs)):
                 assert la[i] == lb[i], (max_al, thr, i, la[i], lb[i])
                 assert _hits(a[i], la[i]) == _hits(b[i], lb[i]), (max_al, thr, i)
+                # ... and against the INDEPENDENT restatement (oracle scores + oracle/evalue_ref.py, neither shares code with
+                # the library): the same targets in the same order, the same scores, e-values to 1e-12 relative
+                vals = [er.evalue(int(exp[i, t]), len(qs[i]), len(ts[t]), cells, P) for t in range(len(ts))]
+                order = sorted((t for t in range(len(ts)) if vals[t] <= thr), key=lambda t: (vals[t], -int(exp[i, t]), t))[:max_al]
+                got = _hits(b[i], lb[i])
+                assert [h[0] for h in got] == order, (max_al, thr, i)
+                assert [h[1] for h in got] == [int(exp[i, t]) for t in order]
+                for h, t in zip(got, order):
+                    assert h[2] == pytest.approx(vals[t], rel=1e-12, abs=0.0)
             assert la[0] == min(max_al, la[0]) and la[0] >= 1
             L.deleteShotgunDatabase(a, la, len(qs)); L.deleteShotgunDatabase(b, lb, len(qs))
         L.chainDatabaseDelete(cdb)
@@ -233,3 +245,48 @@ def test_batched_wrapper_gives_the_reference_flows_alignments(tmp_path):
     parts = tmp_path / "parts"                                  # the database in ~17 parts (merge across parts)
     parts.mkdir()
     assert dropin_synth.run(BATCHED, str(parts), env=dict(os.environ, S4G_CHUNK_BYTES="30000")) == want
+
+
+FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
+
+
+@pytest.mark.skipif(not os.path.exists(FULLSCAN), reason="full-scan drop-in not built (needs /root/reference at build time: make dropin-fullscan)")
+def test_fullscan_build_is_a_superset_of_the_prefiltered_build(tmp_path):
+    """build/dropin/sift4g_fullscan = the reference CLI with the k-mer prefilter replaced by a residue count and
+    the alignment wrapper by one shotgunDatabaseEValues call per chunk over ALL its sequences.  On the MI355X it writes the
+    bytes of tests/golden/dropin_fullscan/ (which the oracle pipeline also writes, tests/test_cpu_pipeline.py); every hit of the
+    prefiltered builds is there with identical score, e-value and alignment, plus the homologs the prefilter missed.  Stage times
+    of both builds on a 60-query x 20 000-target set are printed (pytest -s) and recorded in profiles/."""
+    import dropin_synth, re, time
+    from test_cpu_pipeline import hit_lines
+    tf = os.path.join(GOLDEN, "test_files")
+    out = tmp_path / "fixture"
+    out.mkdir()
+    r = subprocess.run([FULLSCAN, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d",
+                        os.path.join(tf, "sample_protein_database.fa"), "--out", str(out), "--cards", "0", "--sub-results"],
+                       capture_output=True, text=True, timeout=600, cwd=str(out))
+    assert r.returncode == 0, r.stderr[-2000:]
+    gold = os.path.join(GOLDEN, "dropin_fullscan")
+    for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+        assert (out / n).read_bytes() == open(os.path.join(gold, n), "rb").read(), n
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    got = dropin_synth.run(FULLSCAN, str(syn))
+    assert got == open(os.path.join(gold, "synth_alignments.txt"), "rb").read()
+    pre = set(hit_lines(open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()))
+    assert pre <= set(hit_lines(got))
+    parts = tmp_path / "parts"
+    parts.mkdir()
+    assert dropin_synth.run(FULLSCAN, str(parts), env=dict(os.environ, S4G_CHUNK_BYTES="30000")) == got
+    # a larger set: superset again, and the wall time of both builds (whole CLI: FASTA reads, prefilter or count, alignment, SIFT)
+    times = {}
+    outs = {}
+    for name, exe in (("prefiltered (batched wrapper)", BATCHED), ("full scan", FULLSCAN)):
+        d = tmp_path / name.split()[0]
+        d.mkdir()
+        t0 = time.perf_counter()
+        outs[name] = dropin_synth.run(exe, str(d), nq=60, nt=20000)
+        times[name] = time.perf_counter() - t0
+    a, b = set(hit_lines(outs["prefiltered (batched wrapper)"])), set(hit_lines(outs["full scan"]))
+    assert a <= b, sorted(a - b)[:3]
+    print(f"\n60 queries x 20000 targets, whole CLI incl. FASTA generation: " + ", ".join(f"{k} {v:.2f} s ({len(hit_lines(outs[k]))} hits)" for k, v in times.items()))

@@ -46,6 +46,78 @@ def test_blosum62_published_statistics(blosum62):
     assert abs(H - 0.4012) < 1e-3
 
 
+MATRIX_NAMES = ["BLOSUM_45", "BLOSUM_50", "BLOSUM_62", "BLOSUM_80", "BLOSUM_90", "PAM_30", "PAM_70", "PAM_250"]
+
+
+def test_published_statistics_of_every_matrix():
+    """Every built-in table (the five BLOSUMs and three PAMs the CLI offers, main.cpp:304-314) is pinned by the ungapped
+    Karlin-Altschul statistics NCBI publishes for it: lambda, relative entropy H and K, all three recomputed from the typed-in
+    table itself by oracle/evalue_ref.py (lambda and H to four digits, K to the three digits that are published).  This fixes
+    the 20 x 20 core of each table; and the published a = lambda / H of the ungapped rows (PAM_250's published 0.98 is the one
+    that does not follow that rule)."""
+    from oracle import evalue_ref as er
+    from sift4g_amd.device import matrix_by_name
+    for name in MATRIX_NAMES:
+        M = matrix_by_name(name)
+        assert (M == M.T).all(), name
+        st_ = er.ungapped_statistics(M)
+        lam, K, H, a, _, _ = er.PUBLISHED[(name, 0, 0)]
+        assert abs(st_["lam"] - lam) < 1.5e-4, (name, st_)
+        assert abs(st_["H"] - H) < 1e-3 * max(1.0, H), (name, st_)
+        assert abs(st_["K"] - K) < 6e-4 * max(1.0, K / 0.1), (name, st_)
+        if name != "PAM_250":
+            assert abs(st_["lam"] / st_["H"] - a) < 3e-4, (name, st_)
+    # the CLI's own spelling of the PAM tables (main.cpp:310-312) names the same tables
+    for alias, name in (("BLOSUM_30", "PAM_30"), ("BLOSUM_70", "PAM_70"), ("BLOSUM_250", "PAM_250")):
+        assert (matrix_by_name(alias) == matrix_by_name(name)).all()
+
+
+def test_matrix_digests_are_stable():
+    """SHA-256 of every table in the canonical form of tools/matrix_digest.py (what to compare with NCBI's files, which this
+    image does not hold): a change to any typed-in entry shows up here."""
+    import json, os, sys
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import matrix_digest as md
+    from sift4g_amd.device import matrix_by_name
+    want = json.load(open(os.path.join(GOLDEN, "matrix_sha256.json")))
+    assert sorted(want) == sorted(MATRIX_NAMES)
+    for name in MATRIX_NAMES:
+        assert md.digest(md.canonical_from_table26(matrix_by_name(name))) == want[name], name
+    # the file-format reader reduces an NCBI-style rendering of the same table to the same digest
+    M = matrix_by_name("BLOSUM_62")
+    syms = md.ORDER[:-1]
+    text = "# Matrix made by matblas from blosum62.iij\n   " + "  ".join(syms) + "  *\n" + "".join(
+        a + " " + " ".join(f"{int(M[ord(a) - 65][ord(b) - 65]):2d}" for b in syms) + " -4\n" for a in syms) + "* " + " -4" * 23 + "  1\n"
+    assert md.digest(md.canonical_from_ncbi_file(text)) == want["BLOSUM_62"]
+
+
+def test_three_scorers_triangulate(oracle_mod):
+    """oracle/sw_oracle.c (row-major scalar), oracle/sw_simd.c (column-major AVX2 int16) and oracle/sw_numpy.py (anti-diagonal
+    numpy int64): three forms of the same recurrence written separately must agree on random, homologous and degenerate
+    pairs, for every built-in matrix and several gap models."""
+    from oracle import sw_numpy
+    from sift4g_amd.device import matrix_by_name
+    rng = np.random.default_rng(77)
+    qs = rand_seqs(rng, 5, 1, 140, 26) + [np.zeros(0, dtype=np.uint8), np.full(37, 22, dtype=np.uint8)]
+    ts = rand_seqs(rng, 14, 1, 170, 26) + [np.zeros(0, dtype=np.uint8)]
+    ts[0] = qs[0].copy()
+    ts[1] = np.concatenate([qs[1][:40], rand_seqs(rng, 1, 7, 7)[0], qs[1][40:]])       # insertion
+    ts[2] = np.concatenate([qs[2][:30], qs[2][41:]]) if len(qs[2]) > 50 else ts[2]    # deletion
+    for name, go, ge in (("BLOSUM_62", 10, 1), ("BLOSUM_45", 14, 2), ("BLOSUM_80", 10, 1), ("PAM_30", 9, 1), ("PAM_250", 14, 2),
+                         ("BLOSUM_50", 3, 3), ("BLOSUM_90", 12, 0), ("PAM_70", 1, 1)):
+        M = matrix_by_name(name)
+        a = oracle_mod.scan(qs, ts, M, go, ge, threads=4)
+        b = sw_numpy.scan(qs, ts, M, go, ge)
+        assert np.array_equal(a, b), (name, go, ge, np.argwhere(a != b)[:4].tolist())
+        if oracle_mod.simd_available():
+            qc, qo = oracle_mod._flat(qs)
+            tc, to = oracle_mod._flat(ts)
+            c = oracle_mod.scan_simd_flat(qc, qo, tc, to, M, go, ge, threads=2)
+            assert np.array_equal(a, c), (name, go, ge)
+    assert a.max() > 0
+
+
 def test_cfg1_fixture_identities(oracle_mod, blosum62, cfg1):
     """SURVEY.md section 4: DB entry QUERY == query LACI_ECOLI; DB LACI_ECOLI differs at 286 (L->S);
     DB PURR_SALTY == query PURR_SALTY."""

@@ -299,3 +299,82 @@ def test_evalue_behaviour():
 
 def test_cards_api_without_gpu():
     assert L.cudaCheckCards(None, 0) == 1          # main.cpp:78-79,186: zero cards must pass
+
+
+def test_evalues_equal_the_independent_restatement():
+    """createEValueParams + eValues against tests/golden/evalue_kat.json -- vectors computed by oracle/evalue_ref.py, which is
+    written from the published formulas (Karlin-Altschul 1990, Park-Sheetlin-Spouge 2012) and shares no code or constants
+    file with evalue.cpp -- for ten scorers over eight matrices, both row conventions, degenerate lengths, scores from 1 to
+    12 000 and database sizes from the fixture's 3 091 residues to configs[3]'s 5.1e10.  1e-12 relative."""
+    import json
+    kat = json.load(open(os.path.join(GOLDEN, "evalue_kat.json")))
+    assert len(kat["cases"]) > 700
+    groups = {}
+    for c in kat["cases"]:
+        groups.setdefault(tuple(c[:7]), []).append((c[7], c[8]))
+    seen_conventions = set()
+    old = os.environ.get("S4G_EVALUE_CONVENTION")
+    try:
+        for (matrix, go, ge, conv, m, n, db), rows in groups.items():
+            os.environ["S4G_EVALUE_CONVENTION"] = conv
+            seen_conventions.add(conv)
+            s = sw.scorer(go, ge, matrix)
+            ev = L.createEValueParams(db, s)
+            q = sw.chain("q", np.zeros(m, dtype=np.uint8))
+            t = sw.chain("t", np.zeros(n, dtype=np.uint8))
+            k = len(rows)
+            vals = (cd * k)()
+            L.eValues(vals, (ci * k)(*[r[0] for r in rows]), q, sw.chain_array([t] * k), k, None, 0, ev)
+            for (score, want), got in zip(rows, vals):
+                assert got == pytest.approx(want, rel=1e-12, abs=0.0), (matrix, go, ge, conv, m, n, db, score, got, want)
+            L.deleteEValueParams(ev); L.chainDelete(q); L.chainDelete(t); L.scorerDelete(s)
+    finally:
+        if old is None:
+            os.environ.pop("S4G_EVALUE_CONVENTION", None)
+        else:
+            os.environ["S4G_EVALUE_CONVENTION"] = old
+    assert seen_conventions == {"swsharp", "blast"}
+
+
+def test_evalue_row_convention_and_missing_rows(capfd):
+    """sift4g's default scorer (BLOSUM_62, 10/1): the default convention looks the penalties up unconverted (row 10/1, lambda
+    0.243) -- upstream swsharp's behaviour as far as it can be recalled; S4G_EVALUE_CONVENTION=blast converts to BLAST's
+    existence first (row 9/1, lambda 0.206).  Penalties without a published row fall back to the matrix's BLAST default WITH a
+    warning on stderr (round 1 fell back silently)."""
+    from oracle import evalue_ref as er
+    q = sw.chain("q", np.zeros(350, dtype=np.uint8))
+    t = sw.chain("t", np.zeros(340, dtype=np.uint8))
+    arr = sw.chain_array([t])
+
+    def one(go, ge, name="BLOSUM_62", conv=None):
+        old = os.environ.pop("S4G_EVALUE_CONVENTION", None)
+        if conv:
+            os.environ["S4G_EVALUE_CONVENTION"] = conv
+        try:
+            s = sw.scorer(go, ge, name)
+            ev = L.createEValueParams(34_548_336, s)
+            v = (cd * 1)()
+            L.eValues(v, (ci * 1)(100), q, arr, 1, None, 0, ev)
+            L.deleteEValueParams(ev); L.scorerDelete(s)
+            return v[0]
+        finally:
+            os.environ.pop("S4G_EVALUE_CONVENTION", None)
+            if old is not None:
+                os.environ["S4G_EVALUE_CONVENTION"] = old
+
+    capfd.readouterr()
+    default = one(10, 1)
+    assert default == pytest.approx(er.evalue(100, 350, 340, 34_548_336, er.gumbel_parameters("BLOSUM_62", 10, 1, "swsharp")), rel=1e-12)
+    assert one(10, 1, conv="swsharp") == default
+    blast = one(10, 1, conv="blast")
+    assert blast == pytest.approx(er.evalue(100, 350, 340, 34_548_336, er.gumbel_parameters("BLOSUM_62", 10, 1, "blast")), rel=1e-12)
+    assert blast > 3 * default                                   # the two readings differ by far more than any rounding
+    assert one(11, 1, conv="blast") == pytest.approx(default, rel=1e-12)     # existence 10 + extension 1: the same row
+    assert "WARNING" not in capfd.readouterr().err
+    fallback = one(17, 4)                                        # no published row
+    err = capfd.readouterr().err
+    assert "[WARNING]" in err and "17/4" in err and "11/1" in err
+    assert fallback == pytest.approx(one(11, 1), rel=1e-12)
+    one(10, 1, name="BLOSUM_30")                                 # the CLI's spelling of PAM_30 (main.cpp:310): 10/1 has a row there
+    assert "WARNING" not in capfd.readouterr().err
+    L.chainDelete(q); L.chainDelete(t)
