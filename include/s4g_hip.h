@@ -175,6 +175,11 @@ int s4g_score_lists_host(const s4g_db* db, const s4g_queries* q, const uint64_t*
  * columns; flags force one route (tests, measurements). */
 #define S4G_PAIRS_FORCE_WAVE 1u  /* one wave per pair */
 #define S4G_PAIRS_FORCE_SCAN 2u  /* full scan + column pick */
+#define S4G_PAIRS_FORCE_LISTS 4u /* every pair the drifting-frame window admits through the packed list kernel (sw_scan_lists: a query's
+                                    candidates sorted by length on the device, gathered 128 to an item, two targets per register);
+                                    by default only batches of >= 65536 pairs take it, and their longest targets stay with the waves */
+#define S4G_PAIRS_LISTS_SPLIT(residues) (S4G_PAIRS_FORCE_LISTS | ((uint32_t)(residues) << 8))   /* the same with the cut chosen by the
+                                    caller: targets longer than `residues` go to the pair waves (measurements) */
 int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint64_t n_pairs,
                          const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, uint32_t flags);
 
@@ -224,11 +229,11 @@ int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
                   char* kernel_name, size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
                   uint32_t* strip_rows, uint64_t* workspace_bytes);
 
-/* What the last s4g_scan* / s4g_scan_topk* call on `device` did (measurement; synchronises the device):
+/* What the last s4g_scan* / s4g_scan_topk* / s4g_score_*_host call on `device` did (measurement; synchronises the device):
  * out[0..3] = queries routed to the drifting-frame / maximum3 / plain int16 / int32 kernels (summed over database tiles and
  * query batches), out[4] = of those, (query, tile) combinations that ran speculatively, out[5] = score entries the
  * speculative launches marked and the exact int32 pass recomputed, out[6] = (query, target) pairs given to the
- * one-wave-per-pair kernels, out[7] = 0.  cap >= 8. */
+ * one-wave-per-pair kernels, out[7] = pairs scored by the packed list kernel (s4g_score_pairs_host / s4g_score_lists_host).  cap >= 8. */
 int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
 
 /* Shader clock under a full vector-ALU load and the measured issue rate of packed-int16 vector instructions: what bench.py

@@ -130,10 +130,20 @@ struct DeviceCtx {
     // what the last s4g_scan / s4g_scan_topk call on this device did (s4g_scan_stats): queries per tier summed over tiles and
     // batches, queries that ran speculatively, pairs handed to the one-wave-per-pair kernels; the number of marked entries the
     // recheck pass recomputed is counted on the device (d_counter + kStatRechecked)
+    // candidate lists on the packed list kernel (s4g_lists.hip): pinned staging, device tables, gathered residues
+    char* h_lst_stage = nullptr;
+    uint64_t lst_stage_bytes = 0;
+    hipEvent_t lst_stage_done = nullptr;
+    char* d_lst = nullptr;
+    uint64_t lst_bytes = 0;
+    uint32_t* d_lst_res = nullptr;
+    uint64_t lst_res_bytes = 0;
+    uint32_t grid_lists = 0;
     uint64_t stat_tier[4] = {0, 0, 0, 0};
-    uint64_t stat_spec_queries = 0, stat_pair_items = 0;
+    uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
 };
 constexpr int kStatRechecked = 40;      // index into DeviceCtx::d_counter
+constexpr int kListCounter = 44;        // work queue of sw_scan_lists
 
 DeviceCtx* device_ctx(int device);
 
@@ -167,6 +177,7 @@ struct DevBuf {          // scoped device allocation for the non-hot paths
 };
 
 // s4g_scan.hip
+void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer);
 int device_props(DeviceCtx* cx);
 int scratch_acquire(const s4g_db* db, hipStream_t stream);
 int scratch_release(const s4g_db* db, hipStream_t stream);
@@ -193,6 +204,14 @@ struct ScratchScope {
 };
 
 // s4g_pairs.hip
+int ensure_seq_tables(const s4g_db* db);
+// stages and submits the pairs sel[] to the one-wave-per-pair kernels on `stream` (asynchronous; caller holds cx->mu): the score
+// of pair sel[i] will be at (*d_sc_out)[(*where)[i]]
+int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream);
+// s4g_lists.hip
+int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                       const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used);
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);
 uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);

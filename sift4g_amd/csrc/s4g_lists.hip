@@ -1,0 +1,300 @@
+// s4g_lists.hip -- candidate lists on the packed list kernel (sw_lists.hip.h): the host side of s4g_score_pairs_host's third
+// route.  What the batched wrapper submits per chunk -- every query with its own few thousand prefilter candidates
+// (/root/reference/sift4g/src/database_alignment.cpp:61-95,136-162 done for all queries at once) -- is split in two:
+//   * pairs whose target is short enough for an inter-sequence launch to carry (and whose query fits the drifting-frame
+//     window) are sorted by (query, length) on the device, cut into items of 128 candidates of one query, gathered into
+//     lane-transposed blocks and scored by sw_scan_lists, two targets per register;
+//   * the rest -- the long targets, a few percent of the pairs -- runs beside it on the one-wave-per-pair kernels.
+// Both are exact (the window argument is sw_scan_pkd's); which pairs go where only changes the time.
+#include "s4g_internal.hpp"
+#include "sw_lists.hip.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+constexpr int kListRows = 32;                        // strip height of sw_scan_lists
+constexpr uint64_t kListResSlack = 1024;             // dwords behind the gathered residues (an item of empty targets still reads one row)
+// Rates the split is chosen with (tools/lists_bench.py, profiles/r02_lists): cells per second of a chip full of list items
+// and of pair waves, and the cycles one resident list wave needs per row pair and column when it shares its SIMD.
+constexpr double kListChipRate = 8.3e12, kListWaveChipRate = 2.8e12;
+constexpr double kListCyclesPerRowCol = 64.0, kClockHz = 2.4e9;     // measured on the longest item of a launch at raised priority: one wave
+                                                                    // issues a dependent packed op every ~8.5 clocks however idle its SIMD is
+constexpr double kListFixedCost = 250e-6;            // sort + item tables + gather + one host round trip
+
+struct ListBuffers {
+    uint64_t *keys_in, *keys_out, *vals_in, *vals_out, *dwords, *offs;
+    ListItem* items;
+    int32_t* scores;
+    void* cub;
+    size_t cub_bytes;
+};
+
+inline uint64_t align256(uint64_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+// How long would the call take if pairs with targets up to `ls` residues went to the list kernel and the rest to pair waves?
+// cells_le[b] = cells of all eligible pairs with target length < 64 (b + 1); everything else goes to waves.
+static double lists_cost(const std::vector<double>& cells_le, double cells_all, uint32_t lq_max, uint32_t ls, uint32_t lt_max_all) {
+    const size_t b = std::min<size_t>(cells_le.size() - 1, ls / 64);
+    const double c_list = ls == 0 ? 0.0 : cells_le[b];
+    const double c_wave = cells_all - c_list;
+    const double chip = c_list / kListChipRate + c_wave / kListWaveChipRate;          // both parts share the chip
+    // a launch cannot end before the wave that holds its longest item has walked all rows x columns of it
+    const double lat_list = c_list > 0 ? (double)lq_max * std::min<double>(ls, lt_max_all) * kListCyclesPerRowCol / kClockHz : 0.0;
+    return std::max(chip, lat_list) + (c_list > 0 ? kListFixedCost : 0.0);
+}
+
+// Scores of the pairs sel[] (indices into pair_q / pair_t; every query non-empty) into h_scores[sel[i]].
+// force: every eligible pair goes to the list kernel whatever the estimate says (tests, measurements).
+// *used = false: the estimate prefers the pair kernels for everything; nothing was done.
+int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                       const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used) {
+    *used = false;
+    if (sel.empty()) return S4G_OK;
+    static const bool prof = getenv("S4G_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+    const auto t0 = now();
+    const bool gaps16 = scorer->open < 32768 && scorer->ext < 32768;
+    if (!gaps16) return S4G_OK;
+    ensure_bounds(q, scorer);
+    const uint64_t cap = 0x7BFF;
+    const uint64_t bias = (uint64_t)std::max(std::max(-kPadScore, -scorer->min_score), std::max(scorer->open, 2 * scorer->ext));
+
+    // ---- which pairs may go to the list kernel at all: the drifting-frame window per query (as make_plan's drift tier) ----
+    // bound + bias + (rows + columns) * ext <= 0x7BFF with rows = lq + 2R, columns = 4 * len4 + 8
+    std::vector<uint32_t> lt_cap(q->n, 0);              // longest target query i may meet in the list kernel (0: none)
+    for (uint32_t i = 0; i < q->n; ++i) {
+        const uint64_t fixed = q->score_bound[i] + bias;
+        if (fixed > cap) continue;
+        const uint64_t rows = (uint64_t)q->len[i] + 2 * kListRows;
+        uint64_t cols = scorer->ext ? (cap - fixed) / (uint64_t)scorer->ext : 0xFFFFFFFFull;
+        if (scorer->ext && cols < rows + 16) continue;
+        if (scorer->ext) cols -= rows + 12;              // 8 + rounding of the length to 4
+        lt_cap[i] = (uint32_t)std::min<uint64_t>(cols, 0x7FFFFFFFu);
+    }
+    // ---- the split length: histogram of cells over target length (one pass), estimate for every 64-residue cut ----
+    uint32_t lt_db = 0;
+    for (const Tile& t : db->tiles) lt_db = std::max(lt_db, t.max_len4 * 4);
+    std::vector<double> cells_le((size_t)lt_db / 64 + 2, 0.0);
+    std::vector<uint32_t> pairs_in((size_t)lt_db / 64 + 2, 0);          // eligible pairs per 64-residue bucket of target length
+    uint32_t lt_max = 0, lq_max = 0;
+    double cells_all = 0, rows_all = 0;
+    for (uint32_t pi : sel) {
+        const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi], lq = q->len[qi];
+        const double c = (double)lq * lt;
+        lt_max = std::max(lt_max, lt);
+        lq_max = std::max(lq_max, lq);
+        cells_all += c;
+        rows_all += lq;
+        if (lt == 0 || lt > lt_cap[qi]) continue;
+        cells_le[lt / 64] += c;
+        ++pairs_in[lt / 64];
+    }
+    for (size_t b = 1; b < cells_le.size(); ++b) cells_le[b] += cells_le[b - 1];
+    uint32_t best_ls = 0;
+    double best_t = lists_cost(cells_le, cells_all, lq_max, 0, lt_max);
+    const double all_waves = best_t;
+    for (uint32_t ls = 127; ls < lt_max + 64; ls += 64) {
+        const double t = lists_cost(cells_le, cells_all, lq_max, ls, lt_max);
+        if (t < best_t) { best_t = t; best_ls = ls; }
+    }
+    if (force) best_ls = forced_split ? forced_split : std::max(lt_max, 1u);      // everything the window admits (up to the caller's cut)
+    else if (best_ls == 0 || best_t > 0.9 * all_waves) return S4G_OK;       // the pair kernels take it all
+
+    // ---- one pass: which pairs go where, and per query how many list entries ----
+    static thread_local std::vector<uint32_t> list_sel, wave_sel;
+    list_sel.clear(); wave_sel.clear();
+    list_sel.reserve(sel.size());
+    std::vector<uint32_t> count(q->n + 1, 0);
+    for (uint32_t pi : sel) {
+        const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
+        if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { list_sel.push_back(pi); ++count[qi + 1]; } else wave_sel.push_back(pi);
+    }
+    if (list_sel.empty()) return S4G_OK;
+    *used = true;
+    const uint32_t n = (uint32_t)list_sel.size();
+
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    hipStream_t stream = nullptr;
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_seq_tables(db);
+    if (rc) return rc;
+    if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+    ScratchScope scope(db, stream);
+    rc = scope.acquire();
+    if (rc) return rc;
+    rc = ensure_mat(cx, scorer, stream);
+    if (rc) return rc;
+
+    // ---- the long / ineligible pairs start first, on the side stream, as pair waves ----
+    static thread_local std::vector<uint32_t> wave_where;
+    int32_t* d_wave_sc = nullptr;
+    if (!wave_sel.empty()) {
+        if (!cx->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(cx->side_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+        scope.forked = true;
+        rc = pairs_enqueue(db, q, scorer, wave_sel, pair_q, pair_t, &wave_where, &d_wave_sc, cx->side_stream);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
+    }
+    const auto t1 = now();
+
+    // ---- host: entries (key = query, length rank; value = target, local index) and the item table ----
+    // items of block k of every query come before block k + 1 of any: the longest members of every list start first
+    uint32_t n_items = 0, max_blocks = 0;
+    for (uint32_t i = 0; i < q->n; ++i) {
+        const uint32_t blocks = (count[i + 1] + 127) / 128;
+        n_items += blocks;
+        max_blocks = std::max(max_blocks, blocks);
+    }
+    for (uint32_t i = 0; i < q->n; ++i) count[i + 1] += count[i];               // segment offsets in the sorted order
+    const uint64_t b_keys = align256((uint64_t)n * 8), b_items = align256((uint64_t)n_items * sizeof(ListItem));
+    const uint64_t stage_bytes = 2 * b_keys + b_items;
+    if (cx->lst_stage_bytes < stage_bytes) {
+        if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
+        cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
+        const uint64_t want = stage_bytes + stage_bytes / 4;
+        HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, want, hipHostMallocDefault));
+        cx->lst_stage_bytes = want;
+    } else if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+    if (!cx->lst_stage_done) HIP_TRY(hipEventCreateWithFlags(&cx->lst_stage_done, hipEventDisableTiming));
+    uint64_t* h_keys = reinterpret_cast<uint64_t*>(cx->h_lst_stage);
+    uint64_t* h_vals = reinterpret_cast<uint64_t*>(cx->h_lst_stage + b_keys);
+    ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage + 2 * b_keys);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t pi = list_sel[k];
+        h_keys[k] = ((uint64_t)pair_q[pi] << 32) | db->pos_of_id[pair_t[pi]];
+        h_vals[k] = ((uint64_t)pair_t[pi] << 32) | k;
+    }
+    {
+        uint32_t at = 0;
+        for (uint32_t blk = 0; blk < max_blocks; ++blk)
+            for (uint32_t i = 0; i < q->n; ++i) {
+                const uint32_t seg = count[i + 1] - count[i];
+                if (seg <= blk * 128) continue;
+                h_items[at++] = ListItem{i, count[i] + blk * 128, std::min(128u, seg - blk * 128), 0u, 0ull};
+            }
+    }
+    int q_bits = 1;
+    while (q_bits < 32 && (1ull << q_bits) < q->n) ++q_bits;
+
+    // ---- device buffers: one grow-only allocation ----
+    size_t cub_sort = 0, cub_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint64_t*)nullptr,
+                                               (uint64_t*)nullptr, (int)n, 0, 32 + q_bits, stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n_items, stream));
+    const uint64_t b_cub = align256(std::max(cub_sort, cub_scan)), b_dw = align256((uint64_t)n_items * 8), b_sc = align256((uint64_t)n * 4);
+    const uint64_t need = 4 * b_keys + b_items + 2 * b_dw + b_sc + b_cub;
+    if (cx->lst_bytes < need) {
+        if (cx->d_lst) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst)); }
+        cx->d_lst = nullptr; cx->lst_bytes = 0;
+        const uint64_t want = need + need / 4;
+        HIP_TRY(hipMalloc((void**)&cx->d_lst, want));
+        cx->lst_bytes = want;
+    }
+    ListBuffers B;
+    char* p = cx->d_lst;
+    B.keys_in = (uint64_t*)p; p += b_keys; B.vals_in = (uint64_t*)p; p += b_keys;     // keys_in, vals_in, items: one upload
+    B.items = (ListItem*)p; p += b_items;
+    B.keys_out = (uint64_t*)p; p += b_keys; B.vals_out = (uint64_t*)p; p += b_keys;
+    B.dwords = (uint64_t*)p; p += b_dw; B.offs = (uint64_t*)p; p += b_dw;
+    B.scores = (int32_t*)p; p += b_sc;
+    B.cub = p; B.cub_bytes = b_cub;
+    HIP_TRY(hipMemcpyAsync(B.keys_in, cx->h_lst_stage, stage_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(cx->lst_stage_done, stream));
+    const auto t2 = now();
+    size_t tmp = B.cub_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(B.cub, tmp, B.keys_in, B.keys_out, B.vals_in, B.vals_out, (int)n, 0, 32 + q_bits, stream));
+    hipLaunchKernelGGL(list_item_len, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.vals_out, db->d_seq_len, B.dwords);
+    tmp = B.cub_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(B.cub, tmp, B.dwords, B.offs, (int)n_items, stream));
+    hipLaunchKernelGGL(list_item_off, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.offs);
+    HIP_TRY(hipGetLastError());
+    // the one host round trip: the size of the gathered residues and the longest item (workspace) -- item 0 .. are block 0 of
+    // every query, so the longest item is among the first q->n; read offs/dwords of the last item and all len4 of block 0
+    uint64_t tail[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&tail[0], B.offs + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&tail[1], B.dwords + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t res_dwords = tail[0] + tail[1];
+    const uint32_t max_len4 = (std::min(best_ls, lt_max) + 3) / 4;         // no member is longer than the split length
+    if (cx->lst_res_bytes < (res_dwords + kListResSlack) * 4) {
+        if (cx->d_lst_res) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst_res)); }
+        cx->d_lst_res = nullptr; cx->lst_res_bytes = 0;
+        const uint64_t want = (res_dwords + kListResSlack) * 4 * 5 / 4;
+        HIP_TRY(hipMalloc((void**)&cx->d_lst_res, want));
+        cx->lst_res_bytes = want;
+    }
+    if (cx->grid_lists == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows>, kBlock, 0));
+        cx->grid_lists = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(cx->grid_lists, (n_items + kWavesPerBlock - 1) / kWavesPerBlock));
+    const uint64_t ws_slot = 2ull * std::max(1u, max_len4) * 64 * 4;          // int32 per wave: H and F rows, 16 B per lane and chunk
+    const uint64_t ws_bytes = ws_slot * 4 * kWavesPerBlock * grid;
+    if (cx->ws_bytes < ws_bytes) {
+        if (cx->d_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_ws)); }
+        cx->d_ws = nullptr; cx->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_ws, ws_bytes));
+        cx->ws_bytes = ws_bytes;
+    }
+    hipLaunchKernelGGL(list_gather, dim3(n_items), dim3(256), 0, stream, B.items, B.vals_out, db->d_seq_addr, db->d_seq_len, cx->d_lst_res);
+    HIP_TRY(hipMemsetAsync(cx->d_counter + kListCounter, 0, 4, stream));
+    ListArgs a;
+    a.items = B.items; a.res = cx->d_lst_res; a.entries = B.vals_out;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+    a.scores = B.scores; a.ws = cx->d_ws; a.ws_slot = ws_slot; a.counter = cx->d_counter + kListCounter; a.n_items = n_items;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.floor_bits = (uint32_t)(bias | (bias << 16));
+    {   // Critical-path items run at raised wave priority (the SIMD arbitrates issue by priority, then age).  A launch of
+        // lists has only about two items per resident wave, so "large against the wave's share" would mean nearly all of
+        // them; instead: the longest items, as many as there are SIMDs to own (their count is estimated from the length
+        // histogram: 128 pairs to an item).
+        const uint64_t simds = (uint64_t)cx->prop.multiProcessorCount * 4;
+        uint64_t pairs_above = 0;
+        uint32_t lp = std::min(best_ls, lt_max) + 1;
+        for (size_t b = std::min<size_t>(pairs_in.size() - 1, std::min(best_ls, lt_max) / 64);; --b) {
+            if (pairs_above + pairs_in[b] > simds * 3 / 4 * 128) break;
+            pairs_above += pairs_in[b];
+            lp = (uint32_t)b * 64;
+            if (b == 0) break;
+        }
+        const double lq_mean = rows_all / (double)sel.size();
+        a.prio_cost = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, lq_mean * ((lp + 3) / 4)));
+    }
+    hipLaunchKernelGGL(sw_scan_lists<kListRows>, dim3(grid), dim3(kBlock), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    static thread_local std::vector<int32_t> sc;
+    sc.resize(n);
+    HIP_TRY(hipMemcpyAsync(sc.data(), B.scores, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    static thread_local std::vector<int32_t> wsc;
+    if (!wave_sel.empty()) {
+        HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
+        wsc.resize(wave_sel.size());
+        HIP_TRY(hipMemcpyAsync(wsc.data(), d_wave_sc, wave_sel.size() * 4, hipMemcpyDeviceToHost, stream));
+    }
+    const auto t3 = now();
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (uint32_t k = 0; k < n; ++k) h_scores[list_sel[k]] = sc[k];
+    for (size_t k = 0; k < wave_sel.size(); ++k) h_scores[wave_sel[k]] = wsc[wave_where[k]];
+    cx->stat_pair_items = wave_sel.size();          // s4g_scan_stats: what went to the pair waves / the list kernel
+    cx->stat_list_pairs = n;
+    if (prof) {
+        const auto t4 = now();
+        fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: plan+waves %.1f us, entries %.1f us, "
+                        "sort+tables+gather+launch %.1f us, wait+download %.1f us\n",
+                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+    }
+    return scope.release();
+}

@@ -21,6 +21,7 @@ constexpr uint64_t kBandWsBudget = 4ull << 30;  // boundary workspace of the ban
 // inter-sequence lane (which bounds a scan launch from below: one wave walks a whole (query pair, group) DP).
 constexpr double kPairChipRate = 2.5e12, kPairWaveRate = 2.4e9 / 0.7, kPairCallOverhead = 60e-6;
 constexpr double kScanChipRate = 11e12, kScanLaneRate = 2.4e9 / 37.0;
+constexpr size_t kListsMinPairs = 1u << 16;      // below this a call is latency-bound: the list route's sort / gather / round trip would show
 
 // boundary workspace of the banded kernels: one slot of `slot` columns per resident wave; the grid shrinks if the longest
 // target of the launch would push it over the budget (caller holds cx->mu)
@@ -173,18 +174,12 @@ int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sco
     return S4G_OK;
 }
 
-// Explicit list -> host scores.  sel = indices into pair_q / pair_t.
+// Explicit list -> device scores, asynchronous.  sel = indices into pair_q / pair_t.
 // Order inside a class: longest target first at 32-residue granularity (counting sort; a launch cannot end before its
 // longest pair does, so that one must not start last).
-int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
-                       const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores) {
-    DeviceGuard guard(db->device);
+int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream) {
     DeviceCtx* cx = device_ctx(db->device);
-    std::lock_guard<std::mutex> lk(cx->mu);
-    hipStream_t stream = nullptr;
-    static const bool prof = getenv("S4G_PROFILE") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto t0 = now();
     const uint32_t n = (uint32_t)sel.size();
     PairItem* items = nullptr;
     int rc = pair_stage(cx, n, &items);
@@ -204,25 +199,43 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
     uint32_t cls_begin[kScanClasses + 1];
     for (int c = 0; c <= kScanClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    where->resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t pi = sel[i];
         const uint32_t at = count[key_of(pi)]++;
         items[at] = {pair_q[pi], pair_t[pi], at};
-        h_scores[pi] = (int32_t)at;            // remember where this pair's score will sit
+        (*where)[i] = at;                      // where this pair's score will sit
     }
-    auto t1 = now();
-    int32_t* d_sc = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
-    rc = pair_submit(db, q, scorer, n, cls_begin, d_sc, stream, max_lt_band);
+    *d_sc_out = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
+    return pair_submit(db, q, scorer, n, cls_begin, *d_sc_out, stream, max_lt_band);
+}
+
+// Explicit list -> host scores (synchronous).
+int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+                       const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores) {
+    DeviceGuard guard(db->device);
+    DeviceCtx* cx = device_ctx(db->device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    hipStream_t stream = nullptr;
+    static const bool prof = getenv("S4G_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    const uint32_t n = (uint32_t)sel.size();
+    cx->stat_pair_items = n; cx->stat_list_pairs = 0;
+    static thread_local std::vector<uint32_t> where;
+    int32_t* d_sc = nullptr;
+    int rc = pairs_enqueue(db, q, scorer, sel, pair_q, pair_t, &where, &d_sc, stream);
+    if (rc) return rc;
     auto t2 = now();
     static thread_local std::vector<int32_t> sc;
     sc.resize(n);
     HIP_TRY(hipMemcpyAsync(sc.data(), d_sc, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    for (uint32_t i = 0; i < n; ++i) { const uint32_t pi = sel[i]; h_scores[pi] = sc[(uint32_t)h_scores[pi]]; }
+    for (uint32_t i = 0; i < n; ++i) h_scores[sel[i]] = sc[where[i]];
     if (prof) {
         auto t3 = now();
         auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
-        fprintf(stderr, "[s4g profile] pairs n=%u: order %.1f us, upload+launch %.1f us, wait+download %.1f us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
+        fprintf(stderr, "[s4g profile] pairs n=%u: order+upload+launch %.1f us, wait+download %.1f us\n", n, us(t0, t2), us(t2, t3));
     }
     return S4G_OK;
 }
@@ -367,38 +380,69 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
     if (!pair_q || !pair_t || !h_scores) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
     if (n_pairs >= 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "too many pairs in one call");
-    if ((flags & S4G_PAIRS_FORCE_SCAN) && (flags & S4G_PAIRS_FORCE_WAVE)) return fail(S4G_ERR_INVALID, "contradictory flags");
-    for (uint64_t i = 0; i < n_pairs; ++i)
-        if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)i);
-    // Two exact routes.  "wave": one wave per pair (sw_pair_scan; sw_pair_scan_band beyond 1024 query residues).
-    // "scan": score the pair's query against the whole resident database and pick the column.  Per query the cheaper
+    if (((flags & S4G_PAIRS_FORCE_SCAN) != 0) + ((flags & S4G_PAIRS_FORCE_WAVE) != 0) + ((flags & S4G_PAIRS_FORCE_LISTS) != 0) > 1)
+        return fail(S4G_ERR_INVALID, "contradictory flags");
+    // One pass: range checks and, per query, what the route estimate needs (cells, longest pair, pair count).
+    // Two exact routes per query.  "wave": its pairs one by one (sw_pair_scan / sw_pair_scan_band, or the packed list kernel for
+    // large batches).  "scan": score the query against the whole resident database and pick the columns.  Per query the cheaper
     // estimate wins: few candidates -> wave, candidate list ~ the whole database -> scan.
-    std::vector<std::vector<uint32_t>> by_q(q->n);
-    for (uint64_t i = 0; i < n_pairs; ++i) by_q[pair_q[i]].push_back((uint32_t)i);
-    std::vector<uint32_t> wave_sel, scan_queries;
+    std::vector<double> q_cells(q->n, 0.0);
+    std::vector<uint32_t> q_longest(q->n, 0), q_pairs(q->n, 0);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        const uint32_t qi = pair_q[i], t = pair_t[i];
+        if (qi >= q->n || t >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)i);
+        const uint32_t lt = db->len[t];
+        q_cells[qi] += lt;
+        q_longest[qi] = std::max(q_longest[qi], lt);
+        ++q_pairs[qi];
+    }
     uint32_t max_t = 0;
     for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);
+    std::vector<char> route(q->n, 0);                   // 0: no pairs / empty query, 1: wave, 2: scan
+    std::vector<uint32_t> scan_queries;
+    uint64_t n_wave = 0, n_other = 0;
     for (uint32_t qi = 0; qi < q->n; ++qi) {
-        if (by_q[qi].empty()) continue;
+        if (!q_pairs[qi]) continue;
         const uint32_t lq = q->len[qi];
-        if (lq == 0) { for (uint32_t i : by_q[qi]) h_scores[i] = 0; continue; }
+        if (lq == 0) { n_other += q_pairs[qi]; continue; }
         bool wave = true;
-        if (wave && !(flags & S4G_PAIRS_FORCE_WAVE)) {
-            double cells = 0, longest = 0;
-            for (uint32_t i : by_q[qi]) { const double c = (double)lq * db->len[pair_t[i]]; cells += c; longest = std::max(longest, c); }
+        if (!(flags & (S4G_PAIRS_FORCE_WAVE | S4G_PAIRS_FORCE_LISTS))) {
+            const double cells = (double)lq * q_cells[qi], longest = (double)lq * q_longest[qi];
             const double t_wave = std::max(cells / kPairChipRate, longest / kPairWaveRate) + kPairCallOverhead;
             const double full = (double)lq * (double)db->residues;
             const double t_scan = std::max(full / kScanChipRate, (double)lq * max_t / kScanLaneRate) + (double)db->n_seqs * 4.0 / 20e9;
             wave = t_wave <= t_scan;
         }
         if (flags & S4G_PAIRS_FORCE_SCAN) wave = false;
-        if (wave) {
-            wave_sel.insert(wave_sel.end(), by_q[qi].begin(), by_q[qi].end());
-        } else scan_queries.push_back(qi);
+        route[qi] = wave ? 1 : 2;
+        if (wave) n_wave += q_pairs[qi]; else { scan_queries.push_back(qi); n_other += q_pairs[qi]; }
     }
+    // pair indices of the wave route (all of them in the common case) and, only if some query scans, the pairs by query
+    std::vector<uint32_t> wave_sel(n_wave);
+    std::vector<std::vector<uint32_t>> by_q(scan_queries.empty() ? 0 : q->n);
+    {
+        uint64_t at = 0;
+        for (uint64_t i = 0; i < n_pairs; ++i) {
+            const uint32_t qi = pair_q[i];
+            if (route[qi] == 1) wave_sel[at++] = (uint32_t)i;
+            else if (route[qi] == 2) by_q[qi].push_back((uint32_t)i);
+            else h_scores[i] = 0;                       // empty query
+        }
+    }
+    (void)n_other;
     if (!wave_sel.empty()) {
-        int rc = score_pairs_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores);
-        if (rc) return rc;
+        // Large batches of lists (the batched wrapper: every query of a chunk with its own candidates) go to the packed list
+        // kernel, except their longest targets; small ones are latency-bound and stay with one wave per pair.
+        bool used = false;
+        if (!(flags & S4G_PAIRS_FORCE_WAVE) && ((flags & S4G_PAIRS_FORCE_LISTS) || wave_sel.size() >= kListsMinPairs)) {
+            int rc = score_lists_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores, (flags & S4G_PAIRS_FORCE_LISTS) != 0,
+                                        (flags & S4G_PAIRS_FORCE_LISTS) ? (flags >> 8) : 0u, &used);
+            if (rc) return rc;
+        }
+        if (!used) {
+            int rc = score_pairs_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores);
+            if (rc) return rc;
+        }
     }
     if (!scan_queries.empty()) {
         // consecutive runs of scan-route queries share one scan call, bounded to ~1 GiB of host scores

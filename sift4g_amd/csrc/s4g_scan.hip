@@ -321,7 +321,7 @@ static int stats_begin(DeviceCtx* cx, hipStream_t stream) {
     if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
     HIP_TRY(hipMemsetAsync(cx->d_counter + kStatRechecked, 0, 4, stream));
     for (auto& v : cx->stat_tier) v = 0;
-    cx->stat_spec_queries = cx->stat_pair_items = 0;
+    cx->stat_spec_queries = cx->stat_pair_items = cx->stat_list_pairs = 0;
     return S4G_OK;
 }
 static void stats_add(DeviceCtx* cx, const Plan& p) {
@@ -341,7 +341,7 @@ S4G_API int s4g_scan_stats(int device, uint64_t* out, uint32_t cap) {
         HIP_TRY(hipMemcpy(&rechecked, cx->d_counter + kStatRechecked, 4, hipMemcpyDeviceToHost));
     }
     for (int k = 0; k < 4; ++k) out[k] = cx->stat_tier[k];
-    out[4] = cx->stat_spec_queries; out[5] = rechecked; out[6] = cx->stat_pair_items; out[7] = 0;
+    out[4] = cx->stat_spec_queries; out[5] = rechecked; out[6] = cx->stat_pair_items; out[7] = cx->stat_list_pairs;
     return S4G_OK;
 }
 

@@ -1,0 +1,255 @@
+// sw_lists.hip.h -- candidate lists on the packed inter-sequence kernel.
+//
+// sift4g aligns every query with ITS OWN candidates only (createFilteredDatabase,
+// /root/reference/sift4g/src/database_alignment.cpp:136-162: <= 5000 ids per query, main.cpp:69), and the batched
+// wrapper hands all lists of a chunk to the device at once: ~10^6 (query, target) pairs in which two queries rarely share
+// a target.  The packed scan kernels (sw_kernels.hip.h) put two QUERIES on one target in the halves of a register, which
+// needs targets both queries want; the one-wave-per-pair kernels (sw_pair.hip.h) take any pair but spend 11 vector
+// lane-ops per cell (int32, 64 lanes on one DP) and run at the vector-issue limit doing so (profiles/r02_pair).
+//
+// Here the halves of a register carry two different TARGETS of the SAME query:
+//   * a query's candidates are sorted by length on the device and cut into items of 128: candidate 2l of an item sits in
+//     the low half of lane l, candidate 2l+1 in the high half, so both halves see nearly the same lengths;
+//   * list_gather copies the 128 targets of every item out of the resident database into a lane-transposed block of
+//     their own (dword (c*2 + half)*64 + lane = columns 4c .. 4c+3), padded to the item's longest member -- the scan then
+//     reads 2 x 256 contiguous bytes per wave and 4 columns, exactly like a database group;
+//   * sw_scan_lists is sw_scan_pkd (drifting frame, v_pk_maximum3_f16 on integer bit patterns, same exactness window)
+//     with ONE difference: the strip profile holds single 16-bit scores, a lane looks its two residues up separately
+//     (two ds_read_b128 per 8 rows, as before) and one v_perm_b32 per row pairs them up: 7.5 vector ops per pair of
+//     cells instead of 6.5.
+// Targets too long for a launch this short to wait for, and queries beyond the frame window, stay on the pair kernels
+// (the host splits, s4g_lists.hip).
+#pragma once
+#include "sw_kernels.hip.h"
+
+namespace s4g {
+
+struct ListItem {
+    uint32_t q;          // query id
+    uint32_t first;      // index of the item's first entry in the sorted entry list (entry first + 2*lane + half)
+    uint32_t n;          // entries of the item, 1 .. 128
+    uint32_t len4;       // 4-column chunks = ceil(longest member / 4)       (filled on the device: list_item_len)
+    uint64_t res_off;    // dword offset of the item's block in the gathered residues (filled on the device: exclusive scan)
+};
+
+struct ListArgs {
+    const ListItem* __restrict__ items;
+    const uint32_t* __restrict__ res;           // gathered residues
+    const uint64_t* __restrict__ entries;       // sorted entries: (target id << 32) | pair index
+    const uint8_t* __restrict__ q_codes;
+    const uint64_t* __restrict__ q_off;
+    const uint32_t* __restrict__ q_len;
+    const int8_t* __restrict__ mat;
+    int32_t* __restrict__ scores;               // [pair index]
+    int32_t* __restrict__ ws;
+    uint64_t ws_slot;
+    unsigned* counter;
+    uint32_t n_items;
+    uint32_t open, ext, floor_bits;
+    uint32_t prio_cost;
+};
+
+// items[i].len4 and the item's size in dwords (input of the exclusive scan that yields res_off)
+__global__ void list_item_len(ListItem* __restrict__ items, uint32_t n_items, const uint64_t* __restrict__ entries,
+                              const uint32_t* __restrict__ seq_len, uint64_t* __restrict__ dwords) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t t = (uint32_t)(entries[items[i].first] >> 32);        // entries are sorted longest first within a query
+    const uint32_t len4 = (seq_len[t] + 3) / 4;
+    items[i].len4 = len4;
+    dwords[i] = (uint64_t)len4 * 128;
+}
+
+__global__ void list_item_off(ListItem* __restrict__ items, uint32_t n_items, const uint64_t* __restrict__ offs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) items[i].res_off = offs[i];
+}
+
+// One block per item: out[(c*2 + half)*64 + lane] = dword c of entry first + 2*lane + half, pad (code 31) beyond a
+// member's own length and in empty slots.  Sources are lane-transposed database sequences (dword c of a sequence lives
+// 64*c dwords after its first): 128 scattered 4-byte reads per output row, served by L2 -- the pool of a chunk is a few
+// tens of MB and every sector is wanted by the 16 neighbours of its group sooner or later.
+__global__ __launch_bounds__(256) void list_gather(const ListItem* __restrict__ items, const uint64_t* __restrict__ entries,
+                                                   const uint64_t* __restrict__ seq_addr, const uint32_t* __restrict__ seq_len,
+                                                   uint32_t* __restrict__ out) {
+    const ListItem it = items[blockIdx.x];
+    const int slot = threadIdx.x & 127;               // half*64 + lane
+    const int half = slot >> 6, lane = slot & 63;
+    const uint32_t e = 2u * lane + half;
+    const uint32_t* src = nullptr;
+    uint32_t l4 = 0, lt = 0;
+    if (e < it.n) {
+        const uint32_t t = (uint32_t)(entries[it.first + e] >> 32);
+        src = reinterpret_cast<const uint32_t*>(seq_addr[t]);
+        lt = seq_len[t];
+        l4 = (lt + 3) / 4;
+    }
+    uint32_t* dst = out + it.res_off + slot;
+    for (uint32_t c = threadIdx.x >> 7; c < it.len4; c += 2) {
+        uint32_t v = 0x1F1F1F1Fu;
+        if (c < l4) v = src[(uint64_t)c * 64];      // the database pads a sequence's last dword with code 31 already
+        dst[(uint64_t)c * 128] = v;
+    }
+}
+
+// rows row0 .. row0+7 of one column for both halves: xa / xb = the 8 scores (int16 each, s + 2e) of the low / high half's residue
+template <int R>
+__device__ __forceinline__ void lst_rows8(int (&H)[R], int (&E)[R], int row0, const v4i& xa, const v4i& xb, int& diag, int& F, int& best,
+                                          int eo, int& zcur, int e2) {
+    int tprev = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + i;
+        // (high half's score << 16) | low half's score: bytes 0-3 select from the second operand, 4-7 from the first
+        const int sc = (int)__builtin_amdgcn_perm((unsigned)xb[i / 2], (unsigned)xa[i / 2], (i & 1) ? 0x07060302u : 0x05040100u);
+        const int h = pk_maximum3(as_i(as_s(diag) + as_s(sc)), E[r], F);
+        const int t = as_i(as_s(h) - as_s(zcur));
+        if (i & 1) best = pk_maximum3(best, tprev, t); else tprev = t;
+        zcur += e2;
+        const int hm = as_i(as_s(h) + as_s(eo));
+        E[r] = pk_maximum3(E[r], hm, zcur);
+        F = as_i(pk_max(as_s(F), as_s(hm)));
+        diag = H[r];
+        H[r] = h;
+    }
+}
+
+__device__ __forceinline__ v4i lst_load(const char* prof, unsigned taddr, int blk) {
+    return *reinterpret_cast<const v4i*>(prof + blk * 512 + taddr);
+}
+
+// One strip of RR rows over all columns of the item; res points at the item's block + lane (low half; high half 64 dwords on)
+template <int R, int RR, bool FIRST>
+__device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+                                          bool last, int& best, int eo, int e2, int zrow0) {
+    constexpr bool first = FIRST;
+    constexpr int NB = RR / 8;
+    int H[R];
+    int E[R];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) { H[r] = zrow0 + (r - 1) * e2; E[r] = zrow0 + r * e2; }
+    int zcol = zrow0;
+    int hdiag = zrow0 - 2 * e2;
+    uint32_t ra_n = res[0], rb_n = res[64];
+    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+    if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+    v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(prof, pk_taddr(rb_n, 0), 0);
+    for (unsigned c = 0; c < len4; ++c) {
+        const uint32_t ra = ra_n, rb = rb_n;
+        const v4i hb = hb_n, fb = fb_n;
+        const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+        ra_n = res[(uint64_t)cn * 128];
+        rb_n = res[(uint64_t)cn * 128 + 64];
+        if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+        v4i ho, fo;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const unsigned ta = pk_taddr(ra, cc), tb = pk_taddr(rb, cc);
+            const unsigned ta_next = cc < 3 ? pk_taddr(ra, cc + 1) : pk_taddr(ra_n, 0);
+            const unsigned tb_next = cc < 3 ? pk_taddr(rb, cc + 1) : pk_taddr(rb_n, 0);
+            int diag = hdiag;
+            int F = first ? zcol : fb[cc];
+            int zcur = zcol;
+            const int e2c = e2;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const v4i xa = xa_n, xb = xb_n;
+                if (b + 1 < NB) { xa_n = lst_load(prof, ta, b + 1); xb_n = lst_load(prof, tb, b + 1); }
+                else { xa_n = lst_load(prof, ta_next, 0); xb_n = lst_load(prof, tb_next, 0); }
+                lst_rows8<R>(H, E, 8 * b, xa, xb, diag, F, best, eo, zcur, e2c);
+            }
+            hdiag = first ? zcol - e2 : hb[cc];
+            zcol += e2;
+            ho[cc] = H[RR - 1];
+            fo[cc] = F;
+            asm volatile("" : "+v"(best));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
+    static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 64);         // [R/8 blocks][32 residues][8 rows x int16]
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const int e2 = (int)(a.ext | (a.ext << 16));
+    const int eo = (int)(((a.ext - a.open) & 0xFFFFu) * 0x10001u);
+    const int B2 = (int)a.floor_bits;
+    const int two_e = 2 * (int)a.ext;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= a.n_items) break;
+        const ListItem it = a.items[item];
+        const unsigned len4 = it.len4;
+        const uint32_t* res = a.res + it.res_off + lane;
+        const uint8_t* qc = a.q_codes + a.q_off[it.q];
+        const unsigned lq = a.q_len[it.q];
+        const unsigned cap = (lq + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;      // readable bytes of the query
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        int best = 0;
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            const unsigned rows_left = lq - s * R;
+            const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
+            // ---- strip profile: prof[blk][t] = 8 rows of (score + 2e) as int16 ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 4 * R; e0 += 64) {
+                const int e = e0 + lane;
+                const int blk = e >> 5, t = e & 31;
+                const unsigned row0 = s * R + 8 * blk;
+                unsigned c0 = 0x1F1F1F1Fu, c1 = 0x1F1F1F1Fu;
+                if (row0 < cap) { c0 = *reinterpret_cast<const unsigned*>(qc + row0); c1 = *reinterpret_cast<const unsigned*>(qc + row0 + 4); }
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned w = d < 2 ? c0 : c1;
+                    const int s0 = lmat[((w >> (16 * (d & 1))) & 31u) * 32 + t] + two_e;
+                    const int s1 = lmat[((w >> (16 * (d & 1) + 8)) & 31u) * 32 + t] + two_e;
+                    out[d] = (int)(((unsigned)s0 & 0xFFFFu) | ((unsigned)s1 << 16));
+                }
+                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+            const int zrow0 = B2 + (int)(s * R) * e2;
+            bool done = false;
+#define S4G_LAST_STRIP(RR_)                                                                                  \
+            if constexpr (R > RR_) {                                                                         \
+                if (!done && rr == RR_) {                                                                    \
+                    if (first) lst_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0); \
+                    else lst_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);    \
+                    done = true;                                                                             \
+                }                                                                                            \
+            }
+            S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
+#undef S4G_LAST_STRIP
+            if (!done) {
+                if (first) lst_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
+                else lst_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
+            }
+        }
+        const unsigned e_lo = 2u * lane, e_hi = 2u * lane + 1u;
+        if (e_lo < it.n) a.scores[(uint32_t)a.entries[it.first + e_lo]] = (int)as_s(best)[0];
+        if (e_hi < it.n) a.scores[(uint32_t)a.entries[it.first + e_hi]] = (int)as_s(best)[1];
+    }
+}
+
+}  // namespace s4g

@@ -190,7 +190,7 @@ def scan_stats(device=0):
     out = np.zeros(8, dtype=np.uint64)
     check(lib.s4g_scan_stats(device, _ptr(out, c_u64p), 8), "s4g_scan_stats")
     return dict(tier_drift=int(out[0]), tier_m3=int(out[1]), tier_i16=int(out[2]), tier_i32=int(out[3]),
-                speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]))
+                speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]), list_pairs=int(out[7]))
 
 
 def clock_probe(device=0):
@@ -242,13 +242,14 @@ def score_lists(db, queries, scorer, cand_offsets, cand_ids):
 
 
 def score_pairs(db, queries, scorer, pair_q, pair_t, route=None):
-    """scores of explicit (query, target) pairs; route = None (cost model) | "wave" (one wave per pair) | "scan"."""
+    """scores of explicit (query, target) pairs; route = None (cost model) | "wave" (one wave per pair) | "scan" (full scan +
+    column pick) | "lists" (candidates gathered into 128-lane groups for the packed list kernel, long targets as waves)."""
     pair_q = np.ascontiguousarray(pair_q, dtype=np.uint32)
     pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
     if pair_q.shape != pair_t.shape or pair_q.ndim != 1:
         raise ValueError("pair_q and pair_t must be 1-D arrays of the same length")
     out = np.zeros(max(len(pair_q), 1), dtype=np.int32)
-    flags = {None: 0, "wave": 1, "scan": 2}[route]
+    flags = (4 | (int(route[6:]) << 8)) if isinstance(route, str) and route.startswith("lists:") else {None: 0, "wave": 1, "scan": 2, "lists": 4}[route]
     check(lib.s4g_score_pairs_host(db._h, queries._h, scorer._h, len(pair_q), _ptr(pair_q, c_u32p), _ptr(pair_t, c_u32p),
                                    _ptr(out, c_i32p), flags), "s4g_score_pairs_host")
     return out[: len(pair_q)]

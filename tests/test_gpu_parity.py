@@ -263,6 +263,66 @@ def test_candidate_lists(s4g, oracle_mod, blosum62, scorer):
     assert np.array_equal(got, want)
 
 
+def test_candidate_lists_on_the_packed_list_kernel(s4g, oracle_mod, blosum62):
+    """route "lists" of s4g_score_pairs_host (sw_scan_lists: a query's candidates sorted by length on the device, 128 to an item,
+    two targets per register) against the oracle: list sizes around the item size (1, 127, 128, 129, 300), empty targets and an
+    empty query, all 26 codes, a 2900-residue target, queries up to 2600 residues (the frame window decides per query what may
+    go to the kernel; the rest runs as pair waves in the same call), several scorers incl. extend 0 and one whose penalties
+    leave no window at all."""
+    from sift4g_amd.device import matrix_by_name
+    rng = np.random.default_rng(91)
+    qs = rand_seqs(rng, 9, 30, 420, 26) + [np.zeros(0, dtype=np.uint8), rand_seqs(rng, 1, 2600, 2600)[0], rand_seqs(rng, 1, 1100, 1100)[0]]
+    ts = rand_seqs(rng, 700, 1, 520, 26) + [np.zeros(0, dtype=np.uint8)] * 3 + rand_seqs(rng, 6, 900, 2900, 26)
+    for k in range(60):                                            # homologs with an indel
+        src = qs[k % 9]
+        m = src.copy()
+        idx = rng.choice(len(m), size=max(1, len(m) // 6), replace=False)
+        m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]
+        cut = int(rng.integers(1, len(m)))
+        ts[k * 11] = np.concatenate([m[:cut], rand_seqs(rng, 1, 4, 4)[0], m[cut:]])
+    ts[5] = qs[10][300:2300].copy(); ts[6] = qs[11].copy()
+    sizes = [1, 127, 128, 129, 300, 64, 709, 0, 2, 5, 400, 260]
+    pq, pt = [], []
+    for i, n in enumerate(sizes):
+        cand = rng.choice(len(ts), size=n, replace=False) if n else np.zeros(0, dtype=np.int64)
+        pq += [i] * n; pt += cand.tolist()
+    pq += [10, 11, 0]; pt += [5, 6, len(ts) - 1]
+    pq, pt = np.array(pq, dtype=np.uint32), np.array(pt, dtype=np.uint32)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    for name, go, ge in (("BLOSUM_62", 10, 1), ("BLOSUM_62", 7, 0), ("PAM_30", 9, 1), ("BLOSUM_45", 14, 2), ("BLOSUM_62", 40, 25), ("BLOSUM_80", 5, 5)):
+        M = matrix_by_name(name)
+        exp = oracle_mod.pairs_flat(*oracle_mod._flat(qs), *oracle_mod._flat(ts), pq, pt, M, go, ge, threads=8)
+        sc = s4g.Scorer(name, go, ge)
+        for route in ("lists", "wave", None):
+            got = s4g.score_pairs(db, q, sc, pq, pt, route=route)
+            bad = np.nonzero(got != exp)[0]
+            assert bad.size == 0, (name, go, ge, route, len(bad), [(int(pq[b]), int(pt[b]), int(got[b]), int(exp[b])) for b in bad[:5]])
+    assert exp.max() > 100
+
+
+def test_candidate_lists_large_batch_takes_the_list_route_by_itself(s4g, scorer):
+    """the batched wrapper's shape at a third of its size: 240 000 pairs in one call, enough for the library's estimate to send the
+    lists to sw_scan_lists on its own (a launch of lists cannot end before its longest item, so small batches stay with the pair
+    waves, and so do this batch's longest targets); every score equals the full scan's."""
+    import torch
+    from sift4g_amd import synth
+    from sift4g_amd import device as s4gd
+    c = synth.make_config(2, 120, 20000)
+    db = s4g.Database(codes=c["t_codes"], offsets=c["t_off"])
+    q = s4g.QuerySet(codes=c["q_codes"], offsets=c["q_off"])
+    rng = np.random.default_rng(3)
+    pt = np.concatenate([np.sort(rng.choice(db.n, size=2000, replace=False)) for _ in range(q.n)]).astype(np.uint32)
+    pq = np.repeat(np.arange(q.n, dtype=np.uint32), 2000)
+    full = torch.empty((q.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, full, no_pairs=True)
+    want = full.cpu().numpy()[pq, pt]
+    got = s4g.score_pairs(db, q, scorer, pq, pt)
+    st = s4gd.scan_stats(0)
+    assert np.array_equal(got, want)
+    assert st["list_pairs"] > len(pq) // 2 and st["pair_items"] > 0 and st["list_pairs"] + st["pair_items"] == len(pq), st
+    assert np.array_equal(s4g.score_pairs(db, q, scorer, pq, pt, route="lists"), want)
+
+
 def test_topk_matches_sorted_oracle(s4g, oracle_mod, blosum62, scorer):
     import torch
     rng = np.random.default_rng(22)
