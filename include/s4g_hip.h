@@ -36,6 +36,8 @@
  *       createFilteredDatabase, database_alignment.cpp:136-162)
  *   s4g_traceback_host
  *       step 4 of swsharp alignDatabase: traceback of the survivors
+ *   s4g_warmup
+ *       the device initialisation swsharp does behind cudaCheckCards / its first alignDatabase call, main.cpp:186
  *   s4g_scan_stats / s4g_clock_probe / s4g_scan_plan / s4g_scan_cells
  *       measurement only (bench.py); no counterpart in the reference, which prints no throughput figures
  *   s4g_topk / s4g_topk_host / s4g_scan_topk / s4g_scan_topk_host
@@ -235,6 +237,12 @@ int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
  * speculative launches marked and the exact int32 pass recomputed, out[6] = (query, target) pairs given to the
  * one-wave-per-pair kernels, out[7] = pairs scored by the packed list kernel (s4g_score_pairs_host / s4g_score_lists_host).  cap >= 8. */
 int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
+
+/* Starts, once per device and on a thread of its own, everything a process pays before its first scan: HIP context, code
+ * objects, side stream, pinned staging.  Returns at once; calls that need the device meanwhile wait for it.  The
+ * swsharp-compatible library calls it from cudaCheckCards (/root/reference/sift4g/src/main.cpp:186), so the warm-up runs
+ * underneath sift4g's FASTA reading and prefilter (main.cpp:192-205). */
+int s4g_warmup(int device);
 
 /* Shader clock under a full vector-ALU load and the measured issue rate of packed-int16 vector instructions: what bench.py
  * prices the scan kernels' VALU-issue roofline with.  out[0] = shader clock in MHz (0 if the part's cycle counter does not

@@ -44,6 +44,13 @@ DeviceCtx* device_ctx(int device) {
     return c;
 }
 
+int warm_core_kernels(DeviceCtx* cx) {
+    (void)cx;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pack_tile, 256, 0));
+    return S4G_OK;
+}
+
 // ---------------------------------------------------------------------------
 S4G_API const char* s4g_last_error(void) { return g_err.c_str(); }
 S4G_API int s4g_abi_version(void) { return 2; }      // 2: + s4g_scan_stats, s4g_clock_probe

@@ -85,3 +85,37 @@ S4G_API int s4g_clock_probe(int device, double* out, uint32_t cap) {
     out[4] = ms;
     return S4G_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// s4g_warmup: everything a process pays once before its first scan -- the HIP context, loading the code objects, the side
+// stream and its events, the pinned staging buffers -- started on a thread of its own so that it runs UNDERNEATH the
+// caller's CPU work.  sift4g checks its cards at start-up (cudaCheckCards, /root/reference/sift4g/src/main.cpp:186) and then
+// spends a few hundred milliseconds reading FASTA files and prefiltering (main.cpp:192-205) before it aligns anything:
+// the swsharp-compatible library starts the warm-up from that check, and the alignment stage finds a warm device.
+// The thread holds the device's mutex while it works: a call that needs the device meanwhile simply waits for it.
+static std::once_flag g_warm_once[64];
+
+static void warm_device(int device) {
+    DeviceGuard guard(device);
+    DeviceCtx* cx = device_ctx(device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    if (hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (device_props(cx)) return;
+    if (!cx->d_counter && hipMalloc((void**)&cx->d_counter, 256) != hipSuccess) return;
+    if (!cx->d_mat && hipMalloc((void**)&cx->d_mat, 1024) != hipSuccess) return;
+    if (!cx->side_stream) {
+        if (hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking) != hipSuccess) return;
+        (void)hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming);
+    }
+    if (warm_core_kernels(cx) || warm_pair_kernels(cx) || warm_list_kernels(cx) || warm_scan_kernels(cx)) return;
+}
+
+S4G_API int s4g_warmup(int device) {
+    if (device < 0 || device >= 64) return fail(S4G_ERR_INVALID, "bad device %d", device);
+    const int n = device_count_raw();
+    if (n <= 0 || device >= n) return fail(S4G_ERR_NO_DEVICE, "no HIP device %d", device);
+    std::call_once(g_warm_once[device], [device] { std::thread(warm_device, device).detach(); });
+    return S4G_OK;
+}

@@ -176,6 +176,13 @@ struct DevBuf {          // scoped device allocation for the non-hot paths
     }
 };
 
+// Warm-up (s4g_warmup, s4g_diag.hip): each translation unit forces the load of its own code object by asking the runtime
+// for the occupancy of its kernels (which also fills the grid caches the first real call would compute), on cx's device.
+int warm_scan_kernels(DeviceCtx* cx);      // s4g_scan.hip
+int warm_pair_kernels(DeviceCtx* cx);      // s4g_pairs.hip
+int warm_list_kernels(DeviceCtx* cx);      // s4g_lists.hip
+int warm_core_kernels(DeviceCtx* cx);      // s4g_core.hip
+int pair_stage(DeviceCtx* cx, uint64_t n, s4g::PairItem** out);
 // s4g_scan.hip
 void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer);
 int device_props(DeviceCtx* cx);
@@ -210,7 +217,7 @@ int ensure_seq_tables(const s4g_db* db);
 int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                   const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream);
 // s4g_lists.hip
-int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used);
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);

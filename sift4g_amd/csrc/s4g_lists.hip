@@ -46,17 +46,51 @@ static double lists_cost(const std::vector<double>& cells_le, double cells_all, 
     return std::max(chip, lat_list) + (c_list > 0 ? kListFixedCost : 0.0);
 }
 
+int warm_list_kernels(DeviceCtx* cx) {
+    int rc = device_props(cx);
+    if (rc) return rc;
+    if (cx->grid_lists == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows>, kBlock, 0));
+        cx->grid_lists = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    // the device sort and scan are library templates: run them once on a handful of elements
+    DevBuf<uint64_t> buf;
+    HIP_TRY(buf.alloc(4 * 64 + 8192));
+    HIP_TRY(hipMemset(buf.p, 0, (4 * 64 + 8192) * 8));
+    size_t tmp = 8192 * 8 - 512;
+    uint64_t* p = buf.p;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p + 256, tmp, p, p + 64, p + 128, p + 192, 64, 0, 40, nullptr));
+    tmp = 8192 * 8 - 512;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(p + 256, tmp, p, p + 64, 64, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (cx->lst_stage_bytes < (16u << 20)) {                    // pinned staging for ~700k entries
+        if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
+        cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
+        HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, 16u << 20, hipHostMallocDefault));
+        cx->lst_stage_bytes = 16u << 20;
+    }
+    return S4G_OK;
+}
+
 // Scores of the pairs sel[] (indices into pair_q / pair_t; every query non-empty) into h_scores[sel[i]].
 // force: every eligible pair goes to the list kernel whatever the estimate says (tests, measurements).
 // *used = false: the estimate prefers the pair kernels for everything; nothing was done.
-int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
+int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used) {
     *used = false;
-    if (sel.empty()) return S4G_OK;
+    if (n_sel == 0) return S4G_OK;
+    // the pairs of this call: sel_idx[0 .. n_sel), or 0 .. n_sel when sel_idx is NULL (every pair of the caller's arrays)
+    struct Sel {
+        const uint32_t* idx; uint32_t n;
+        uint32_t operator[](uint32_t i) const { return idx ? idx[i] : i; }
+        uint32_t size() const { return n; }
+    } sel{sel_idx, n_sel};
     static const bool prof = getenv("S4G_PROFILE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
     const auto t0 = now();
+    double t_alloc = 0;          // S4G_PROFILE: time spent growing buffers (first call of a process)
     const bool gaps16 = scorer->open < 32768 && scorer->ext < 32768;
     if (!gaps16) return S4G_OK;
     ensure_bounds(q, scorer);
@@ -82,7 +116,8 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     std::vector<uint32_t> pairs_in((size_t)lt_db / 64 + 2, 0);          // eligible pairs per 64-residue bucket of target length
     uint32_t lt_max = 0, lq_max = 0;
     double cells_all = 0, rows_all = 0;
-    for (uint32_t pi : sel) {
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        const uint32_t pi = sel[i];
         const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi], lq = q->len[qi];
         const double c = (double)lq * lt;
         lt_max = std::max(lt_max, lt);
@@ -105,17 +140,17 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     else if (best_ls == 0 || best_t > 0.9 * all_waves) return S4G_OK;       // the pair kernels take it all
 
     // ---- one pass: which pairs go where, and per query how many list entries ----
-    static thread_local std::vector<uint32_t> list_sel, wave_sel;
-    list_sel.clear(); wave_sel.clear();
-    list_sel.reserve(sel.size());
+    static thread_local std::vector<uint32_t> wave_sel;
+    wave_sel.clear();
     std::vector<uint32_t> count(q->n + 1, 0);
-    for (uint32_t pi : sel) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        const uint32_t pi = sel[i];
         const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
-        if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { list_sel.push_back(pi); ++count[qi + 1]; } else wave_sel.push_back(pi);
+        if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { ++n; ++count[qi + 1]; } else wave_sel.push_back(pi);
     }
-    if (list_sel.empty()) return S4G_OK;
+    if (n == 0) return S4G_OK;
     *used = true;
-    const uint32_t n = (uint32_t)list_sel.size();
 
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
@@ -160,22 +195,31 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
     for (uint32_t i = 0; i < q->n; ++i) count[i + 1] += count[i];               // segment offsets in the sorted order
     const uint64_t b_keys = align256((uint64_t)n * 8), b_items = align256((uint64_t)n_items * sizeof(ListItem));
-    const uint64_t stage_bytes = 2 * b_keys + b_items;
-    if (cx->lst_stage_bytes < stage_bytes) {
+    const uint64_t stage_bytes = 2 * b_keys + b_items;          // >= the results that come back through it (4 bytes per pair of the call)
+    { const auto ta = now();
+    const uint64_t stage_need = std::max<uint64_t>(stage_bytes, ((uint64_t)n_sel + wave_sel.size()) * 4 + 256);
+    if (cx->lst_stage_bytes < stage_need) {
         if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
         cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
-        const uint64_t want = stage_bytes + stage_bytes / 4;
+        const uint64_t want = stage_need + stage_need / 4;
         HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, want, hipHostMallocDefault));
         cx->lst_stage_bytes = want;
     } else if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+    t_alloc += us(ta, now()); }
     if (!cx->lst_stage_done) HIP_TRY(hipEventCreateWithFlags(&cx->lst_stage_done, hipEventDisableTiming));
     uint64_t* h_keys = reinterpret_cast<uint64_t*>(cx->h_lst_stage);
     uint64_t* h_vals = reinterpret_cast<uint64_t*>(cx->h_lst_stage + b_keys);
     ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage + 2 * b_keys);
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t pi = list_sel[k];
-        h_keys[k] = ((uint64_t)pair_q[pi] << 32) | db->pos_of_id[pair_t[pi]];
-        h_vals[k] = ((uint64_t)pair_t[pi] << 32) | k;
+    {   // entries: key = (query, rank of the target in the database's length order), value = (target, position in sel)
+        uint32_t k = 0, w = 0;
+        const uint32_t nw = (uint32_t)wave_sel.size();
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            const uint32_t pi = sel[i];
+            if (w < nw && wave_sel[w] == pi) { ++w; continue; }       // wave_sel holds its pairs in the same order
+            h_keys[k] = ((uint64_t)pair_q[pi] << 32) | db->pos_of_id[pair_t[pi]];
+            h_vals[k] = ((uint64_t)pair_t[pi] << 32) | i;
+            ++k;
+        }
     }
     {
         uint32_t at = 0;
@@ -194,8 +238,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint64_t*)nullptr,
                                                (uint64_t*)nullptr, (int)n, 0, 32 + q_bits, stream));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n_items, stream));
-    const uint64_t b_cub = align256(std::max(cub_sort, cub_scan)), b_dw = align256((uint64_t)n_items * 8), b_sc = align256((uint64_t)n * 4);
+    const uint64_t b_cub = align256(std::max(cub_sort, cub_scan)), b_dw = align256((uint64_t)n_items * 8), b_sc = align256((uint64_t)n_sel * 4);
     const uint64_t need = 4 * b_keys + b_items + 2 * b_dw + b_sc + b_cub;
+    { const auto ta = now();
     if (cx->lst_bytes < need) {
         if (cx->d_lst) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst)); }
         cx->d_lst = nullptr; cx->lst_bytes = 0;
@@ -203,6 +248,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
         HIP_TRY(hipMalloc((void**)&cx->d_lst, want));
         cx->lst_bytes = want;
     }
+    t_alloc += us(ta, now()); }
     ListBuffers B;
     char* p = cx->d_lst;
     B.keys_in = (uint64_t*)p; p += b_keys; B.vals_in = (uint64_t*)p; p += b_keys;     // keys_in, vals_in, items: one upload
@@ -229,6 +275,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     HIP_TRY(hipStreamSynchronize(stream));
     const uint64_t res_dwords = tail[0] + tail[1];
     const uint32_t max_len4 = (std::min(best_ls, lt_max) + 3) / 4;         // no member is longer than the split length
+    const auto ta2 = now();
     if (cx->lst_res_bytes < (res_dwords + kListResSlack) * 4) {
         if (cx->d_lst_res) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst_res)); }
         cx->d_lst_res = nullptr; cx->lst_res_bytes = 0;
@@ -241,15 +288,16 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows>, kBlock, 0));
         cx->grid_lists = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
     }
-    const uint32_t grid = std::max(1u, std::min(cx->grid_lists, (n_items + kWavesPerBlock - 1) / kWavesPerBlock));
-    const uint64_t ws_slot = 2ull * std::max(1u, max_len4) * 64 * 4;          // int32 per wave: H and F rows, 16 B per lane and chunk
-    const uint64_t ws_bytes = ws_slot * 4 * kWavesPerBlock * grid;
+    const uint32_t grid = std::max(1u, std::min(cx->grid_lists, n_items));         // a block works on one item at a time (4 in flight)
+    const uint64_t ws_slot = 2ull * std::max(1u, max_len4) * 64 * 4;          // int32 per buffer: H and F rows, 16 B per lane and chunk
+    const uint64_t ws_bytes = ws_slot * 4 * kListBufs * grid;
     if (cx->ws_bytes < ws_bytes) {
         if (cx->d_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_ws)); }
         cx->d_ws = nullptr; cx->ws_bytes = 0;
         HIP_TRY(hipMalloc((void**)&cx->d_ws, ws_bytes));
         cx->ws_bytes = ws_bytes;
     }
+    t_alloc += us(ta2, now());
     hipLaunchKernelGGL(list_gather, dim3(n_items), dim3(256), 0, stream, B.items, B.vals_out, db->d_seq_addr, db->d_seq_len, cx->d_lst_res);
     HIP_TRY(hipMemsetAsync(cx->d_counter + kListCounter, 0, 4, stream));
     ListArgs a;
@@ -270,31 +318,33 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
             lp = (uint32_t)b * 64;
             if (b == 0) break;
         }
-        const double lq_mean = rows_all / (double)sel.size();
+        const double lq_mean = rows_all / (double)n_sel;
         a.prio_cost = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, lq_mean * ((lp + 3) / 4)));
     }
     hipLaunchKernelGGL(sw_scan_lists<kListRows>, dim3(grid), dim3(kBlock), 0, stream, a);
     HIP_TRY(hipGetLastError());
-    static thread_local std::vector<int32_t> sc;
-    sc.resize(n);
-    HIP_TRY(hipMemcpyAsync(sc.data(), B.scores, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-    static thread_local std::vector<int32_t> wsc;
+    // results come back into the pinned staging buffer (its upload has long completed): a download into pageable memory makes
+    // the runtime pin the destination first, which costs milliseconds the first time a process does it
+    HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+    int32_t* sc = reinterpret_cast<int32_t*>(cx->h_lst_stage);        // [n_sel]: by position in sel (entries of wave pairs stay unwritten)
+    int32_t* wsc = sc + n_sel;
+    HIP_TRY(hipMemcpyAsync(sc, B.scores, (size_t)n_sel * 4, hipMemcpyDeviceToHost, stream));
     if (!wave_sel.empty()) {
         HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
-        wsc.resize(wave_sel.size());
-        HIP_TRY(hipMemcpyAsync(wsc.data(), d_wave_sc, wave_sel.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(wsc, d_wave_sc, wave_sel.size() * 4, hipMemcpyDeviceToHost, stream));
     }
     const auto t3 = now();
     HIP_TRY(hipStreamSynchronize(stream));
-    for (uint32_t k = 0; k < n; ++k) h_scores[list_sel[k]] = sc[k];
+    if (!sel_idx) memcpy(h_scores, sc, (size_t)n_sel * 4);
+    else for (uint32_t i = 0; i < n_sel; ++i) h_scores[sel_idx[i]] = sc[i];
     for (size_t k = 0; k < wave_sel.size(); ++k) h_scores[wave_sel[k]] = wsc[wave_where[k]];
     cx->stat_pair_items = wave_sel.size();          // s4g_scan_stats: what went to the pair waves / the list kernel
     cx->stat_list_pairs = n;
     if (prof) {
         const auto t4 = now();
         fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: plan+waves %.1f us, entries %.1f us, "
-                        "sort+tables+gather+launch %.1f us, wait+download %.1f us\n",
-                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+                        "sort+tables+gather+scan %.1f us, wait+download %.1f us; of which growing buffers %.1f us (ws %.0f MB, residues %.0f MB)\n",
+                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), t_alloc, ws_bytes / 1e6, res_dwords * 4 / 1e6);
     }
     return scope.release();
 }

@@ -51,6 +51,26 @@ int launch_pairs(DeviceCtx* cx, PairArgs a, uint32_t* grid_cache, hipStream_t st
     return S4G_OK;
 }
 
+int warm_pair_kernels(DeviceCtx* cx) {
+    int rc = device_props(cx);
+    if (rc) return rc;
+    auto occ = [&](const void* k, uint32_t* cache) -> int {
+        if (*cache) return S4G_OK;
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64, 0));
+        *cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+        return S4G_OK;
+    };
+    // the classes a 300-400 residue query uses for scores and traceback (the others load with the same code object)
+    rc = occ((const void*)sw_pair_scan<6>, &cx->grid_pair[2]);
+    if (!rc) rc = occ((const void*)sw_pair_scan<8>, &cx->grid_pair[3]);
+    if (!rc) rc = occ((const void*)sw_pair_trace<6>, &cx->grid_pair_trace[2]);
+    if (!rc) rc = occ((const void*)sw_pair_trace<8>, &cx->grid_pair_trace[3]);
+    PairItem* items = nullptr;
+    if (!rc) rc = pair_stage(cx, 1u << 16, &items);           // pinned staging + device items: a pinned allocation costs milliseconds
+    return rc;
+}
+
 // device tables indexed by original target id (caller holds cx->mu)
 int ensure_seq_tables(const s4g_db* db) {
     if (db->d_seq_addr || db->n_seqs == 0) return S4G_OK;
@@ -227,9 +247,11 @@ int score_pairs_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     int rc = pairs_enqueue(db, q, scorer, sel, pair_q, pair_t, &where, &d_sc, stream);
     if (rc) return rc;
     auto t2 = now();
-    static thread_local std::vector<int32_t> sc;
-    sc.resize(n);
-    HIP_TRY(hipMemcpyAsync(sc.data(), d_sc, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    // the scores come back into the pinned item staging (12 bytes per pair, its upload is complete by then): a download into
+    // pageable memory would have the runtime pin the destination first
+    HIP_TRY(hipEventSynchronize(cx->items_done));
+    int32_t* sc = reinterpret_cast<int32_t*>(cx->h_items);
+    HIP_TRY(hipMemcpyAsync(sc, d_sc, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     for (uint32_t i = 0; i < n; ++i) h_scores[sel[i]] = sc[where[i]];
     if (prof) {
@@ -417,10 +439,12 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
         route[qi] = wave ? 1 : 2;
         if (wave) n_wave += q_pairs[qi]; else { scan_queries.push_back(qi); n_other += q_pairs[qi]; }
     }
-    // pair indices of the wave route (all of them in the common case) and, only if some query scans, the pairs by query
-    std::vector<uint32_t> wave_sel(n_wave);
+    // pair indices of the wave route -- not materialised when that is every pair of the call (the common case) -- and, only if
+    // some query scans, the pairs by query
+    const bool all_wave = n_wave == n_pairs;
+    std::vector<uint32_t> wave_sel(all_wave ? 0 : n_wave);
     std::vector<std::vector<uint32_t>> by_q(scan_queries.empty() ? 0 : q->n);
-    {
+    if (!all_wave) {
         uint64_t at = 0;
         for (uint64_t i = 0; i < n_pairs; ++i) {
             const uint32_t qi = pair_q[i];
@@ -430,16 +454,17 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
         }
     }
     (void)n_other;
-    if (!wave_sel.empty()) {
+    if (n_wave) {
         // Large batches of lists (the batched wrapper: every query of a chunk with its own candidates) go to the packed list
         // kernel, except their longest targets; small ones are latency-bound and stay with one wave per pair.
         bool used = false;
-        if (!(flags & S4G_PAIRS_FORCE_WAVE) && ((flags & S4G_PAIRS_FORCE_LISTS) || wave_sel.size() >= kListsMinPairs)) {
-            int rc = score_lists_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores, (flags & S4G_PAIRS_FORCE_LISTS) != 0,
-                                        (flags & S4G_PAIRS_FORCE_LISTS) ? (flags >> 8) : 0u, &used);
+        if (!(flags & S4G_PAIRS_FORCE_WAVE) && ((flags & S4G_PAIRS_FORCE_LISTS) || n_wave >= kListsMinPairs)) {
+            int rc = score_lists_device(db, q, scorer, all_wave ? nullptr : wave_sel.data(), (uint32_t)n_wave, pair_q, pair_t, h_scores,
+                                        (flags & S4G_PAIRS_FORCE_LISTS) != 0, (flags & S4G_PAIRS_FORCE_LISTS) ? (flags >> 8) : 0u, &used);
             if (rc) return rc;
         }
         if (!used) {
+            if (all_wave) { wave_sel.resize(n_wave); std::iota(wave_sel.begin(), wave_sel.end(), 0u); }
             int rc = score_pairs_device(db, q, scorer, wave_sel, pair_q, pair_t, h_scores);
             if (rc) return rc;
         }

@@ -62,6 +62,16 @@ int grid_for(const s4g_db* db, const void* kernel, uint32_t* cache) {
     return S4G_OK;
 }
 
+int warm_scan_kernels(DeviceCtx* cx) {
+    s4g_db probe;
+    probe.device = cx->device;
+    int rc = grid_for(&probe, (const void*)sw_scan_i32<kStripRows>, &cx->grid_i32);
+    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &cx->grid_i16);
+    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &cx->grid_f16);
+    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
+    return rc;
+}
+
 inline uint64_t ws_slot_elems(const Tile& t) { return 2ull * (t.max_len4 ? t.max_len4 : 1) * 64 * 4; }   // int32 per wave slot
 
 // grid of a tile launch: the full persistent grid unless the tile's sequences are so long that the per-wave

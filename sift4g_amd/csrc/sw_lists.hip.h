@@ -118,10 +118,48 @@ __device__ __forceinline__ v4i lst_load(const char* prof, unsigned taddr, int bl
     return *reinterpret_cast<const v4i*>(prof + blk * 512 + taddr);
 }
 
-// One strip of RR rows over all columns of the item; res points at the item's block + lane (low half; high half 64 dwords on)
+// ---- the four waves of a block work on ONE item at a time, strip by strip, as a pipeline ----
+// A launch of lists has about two items per resident wave and cannot end before its longest item, so an item walked by
+// one wave (11 strips x 1000 columns, one dependent packed op every ~8 clocks) sets the time of the whole call.  Instead
+// the block takes items from the queue one after the other and deals their strips out round-robin: strip g of the block's
+// stream goes to wave g % 4.  Strip s reads the boundary row strip s-1 leaves in the workspace, so the wave that owns it
+// trails its predecessor by a chunk of 4 columns: the predecessor publishes how many chunks it has finished in an LDS word
+// (tag = its strip number, count), the follower waits on that word before it prefetches a boundary chunk.  Both waves
+// sit on the same CU, whose L1 they share, so the boundary needs no more than workgroup-scope ordering: stores complete
+// (s_waitcnt) before the count is published, and the loads are issued after the count was read.  Per-item latency drops
+// to its strips / 4, the queue hands out 4x larger units to 4x fewer takers, and no wave ever idles at an item's end:
+// the stream continues into the next item (whose first strip depends on nothing).
+constexpr int kListRing = 16;            // fetched items a block keeps in LDS
+#ifndef S4G_LIST_PUBLISH_EVERY
+#define S4G_LIST_PUBLISH_EVERY 1
+#endif
+constexpr unsigned kListPublishEvery = S4G_LIST_PUBLISH_EVERY;     // chunks between two publications of a strip's progress (power of 2)
+constexpr int kListBufs = 4;             // workspace buffers (and best-score rows) per block: item k uses buffer k % 4; a wave may
+                                         // run at most 3 items ahead of the slowest wave of its block
+
+struct ListSync {
+    unsigned long long prog[kWavesPerBlock];   // (strip number + 1) << 32 | chunks finished, per wave
+    unsigned cur[kWavesPerBlock];              // item (position in the block's stream) a wave is working on
+    unsigned fetched;                          // items in the ring
+    unsigned lock;
+    ListItem ring[kListRing];
+    int best[kListBufs][128];                  // running maximum of an item: [lane * 2 + half]
+};
+
+__device__ __forceinline__ unsigned long long lds_load64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned lds_load32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One strip of RR rows over all columns of the item; res points at the item's block + lane (low half; high half 64 dwords on).
+// prod: progress word of the wave that owns the strip above (FIRST: unused), need_tag = that strip's tag; mine / my_tag: this wave's.
 template <int R, int RR, bool FIRST>
 __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
-                                          bool last, int& best, int eo, int e2, int zrow0) {
+                                          bool last, int& best, int eo, int e2, int zrow0,
+                                          const unsigned long long* prod, unsigned long long need_tag,
+                                          unsigned long long* mine, unsigned long long my_tag) {
     constexpr bool first = FIRST;
     constexpr int NB = RR / 8;
     int H[R];
@@ -130,9 +168,20 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
     for (int r = 0; r < RR; ++r) { H[r] = zrow0 + (r - 1) * e2; E[r] = zrow0 + r * e2; }
     int zcol = zrow0;
     int hdiag = zrow0 - 2 * e2;
+    unsigned avail = 0;                  // boundary chunks the strip above is known to have finished
+    auto wait_for = [&](unsigned chunks) {
+        if constexpr (!first) {
+            while (avail < chunks) {
+                const unsigned long long v = lds_load64(prod);
+                const unsigned a = (v >> 32) > need_tag ? 0xFFFFFFFFu : ((v >> 32) == need_tag ? (unsigned)v : 0u);
+                avail = (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+                if (avail < chunks) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    };
     uint32_t ra_n = res[0], rb_n = res[64];
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
-    if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+    if (!first && len4) { wait_for(1); hb_n = wsH[lane]; fb_n = wsF[lane]; }
     v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(prof, pk_taddr(rb_n, 0), 0);
     for (unsigned c = 0; c < len4; ++c) {
         const uint32_t ra = ra_n, rb = rb_n;
@@ -140,7 +189,7 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
         const unsigned cn = (c + 1 < len4) ? c + 1 : c;
         ra_n = res[(uint64_t)cn * 128];
         rb_n = res[(uint64_t)cn * 128 + 64];
-        if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+        if (!first) { wait_for(cn + 1); hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
         v4i ho, fo;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
@@ -165,7 +214,14 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
             asm volatile("" : "+v"(best));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+        if (!last) {
+            wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo;
+            if (c + 1 < len4 && (c & (kListPublishEvery - 1)) == kListPublishEvery - 1) {
+                // (the last chunk is published by the caller, after the strip's maximum has been merged)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(mine, (my_tag << 32) | (c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
 }
 
@@ -173,83 +229,155 @@ template <int R>
 __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
     __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 64];
+    __shared__ ListSync sy;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     signed char* lmat = reinterpret_cast<signed char*>(lds);
     char* prof = lds + 1024 + wave * (R * 64);         // [R/8 blocks][32 residues][8 rows x int16]
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    for (int i = threadIdx.x; i < kListBufs * 128; i += kBlock) (&sy.best[0][0])[i] = 0;
+    if (threadIdx.x < kWavesPerBlock) { sy.prog[threadIdx.x] = 0; sy.cur[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { sy.fetched = 0; sy.lock = 0; }
     __syncthreads();
 
-    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
-    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    v4i* const ws_block = reinterpret_cast<v4i*>(a.ws + (uint64_t)blockIdx.x * kListBufs * a.ws_slot);
     const int e2 = (int)(a.ext | (a.ext << 16));
     const int eo = (int)(((a.ext - a.open) & 0xFFFFu) * 0x10001u);
     const int B2 = (int)a.floor_bits;
     const int two_e = 2 * (int)a.ext;
+    const int prev_wave = (wave + kWavesPerBlock - 1) % kWavesPerBlock;
 
-    for (;;) {
-        unsigned item = 0;
-        if (lane == 0) item = atomicAdd(a.counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= a.n_items) break;
-        const ListItem it = a.items[item];
+    // item k of this block's stream (fetched from the global queue by whichever wave needs it first); n == 0: end of the queue
+    auto get_item = [&](unsigned k) -> ListItem {
+        for (;;) {
+            if (k < lds_load32(&sy.fetched)) break;
+            unsigned got = 0;
+            if (lane == 0) got = atomicCAS(&sy.lock, 0u, 1u) == 0u ? 1u : 0u;
+            got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+            if (got) {
+                const unsigned f = lds_load32(&sy.fetched);
+                if (k >= f) {
+                    if (lane == 0) {
+                        const unsigned idx = atomicAdd(a.counter, 1u);
+                        ListItem it;
+                        if (idx < a.n_items) it = a.items[idx]; else { it.q = 0; it.first = 0; it.n = 0; it.len4 = 0; it.res_off = 0; }
+                        sy.ring[f % kListRing] = it;
+                        __hip_atomic_store(&sy.fetched, f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (lane == 0) __hip_atomic_store(&sy.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else __builtin_amdgcn_s_sleep(1);
+        }
+        ListItem it = sy.ring[k % kListRing];
+        it.q = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.q);
+        it.first = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.first);
+        it.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.n);
+        it.len4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.len4);
+        it.res_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(it.res_off >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it.res_off);
+        return it;
+    };
+
+    unsigned k = 0, base = 0;                      // the item strip g falls into, and that item's first strip number
+    ListItem it = get_item(0);
+    unsigned lq = it.n ? a.q_len[it.q] : 0u;
+    unsigned nstrips = (lq + R - 1) / R;
+    for (unsigned g = (unsigned)wave;; g += kWavesPerBlock) {
+        while (it.n && g >= base + nstrips) {
+            base += nstrips;
+            ++k;
+            it = get_item(k);
+            lq = it.n ? a.q_len[it.q] : 0u;
+            nstrips = (lq + R - 1) / R;
+        }
+        if (!it.n) break;
+        const unsigned s = g - base;
+        // workspace buffer and best row k % 4 were last used by item k - 4: wait until no wave of the block is still there
+        if (lane == 0) __hip_atomic_store(&sy.cur[wave], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k >= kListBufs - 1) {
+            for (int w = 0; w < kWavesPerBlock; ++w)
+                while (lds_load32(&sy.cur[w]) + (kListBufs - 1) < k) __builtin_amdgcn_s_sleep(1);
+        }
+        const unsigned buf = k % kListBufs;
         const unsigned len4 = it.len4;
+        v4i* wsH = ws_block + (uint64_t)buf * (a.ws_slot / 4);
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
         const uint32_t* res = a.res + it.res_off + lane;
         const uint8_t* qc = a.q_codes + a.q_off[it.q];
-        const unsigned lq = a.q_len[it.q];
         const unsigned cap = (lq + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;      // readable bytes of the query
-        const unsigned nstrips = (lq + R - 1) / R;
-        v4i* wsF = wsH + (uint64_t)len4 * 64;
         if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-        int best = 0;
+        const unsigned long long my_tag = (unsigned long long)g + 1;          // tags start at 1: the initial word 0 matches no strip
+        if (lane == 0) __hip_atomic_store(&sy.prog[wave], my_tag << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 
-        for (unsigned s = 0; s < nstrips; ++s) {
-            const unsigned rows_left = lq - s * R;
-            const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
-            // ---- strip profile: prof[blk][t] = 8 rows of (score + 2e) as int16 ----
-            __builtin_amdgcn_wave_barrier();
+        const unsigned rows_left = lq - s * R;
+        const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
+        // ---- strip profile: prof[blk][t] = 8 rows of (score + 2e) as int16 ----
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e0 = 0; e0 < 4 * R; e0 += 64) {
-                const int e = e0 + lane;
-                const int blk = e >> 5, t = e & 31;
-                const unsigned row0 = s * R + 8 * blk;
-                unsigned c0 = 0x1F1F1F1Fu, c1 = 0x1F1F1F1Fu;
-                if (row0 < cap) { c0 = *reinterpret_cast<const unsigned*>(qc + row0); c1 = *reinterpret_cast<const unsigned*>(qc + row0 + 4); }
-                v4i out;
+        for (int e0 = 0; e0 < 4 * R; e0 += 64) {
+            const int e = e0 + lane;
+            const int blk = e >> 5, t = e & 31;
+            const unsigned row0 = s * R + 8 * blk;
+            unsigned c0 = 0x1F1F1F1Fu, c1 = 0x1F1F1F1Fu;
+            if (row0 < cap) { c0 = *reinterpret_cast<const unsigned*>(qc + row0); c1 = *reinterpret_cast<const unsigned*>(qc + row0 + 4); }
+            v4i out;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned w = d < 2 ? c0 : c1;
-                    const int s0 = lmat[((w >> (16 * (d & 1))) & 31u) * 32 + t] + two_e;
-                    const int s1 = lmat[((w >> (16 * (d & 1) + 8)) & 31u) * 32 + t] + two_e;
-                    out[d] = (int)(((unsigned)s0 & 0xFFFFu) | ((unsigned)s1 << 16));
-                }
-                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            for (int d = 0; d < 4; ++d) {
+                const unsigned w = d < 2 ? c0 : c1;
+                const int s0 = lmat[((w >> (16 * (d & 1))) & 31u) * 32 + t] + two_e;
+                const int s1 = lmat[((w >> (16 * (d & 1) + 8)) & 31u) * 32 + t] + two_e;
+                out[d] = (int)(((unsigned)s0 & 0xFFFFu) | ((unsigned)s1 << 16));
             }
-            __builtin_amdgcn_wave_barrier();
-
-            const bool first = (s == 0), last = (s + 1 == nstrips);
-            const int zrow0 = B2 + (int)(s * R) * e2;
-            bool done = false;
-#define S4G_LAST_STRIP(RR_)                                                                                  \
-            if constexpr (R > RR_) {                                                                         \
-                if (!done && rr == RR_) {                                                                    \
-                    if (first) lst_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0); \
-                    else lst_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);    \
-                    done = true;                                                                             \
-                }                                                                                            \
-            }
-            S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
-#undef S4G_LAST_STRIP
-            if (!done) {
-                if (first) lst_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
-                else lst_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0);
-            }
+            *reinterpret_cast<v4i*>(prof + e * 16) = out;
         }
-        const unsigned e_lo = 2u * lane, e_hi = 2u * lane + 1u;
-        if (e_lo < it.n) a.scores[(uint32_t)a.entries[it.first + e_lo]] = (int)as_s(best)[0];
-        if (e_hi < it.n) a.scores[(uint32_t)a.entries[it.first + e_hi]] = (int)as_s(best)[1];
+        __builtin_amdgcn_wave_barrier();
+
+        const bool first = (s == 0), last = (s + 1 == nstrips);
+        const int zrow0 = B2 + (int)(s * R) * e2;
+        int best = 0;
+        const unsigned long long* prod = &sy.prog[prev_wave];
+        unsigned long long* mine = &sy.prog[wave];
+        const unsigned long long need_tag = (unsigned long long)g;            // tag of strip g - 1
+        bool done = false;
+#define S4G_LAST_STRIP(RR_)                                                                                  \
+        if constexpr (R > RR_) {                                                                             \
+            if (!done && rr == RR_) {                                                                        \
+                if (first) lst_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag); \
+                else lst_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);    \
+                done = true;                                                                                 \
+            }                                                                                                \
+        }
+        S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
+#undef S4G_LAST_STRIP
+        if (!done) {
+            if (first) lst_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
+            else lst_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
+        }
+        // merge this strip's maximum into the item's, THEN publish the strip as finished: the wave that ends the item's last strip
+        // has seen every strip above finished (each waited for its predecessor's last chunk), so the row is complete for it
+        if (!(first && last)) {
+            atomicMax(&sy.best[buf][2 * lane], (int)as_s(best)[0]);
+            atomicMax(&sy.best[buf][2 * lane + 1], (int)as_s(best)[1]);
+        }
+        if (!last) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(mine, (my_tag << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            int lo = (int)as_s(best)[0], hi = (int)as_s(best)[1];
+            if (!first) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                lo = __hip_atomic_load(&sy.best[buf][2 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                hi = __hip_atomic_load(&sy.best[buf][2 * lane + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                sy.best[buf][2 * lane] = 0;
+                sy.best[buf][2 * lane + 1] = 0;
+            }
+            const unsigned e_lo = 2u * lane, e_hi = 2u * lane + 1u;
+            if (e_lo < it.n) a.scores[(uint32_t)a.entries[it.first + e_lo]] = lo;
+            if (e_hi < it.n) a.scores[(uint32_t)a.entries[it.first + e_hi]] = hi;
+        }
     }
+    if (lane == 0) __hip_atomic_store(&sy.cur[wave], 0xFFFFFFF0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace s4g

@@ -293,7 +293,16 @@ SW_API void cudaGetCards(int** cards, int* cardsLen) {
     *cardsLen = n;
 }
 
-SW_API int cudaCheckCards(int* cards, int cardsLen) { return s4g_device_check(cards, cardsLen); }
+// sift4g calls this once at start-up (main.cpp:186), a few hundred milliseconds of FASTA reading and prefiltering before it
+// aligns anything: the cards it names (card 0 when it names none) start warming up underneath that work (s4g_warmup).
+SW_API int cudaCheckCards(int* cards, int cardsLen) {
+    const int ok = s4g_device_check(cards, cardsLen);
+    if (ok) {
+        if (cardsLen <= 0) (void)s4g_warmup(0);
+        for (int i = 0; i < cardsLen; ++i) (void)s4g_warmup(cards[i]);
+    }
+    return ok;
+}
 
 // ------------------------------------------------------------------------------------------------ thread pool
 struct ThreadPoolTask {

@@ -32,6 +32,7 @@ static thread_local std::string g_err;
 static int fail(int code, const char* msg) { g_err = msg; return code; }
 
 API const char* s4g_last_error(void) { return g_err.c_str(); }
+API int s4g_warmup(int) { return S4G_OK; }   // nothing to warm
 API int s4g_is_shim(void) { return 1; }     // the mark sift4g_amd/_lib.py refuses: this file can never be loaded as the product library
 API int s4g_device_count(int* count) { if (count) *count = 1; return S4G_OK; }      // one pretend card
 API int s4g_device_check(const int* cards, int n) {
