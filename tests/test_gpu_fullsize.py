@@ -1,0 +1,183 @@
+"""BASELINE.json configs at their FULL sizes on one MI355X: what the oracle cannot visit (10^13 .. 10^14 cells) is checked through
+size-independent properties, the oracle on samples, and independent implementations of the same result.
+
+  configs[1]  1000 queries x 100 000 targets   -- every score of the matrix (properties), exact top-400 lists, oracle samples
+  configs[2]  1000 queries x 570 000 targets   -- the Swiss-Prot-scale scan bench.py strong-scales at N > 1
+  configs[3]  one GPU's share of the UniRef90-scale database: 20 M targets (6.8e9 residues, beyond 2^32) generated on the
+              device, streaming scan + running top-400
+  configs[4]  64 queries of 2000-5000 residues x 100 000 targets (speculative drift tier + recheck)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s4g():
+    import sift4g_amd
+    assert sift4g_amd.device_count() >= 1
+    return sift4g_amd
+
+
+def _properties(got, q_len, t_len, planted, scorer_max=11):
+    """score matrix `got` (torch int32 on the device, [q, n]): bounds and planted homologs"""
+    assert int(got.min()) >= 0
+    ql = torch.from_numpy(np.asarray(q_len, dtype=np.int64)).cuda()[:, None]
+    tl = torch.from_numpy(np.asarray(t_len, dtype=np.int64)).cuda()[None, :]
+    assert bool((got.long() <= scorer_max * torch.minimum(ql, tl)).all())          # a local alignment has at most min(Lq, Lt) columns
+    pa = torch.tensor([a for a, _ in planted], device="cuda")
+    pb = torch.tensor([b for _, b in planted], device="cuda")
+    hom = got[pa, pb].float()
+    bg = torch.quantile(got[:64].float().flatten()[:16_000_000], 0.999)
+    assert float((hom > bg).float().mean()) > 0.95                                   # planted homologs stand out from the background
+
+
+def _oracle_sample(oracle_mod, cfg, got, n_random, planted, seed):
+    rng = np.random.default_rng(seed)
+    nq, nt = got.shape
+    pq = np.concatenate([rng.integers(0, nq, n_random), [a for a, _ in planted]]).astype(np.uint32)
+    pt = np.concatenate([rng.integers(0, nt, n_random), [b for _, b in planted]]).astype(np.uint32)
+    exp = oracle_mod.pairs_flat(cfg["q_codes"], cfg["q_off"], cfg["t_codes"], cfg["t_off"], pq, pt, oracle_mod.blosum62(), 10, 1,
+                                threads=os.cpu_count() or 8)
+    have = got[torch.from_numpy(pq.astype(np.int64)).cuda(), torch.from_numpy(pt.astype(np.int64)).cuda()].cpu().numpy()
+    assert np.array_equal(have, exp)
+
+
+def test_configs1_all_1000_queries(s4g, oracle_mod):
+    """BASELINE configs[1] as bench.py runs it: all 1000 queries x 100 000 targets (1.2e13 cells).  Properties over the WHOLE matrix,
+    idempotence, the int32 kernel on a query range against the packed tier, the oracle on 4000 random and 400 planted pairs, and
+    for 16 queries the exact top-400 list against the oracle's own scan of the whole database."""
+    from sift4g_amd import synth
+    cfg = synth.make_config(2, n_queries=1000, n_targets=100000)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    got = torch.empty((q.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, got)
+    _properties(got, q.lengths, db.lengths, cfg["planted"][::25])
+    again = torch.empty_like(got)
+    s4g.scan(db, q, scorer, again)
+    assert torch.equal(got, again)                                                   # idempotent, bit for bit
+    del again
+    part = torch.empty((48, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, part, q_begin=500, q_count=48, force_i32=True)           # north_star's int32 scores: the same numbers
+    assert torch.equal(part, got[500:548])
+    _oracle_sample(oracle_mod, cfg, got, 4000, cfg["planted"][:400], 23)
+    # exact top-400 of 16 queries against the oracle's scan of the whole database (AVX2 port where the CPU has it: it is itself
+    # pinned to the scalar oracle by tests/test_oracle.py)
+    qs = list(range(0, 1000, 64))[:16]
+    ids, sc, cnt = s4g.topk(db, got, 400, 1)
+    sub_off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    sub_off[1:] = np.cumsum(q.lengths[qs]).astype(np.uint64)
+    sub_codes = np.concatenate([cfg["q_codes"][int(cfg["q_off"][i]):int(cfg["q_off"][i + 1])] for i in qs])
+    scan = oracle_mod.scan_simd_flat if oracle_mod.simd_available() else oracle_mod.scan_flat
+    full = scan(np.ascontiguousarray(sub_codes), sub_off, cfg["t_codes"], cfg["t_off"], oracle_mod.blosum62(), 10, 1, os.cpu_count() or 8)
+    for row, i in enumerate(qs):
+        order = np.lexsort((np.arange(db.n), -full[row].astype(np.int64)))[:400]
+        assert cnt[i] == 400 and ids[i].astype(np.int64).tolist() == order.tolist(), i
+        assert sc[i].tolist() == full[row][order].tolist(), i
+
+
+def test_configs2_swissprot_scale_scan(s4g, oracle_mod):
+    """BASELINE configs[2] on one GPU: the 1000 queries x 570 000 targets (6.8e13 cells) that bench.py splits over the ranks at
+    N > 1.  Properties over the whole matrix, the oracle on 3000 random + 300 planted pairs, and the streaming scan's running
+    top-400 (no score matrix) against the top-400 of the matrix for every query."""
+    from sift4g_amd import synth
+    cfg = synth.make_config(3, n_queries=1000, n_targets=570000)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    got = torch.empty((q.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, got)
+    _properties(got, q.lengths, db.lengths, cfg["planted"][::50])
+    _oracle_sample(oracle_mod, cfg, got, 3000, cfg["planted"][:300], 29)
+    ids, sc, cnt = s4g.topk_device(db, got, 400, 1)
+    del got
+    sids, ssc, scnt = s4g.scan_topk(db, q, scorer, 400, 1)
+    assert torch.equal(ids, sids) and torch.equal(sc, ssc) and torch.equal(cnt, scnt)
+
+
+def test_configs3_streaming_scan_of_one_gpus_share(s4g, oracle_mod):
+    """BASELINE configs[3], one GPU's share: 20 M targets generated on the device (6.8e9 residues: every offset beyond 32 bits),
+    packed where they lie, streaming scan + running top-400 for 16 queries (3.8e13 cells, 20 tiles).  A planted copy of every query
+    must lead its list with the self-score; every reported hit and 100 000 random pairs are re-scored by the one-wave-per-pair
+    kernels (an independent implementation) and 600 of the hits by the CPU oracle; no sampled pair beats a list's last entry."""
+    from sift4g_amd import synth
+    from sift4g_amd import device as s4gd
+    N, Q, K = 20_000_000, 16, 400
+    dev = torch.device("cuda", 0)
+    codes, offsets = synth.device_database(N, synth.SEED_BASE + 4 + 0x1000, dev)
+    assert int(offsets[-1]) > 2**32
+    ql = synth.query_lengths(synth.SEED_BASE + 4 + 0x100, Q)
+    q_codes, q_off = synth.random_set(synth.SEED_BASE + 4 + 0x200, ql)
+    lens = (offsets[1:] - offsets[:-1])
+    planted = []
+    for i in range(Q):
+        p = (i + 1) * (N // (Q + 1))
+        while int(lens[p]) < ql[i]:
+            p += 1
+        planted.append(p)
+        o = int(offsets[p])
+        codes[o:o + int(ql[i])] = torch.from_numpy(q_codes[int(q_off[i]):int(q_off[i + 1])].copy()).to(dev)
+    torch.cuda.synchronize()
+    db = s4g.Database.from_device(codes, offsets)
+    assert len(db.tiles()) >= 19
+    q = s4g.QuerySet(codes=q_codes, offsets=q_off)
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    ids, sc, cnt = s4g.scan_topk(db, q, scorer, K)
+    ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+    assert (cnt == K).all()
+    M = s4gd.matrix_by_name("BLOSUM_62")
+    for i in range(Q):
+        qc = q_codes[int(q_off[i]):int(q_off[i + 1])]
+        assert ids[i, 0] == planted[i] and sc[i, 0] == int(M[qc, qc].sum()), i
+        key = list(zip((-sc[i].astype(np.int64)).tolist(), ids[i].astype(np.int64).tolist()))
+        assert key == sorted(key), i                                                  # score descending, ties by id ascending
+    pq = np.repeat(np.arange(Q, dtype=np.uint32), K)
+    pt = ids.reshape(-1).astype(np.uint32)
+    assert np.array_equal(s4g.score_pairs(db, q, scorer, pq, pt, route="wave"), sc.reshape(-1))
+    rng = np.random.default_rng(41)
+    rq = rng.integers(0, Q, 100_000).astype(np.uint32)
+    rt = rng.integers(0, N, 100_000).astype(np.uint32)
+    rs = s4g.score_pairs(db, q, scorer, rq, rt, route="wave")
+    member = set(zip(pq.tolist(), pt.tolist()))
+    last, last_id = sc[:, K - 1], ids[:, K - 1]
+    for a, b, s_ in zip(rq.tolist(), rt.tolist(), rs.tolist()):
+        if (a, b) not in member:
+            assert s_ < last[a] or (s_ == last[a] and b > last_id[a]), (a, b, s_)
+    # the oracle on 600 of the reported hits (their residues come back from the device)
+    pick = rng.choice(Q * K, size=600, replace=False)
+    off_h = offsets.cpu().numpy()
+    seqs = [codes[int(off_h[t]):int(off_h[t + 1])].cpu().numpy() for t in pt[pick]]
+    t_off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    t_off[1:] = np.cumsum([len(x) for x in seqs]).astype(np.uint64)
+    exp = oracle_mod.pairs_flat(q_codes, q_off, np.concatenate(seqs), t_off, pq[pick], np.arange(600, dtype=np.uint32),
+                                oracle_mod.blosum62(), 10, 1, threads=os.cpu_count() or 8)
+    assert np.array_equal(exp, sc.reshape(-1)[pick])
+
+
+def test_configs4_long_queries_full_size(s4g, oracle_mod):
+    """BASELINE configs[4]: 64 queries of 2000-5000 residues x the 100 000-target database (7.7e12 cells; score bounds up to 28 000,
+    so most queries run the drifting-frame kernel speculatively and the exact int32 pass recomputes what it marks).  Routing by
+    bound alone (no_spec) must give the same matrix bit for bit; the oracle on 1500 random and all planted pairs of 8 queries."""
+    from sift4g_amd import synth
+    from sift4g_amd import device as s4gd
+    cfg = synth.make_config(5, n_queries=64, n_targets=100000, q_len=(2000, 5000))
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    got = torch.empty((q.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, got)
+    st = s4gd.scan_stats(0)
+    assert st["speculative"] > 0, st
+    by_bound = torch.empty_like(got)
+    s4g.scan(db, q, scorer, by_bound, no_spec=True)
+    assert torch.equal(got, by_bound)
+    planted = [(a, b) for a, b in cfg["planted"] if a < 8]
+    _oracle_sample(oracle_mod, cfg, got, 1500, planted, 31)

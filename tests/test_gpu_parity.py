@@ -372,38 +372,6 @@ def test_topk_heavy_ties_and_large_scores(s4g, scorer):
             assert (ids[i, cnt[i]:] == 0xFFFFFFFF).all() and (sc[i, cnt[i]:] == 0).all()
 
 
-def test_full_size_properties(s4g, oracle_mod, blosum62, scorer):
-    """BASELINE configs[1] shape (subsampled queries x the full 100k DB): size-independent properties
-    plus an oracle spot-check."""
-    import torch
-    from sift4g_amd import synth
-    cfg = synth.make_config(2, n_queries=1000, n_targets=100000)
-    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
-    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
-    nq = 24
-    out = torch.empty((nq, db.n), dtype=torch.int32, device="cuda:0")
-    s4g.scan(db, q, scorer, out, q_begin=0, q_count=nq)
-    got = out.cpu().numpy()
-    assert (got >= 0).all()
-    # local score bounds: <= 11 * min(Lq, Lt)
-    ql = q.lengths[:nq, None]; tl = db.lengths[None, :]
-    assert (got <= 11 * np.minimum(ql, tl)).all()
-    # planted homologs stand out from the background
-    planted = [(a, b) for a, b in cfg["planted"] if a < nq]
-    bg = np.percentile(got, 99.9)
-    assert np.mean([got[a, b] > bg for a, b in planted]) > 0.95
-    # idempotence: a second scan gives identical bytes
-    out2 = torch.empty_like(out)
-    s4g.scan(db, q, scorer, out2, q_begin=0, q_count=nq)
-    assert torch.equal(out, out2)
-    # oracle spot-check on a random sample of pairs + every planted pair of the first queries
-    rng = np.random.default_rng(23)
-    pq = np.concatenate([rng.integers(0, nq, 3000), [a for a, _ in planted[:200]]]).astype(np.uint32)
-    pt = np.concatenate([rng.integers(0, db.n, 3000), [b for _, b in planted[:200]]]).astype(np.uint32)
-    exp = oracle_mod.pairs_flat(cfg["q_codes"], cfg["q_off"], cfg["t_codes"], cfg["t_off"], pq, pt, blosum62, 10, 1, threads=8)
-    assert np.array_equal(got[pq, pt], exp)
-
-
 def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
     """the database is stored as tiles of the length-sorted order (incl. a separate long-sequence class):
     full-matrix scans must not depend on the tiling."""
