@@ -44,6 +44,65 @@ DeviceCtx* device_ctx(int device) {
     return c;
 }
 
+// ---------------------------------------------------------------------------
+// Persistent host workers for parallel_for (s4g_internal.hpp): 7 threads started on first use, woken per job, joined when the
+// library is unloaded.  One job at a time (callers hold no lock they could deadlock on: jobs are pure host loops).
+namespace {
+struct HostPool {
+    static constexpr unsigned kWorkers = 7;
+    std::mutex mu, job_mu;
+    std::condition_variable wake, done_cv;
+    std::thread th[kWorkers];
+    bool started = false, quit = false;
+    uint64_t generation = 0;
+    unsigned parts = 0, remaining = 0;
+    void (*fn)(void*, unsigned) = nullptr;
+    void* ctx = nullptr;
+
+    void worker(unsigned w) {
+        uint64_t seen = 0;
+        for (;;) {
+            void (*f)(void*, unsigned); void* c; unsigned p;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+                f = fn; c = ctx; p = parts;
+            }
+            if (w + 1 < p) f(c, w + 1);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--remaining == 0) done_cv.notify_one();
+            }
+        }
+    }
+    void run(unsigned n_parts, void (*f)(void*, unsigned), void* c) {
+        std::lock_guard<std::mutex> job(job_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!started) { for (unsigned w = 0; w < kWorkers; ++w) th[w] = std::thread(&HostPool::worker, this, w); started = true; }
+            fn = f; ctx = c; parts = n_parts; remaining = kWorkers;
+            ++generation;
+        }
+        wake.notify_all();
+        f(c, 0);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return remaining == 0; });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        wake.notify_all();
+        if (started) for (auto& t : th) if (t.joinable()) t.join();
+    }
+} g_host_pool;
+}  // namespace
+
+void host_pool_run(unsigned parts, void (*fn)(void* ctx, unsigned part), void* ctx) {
+    if (parts > HostPool::kWorkers + 1) parts = HostPool::kWorkers + 1;
+    g_host_pool.run(parts, fn, ctx);
+}
+
 int warm_core_kernels(DeviceCtx* cx) {
     (void)cx;
     int per_cu = 0;

@@ -95,6 +95,13 @@ S4G_API int s4g_clock_probe(int device, double* out, uint32_t cap) {
 // the swsharp-compatible library starts the warm-up from that check, and the alignment stage finds a warm device.
 // The thread holds the device's mutex while it works: a call that needs the device meanwhile simply waits for it.
 static std::once_flag g_warm_once[64];
+// The warm-up threads are joined when the library is unloaded (static destruction runs before the HIP runtime's own, which
+// this library depends on): a process that exits early -- sift4g's ASSERT does, on a bad argument -- must not tear the
+// runtime down underneath a thread that is still inside it.
+static struct WarmThreads {
+    std::thread t[64];
+    ~WarmThreads() { for (auto& x : t) if (x.joinable()) x.join(); }
+} g_warm_threads;
 
 static void warm_device(int device) {
     DeviceGuard guard(device);
@@ -116,6 +123,6 @@ S4G_API int s4g_warmup(int device) {
     if (device < 0 || device >= 64) return fail(S4G_ERR_INVALID, "bad device %d", device);
     const int n = device_count_raw();
     if (n <= 0 || device >= n) return fail(S4G_ERR_NO_DEVICE, "no HIP device %d", device);
-    std::call_once(g_warm_once[device], [device] { std::thread(warm_device, device).detach(); });
+    std::call_once(g_warm_once[device], [device] { g_warm_threads.t[device] = std::thread(warm_device, device); });
     return S4G_OK;
 }

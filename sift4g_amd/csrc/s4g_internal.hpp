@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -163,6 +164,24 @@ struct s4g_queries {
 
 constexpr uint32_t kLongSeq = 12288;                   // sequences longer than this get tiles of their own: beyond ~16k residues
                                                        // the per-wave strip-boundary workspace no longer fits the budget at full grid
+
+// Fork-join over [0, n): f(part, parts, begin, end) on `parts` host threads (the caller's included).  For the O(pairs) passes of
+// the list route, which are a third of a call's time when left to one thread; small inputs run inline.  The workers are a
+// small persistent pool (s4g_core.hip): starting a std::thread costs ~100 us on the GPU box, as much as the work of a part.
+inline unsigned parallel_parts(uint64_t n, uint64_t min_per_part) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(hw, 8u), n / std::max<uint64_t>(1, min_per_part)));
+}
+void host_pool_run(unsigned parts, void (*fn)(void* ctx, unsigned part), void* ctx);     // parts <= 8; part 0 runs on the caller
+template <class F>
+inline void parallel_for(uint64_t n, unsigned parts, F f) {
+    if (parts <= 1) { f(0u, 1u, (uint64_t)0, n); return; }
+    struct Ctx { F* f; uint64_t n; unsigned parts; } ctx{&f, n, parts};
+    host_pool_run(parts, [](void* c, unsigned p) {
+        Ctx* x = static_cast<Ctx*>(c);
+        (*x->f)(p, x->parts, x->n * p / x->parts, x->n * (p + 1) / x->parts);
+    }, &ctx);
+}
 
 template <typename T>
 struct DevBuf {          // scoped device allocation for the non-hot paths

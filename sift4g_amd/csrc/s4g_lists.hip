@@ -112,21 +112,42 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     // ---- the split length: histogram of cells over target length (one pass), estimate for every 64-residue cut ----
     uint32_t lt_db = 0;
     for (const Tile& t : db->tiles) lt_db = std::max(lt_db, t.max_len4 * 4);
-    std::vector<double> cells_le((size_t)lt_db / 64 + 2, 0.0);
-    std::vector<uint32_t> pairs_in((size_t)lt_db / 64 + 2, 0);          // eligible pairs per 64-residue bucket of target length
+    const size_t n_buckets = (size_t)lt_db / 64 + 2;
+    std::vector<double> cells_le(n_buckets, 0.0);
+    std::vector<uint32_t> pairs_in(n_buckets, 0);                      // eligible pairs per 64-residue bucket of target length
     uint32_t lt_max = 0, lq_max = 0;
     double cells_all = 0, rows_all = 0;
-    for (uint32_t i = 0; i < n_sel; ++i) {
-        const uint32_t pi = sel[i];
-        const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi], lq = q->len[qi];
-        const double c = (double)lq * lt;
-        lt_max = std::max(lt_max, lt);
-        lq_max = std::max(lq_max, lq);
-        cells_all += c;
-        rows_all += lq;
-        if (lt == 0 || lt > lt_cap[qi]) continue;
-        cells_le[lt / 64] += c;
-        ++pairs_in[lt / 64];
+    const unsigned parts = parallel_parts(n_sel, 1u << 16);
+    {
+        struct Part { std::vector<double> cells; std::vector<uint32_t> pairs; uint32_t lt_max = 0, lq_max = 0; double cells_all = 0, rows_all = 0; };
+        std::vector<Part> part(parts);
+        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
+            // locals, written back once: the Part structs sit side by side in one array (false sharing)
+            std::vector<double> cells(n_buckets, 0.0);
+            std::vector<uint32_t> pairs(n_buckets, 0);
+            uint32_t my_lt = 0, my_lq = 0;
+            double my_cells = 0, my_rows = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t pi = sel[(uint32_t)i];
+                const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi], lq = q->len[qi];
+                const double c = (double)lq * lt;
+                my_lt = std::max(my_lt, lt);
+                my_lq = std::max(my_lq, lq);
+                my_cells += c;
+                my_rows += lq;
+                if (lt == 0 || lt > lt_cap[qi]) continue;
+                cells[lt / 64] += c;
+                ++pairs[lt / 64];
+            }
+            Part& P = part[p];
+            P.cells.swap(cells); P.pairs.swap(pairs);
+            P.lt_max = my_lt; P.lq_max = my_lq; P.cells_all = my_cells; P.rows_all = my_rows;
+        });
+        for (const Part& P : part) {
+            lt_max = std::max(lt_max, P.lt_max); lq_max = std::max(lq_max, P.lq_max);
+            cells_all += P.cells_all; rows_all += P.rows_all;
+            for (size_t b = 0; b < n_buckets; ++b) { cells_le[b] += P.cells[b]; pairs_in[b] += P.pairs[b]; }
+        }
     }
     for (size_t b = 1; b < cells_le.size(); ++b) cells_le[b] += cells_le[b - 1];
     uint32_t best_ls = 0;
@@ -139,18 +160,35 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     if (force) best_ls = forced_split ? forced_split : std::max(lt_max, 1u);      // everything the window admits (up to the caller's cut)
     else if (best_ls == 0 || best_t > 0.9 * all_waves) return S4G_OK;       // the pair kernels take it all
 
+    const auto t_h = now();
     // ---- one pass: which pairs go where, and per query how many list entries ----
     static thread_local std::vector<uint32_t> wave_sel;
     wave_sel.clear();
     std::vector<uint32_t> count(q->n + 1, 0);
     uint32_t n = 0;
-    for (uint32_t i = 0; i < n_sel; ++i) {
-        const uint32_t pi = sel[i];
-        const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
-        if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { ++n; ++count[qi + 1]; } else wave_sel.push_back(pi);
+    std::vector<uint32_t> part_lists(parts, 0);                         // list entries found by each part, in order
+    {
+        std::vector<std::vector<uint32_t>> part_wave(parts), part_count(parts);
+        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
+            std::vector<uint32_t>& cnt = part_count[p];
+            cnt.assign(q->n + 1, 0);
+            uint32_t mine = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t pi = sel[(uint32_t)i];
+                const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
+                if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { ++mine; ++cnt[qi + 1]; } else part_wave[p].push_back(pi);
+            }
+            part_lists[p] = mine;
+        });
+        for (unsigned p = 0; p < parts; ++p) {
+            n += part_lists[p];
+            wave_sel.insert(wave_sel.end(), part_wave[p].begin(), part_wave[p].end());
+            for (uint32_t i = 0; i <= q->n; ++i) count[i] += part_count[p][i];
+        }
     }
     if (n == 0) return S4G_OK;
     *used = true;
+    const auto t_c = now();
 
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
@@ -210,16 +248,21 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     uint64_t* h_keys = reinterpret_cast<uint64_t*>(cx->h_lst_stage);
     uint64_t* h_vals = reinterpret_cast<uint64_t*>(cx->h_lst_stage + b_keys);
     ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage + 2 * b_keys);
-    {   // entries: key = (query, rank of the target in the database's length order), value = (target, position in sel)
-        uint32_t k = 0, w = 0;
-        const uint32_t nw = (uint32_t)wave_sel.size();
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            const uint32_t pi = sel[i];
-            if (w < nw && wave_sel[w] == pi) { ++w; continue; }       // wave_sel holds its pairs in the same order
-            h_keys[k] = ((uint64_t)pair_q[pi] << 32) | db->pos_of_id[pair_t[pi]];
-            h_vals[k] = ((uint64_t)pair_t[pi] << 32) | i;
-            ++k;
-        }
+    {   // entries: key = (query, rank of the target in the database's length order), value = (target, position in sel); every part
+        // writes its own stretch (the classification is repeated: cheaper than remembering it)
+        std::vector<uint32_t> part_at(parts, 0);
+        for (unsigned p = 1; p < parts; ++p) part_at[p] = part_at[p - 1] + part_lists[p - 1];
+        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
+            uint32_t k = part_at[p];
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t pi = sel[(uint32_t)i];
+                const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
+                if (!(lt != 0 && lt <= best_ls && lt <= lt_cap[qi])) continue;
+                h_keys[k] = ((uint64_t)qi << 32) | db->pos_of_id[pair_t[pi]];
+                h_vals[k] = ((uint64_t)pair_t[pi] << 32) | (uint32_t)i;
+                ++k;
+            }
+        });
     }
     {
         uint32_t at = 0;
@@ -342,9 +385,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     cx->stat_list_pairs = n;
     if (prof) {
         const auto t4 = now();
-        fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: plan+waves %.1f us, entries %.1f us, "
+        fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: plan+waves %.1f us (histogram %.1f, classify %.1f, %u threads), entries %.1f us, "
                         "sort+tables+gather+scan %.1f us, wait+download %.1f us; of which growing buffers %.1f us (ws %.0f MB, residues %.0f MB)\n",
-                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), t_alloc, ws_bytes / 1e6, res_dwords * 4 / 1e6);
+                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t0, t_h), us(t_h, t_c), parts, us(t1, t2), us(t2, t3), us(t3, t4), t_alloc, ws_bytes / 1e6, res_dwords * 4 / 1e6);
     }
     return scope.release();
 }

@@ -410,13 +410,29 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
     // estimate wins: few candidates -> wave, candidate list ~ the whole database -> scan.
     std::vector<double> q_cells(q->n, 0.0);
     std::vector<uint32_t> q_longest(q->n, 0), q_pairs(q->n, 0);
-    for (uint64_t i = 0; i < n_pairs; ++i) {
-        const uint32_t qi = pair_q[i], t = pair_t[i];
-        if (qi >= q->n || t >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)i);
-        const uint32_t lt = db->len[t];
-        q_cells[qi] += lt;
-        q_longest[qi] = std::max(q_longest[qi], lt);
-        ++q_pairs[qi];
+    {
+        const unsigned parts = parallel_parts(n_pairs, 1u << 16);
+        struct Part { std::vector<double> cells; std::vector<uint32_t> longest, pairs; uint64_t bad = ~0ull; };
+        std::vector<Part> part(parts);
+        parallel_for(n_pairs, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
+            std::vector<double> cells(q->n, 0.0);               // locals, handed over once (the Part structs share cache lines)
+            std::vector<uint32_t> longest(q->n, 0), pairs(q->n, 0);
+            uint64_t bad = ~0ull;
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t qi = pair_q[i], t = pair_t[i];
+                if (qi >= q->n || t >= db->n_seqs) { bad = i; break; }
+                const uint32_t lt = db->len[t];
+                cells[qi] += lt;
+                longest[qi] = std::max(longest[qi], lt);
+                ++pairs[qi];
+            }
+            Part& P = part[p];
+            P.cells.swap(cells); P.longest.swap(longest); P.pairs.swap(pairs); P.bad = bad;
+        });
+        for (const Part& P : part) {
+            if (P.bad != ~0ull) return fail(S4G_ERR_INVALID, "pair %llu out of range", (unsigned long long)P.bad);
+            for (uint32_t i = 0; i < q->n; ++i) { q_cells[i] += P.cells[i]; q_longest[i] = std::max(q_longest[i], P.longest[i]); q_pairs[i] += P.pairs[i]; }
+        }
     }
     uint32_t max_t = 0;
     for (const Tile& t : db->tiles) max_t = std::max(max_t, t.max_len4 * 4);

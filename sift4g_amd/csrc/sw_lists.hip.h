@@ -130,10 +130,8 @@ __device__ __forceinline__ v4i lst_load(const char* prof, unsigned taddr, int bl
 // to its strips / 4, the queue hands out 4x larger units to 4x fewer takers, and no wave ever idles at an item's end:
 // the stream continues into the next item (whose first strip depends on nothing).
 constexpr int kListRing = 16;            // fetched items a block keeps in LDS
-#ifndef S4G_LIST_PUBLISH_EVERY
-#define S4G_LIST_PUBLISH_EVERY 1
-#endif
-constexpr unsigned kListPublishEvery = S4G_LIST_PUBLISH_EVERY;     // chunks between two publications of a strip's progress (power of 2)
+constexpr unsigned kListPublishEvery = 1;     // chunks between two publications of a strip's progress (power of 2; 2 and 4 measured
+                                              // the same: the release's wait for the boundary stores is hidden by the other waves)
 constexpr int kListBufs = 4;             // workspace buffers (and best-score rows) per block: item k uses buffer k % 4; a wave may
                                          // run at most 3 items ahead of the slowest wave of its block
 

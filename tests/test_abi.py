@@ -106,3 +106,12 @@ def test_libswsharp_exports_only_its_c_api():
     for must in ("alignDatabase", "chainCreate", "scorerCreateMatrix", "createEValueParams", "eValues", "dbAlignmentsMerge",
                  "shotgunDatabaseEValues", "readFastaChainsPart", "threadPoolSubmit", "cudaCheckCards"):
         assert must in names, must
+
+
+def test_warmup_without_a_device_reports_it():
+    """s4g_warmup is asynchronous, but the absence of a device is known at once (no thread is started)."""
+    from sift4g_amd import _lib
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert _lib.lib.s4g_warmup(0) == _lib.S4G_ERR_NO_DEVICE
+    assert _lib.lib.s4g_warmup(-1) == _lib.S4G_ERR_INVALID and _lib.lib.s4g_warmup(64) == _lib.S4G_ERR_INVALID

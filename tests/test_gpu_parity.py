@@ -263,6 +263,29 @@ def test_candidate_lists(s4g, oracle_mod, blosum62, scorer):
     assert np.array_equal(got, want)
 
 
+def test_warmup_then_scan_in_a_fresh_process():
+    """s4g_warmup (what cudaCheckCards starts, main.cpp:186): a fresh process warms the device on a thread of its own and scans
+    right away -- the scan waits for the warm-up on the device mutex and gives the oracle's scores; calling it again is a no-op."""
+    import subprocess, sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from sift4g_amd import _lib
+assert _lib.lib.s4g_warmup(0) == 0 and _lib.lib.s4g_warmup(0) == 0
+import numpy as np, oracle, sift4g_amd as s4g
+from conftest import rand_seqs
+rng = np.random.default_rng(5)
+qs, ts = rand_seqs(rng, 3, 50, 300), rand_seqs(rng, 200, 1, 400)
+got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), s4g.Scorer("BLOSUM_62", 10, 1))
+assert np.array_equal(got, oracle.scan(qs, ts, oracle.blosum62(), 10, 1, threads=4))
+pq = np.repeat(np.arange(3, dtype=np.uint32), 200); pt = np.tile(np.arange(200, dtype=np.uint32), 3)
+assert np.array_equal(s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), s4g.Scorer("BLOSUM_62", 10, 1), pq, pt, route="lists"), got.reshape(-1))
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_candidate_lists_on_the_packed_list_kernel(s4g, oracle_mod, blosum62):
     """route "lists" of s4g_score_pairs_host (sw_scan_lists: a query's candidates sorted by length on the device, 128 to an item,
     two targets per register) against the oracle: list sizes around the item size (1, 127, 128, 129, 300), empty targets and an
