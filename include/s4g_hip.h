@@ -79,8 +79,9 @@ int s4g_device_count(int* count);
 int s4g_device_check(const int* cards, int n);
 
 /* Built-in substitution tables by the names scorerCreateMatrix accepts
- * (/root/reference/sift4g/src/main.cpp:73,208,304-314).  Round 1 ships BLOSUM_62
- * (the reference default); other names return S4G_ERR_INVALID.
+ * (/root/reference/sift4g/src/main.cpp:73,208,304-314): BLOSUM_45, BLOSUM_50, BLOSUM_62, BLOSUM_80, BLOSUM_90, PAM_30,
+ * PAM_70, PAM_250, and the help text's spellings BLOSUM_30 / BLOSUM_70 / BLOSUM_250 for the three PAM tables; any other
+ * name returns S4G_ERR_INVALID.
  * table26x26 receives 676 int32, letter-indexed (code = letter - 'A'). */
 int s4g_matrix_by_name(const char* name, int32_t* table26x26);
 

@@ -39,27 +39,33 @@ void evalue_callback(double* values, int* scores, Chain* query, Chain** database
     eValues(values, scores, query, database, databaseLen, cards, cardsLen, static_cast<EValueParams*>(param));
 }
 
-// The candidates of one chunk: the union of all queries' ids below `end`, and every query's list as positions in it.
+// The candidates of one chunk: the union of all queries' ids in [begin, end), and every query's list as positions in it.
+// (A membership table over the chunk's id range and its running count give the union and every position in O(pairs + range);
+// sorting the ~10^6 ids of a chunk and searching each one took a third of the stage's host time.)
 struct ChunkCandidates {
     std::vector<uint32_t> ids;               // sorted, unique global ids
     std::vector<std::vector<int>> lists;     // per query: positions into `ids`
 
-    ChunkCandidates(std::vector<std::vector<uint32_t>>& indices, uint32_t end) : lists(indices.size()) {
+    ChunkCandidates(std::vector<std::vector<uint32_t>>& indices, uint32_t begin, uint32_t end) : lists(indices.size()) {
         std::vector<size_t> taken(indices.size(), 0);
+        std::vector<uint32_t> rank((size_t)(end - begin) + 1, 0);      // first: membership, then: position in `ids`
         for (size_t q = 0; q < indices.size(); ++q) {
             const std::vector<uint32_t>& v = indices[q];
             size_t n = 0;
-            while (n < v.size() && v[n] < end) ++n;
+            while (n < v.size() && v[n] < end) { if (v[n] >= begin) rank[v[n] - begin] = 1; ++n; }
             taken[q] = n;
-            ids.insert(ids.end(), v.begin(), v.begin() + n);
         }
-        std::sort(ids.begin(), ids.end());
-        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        uint32_t seen = 0;
+        for (uint32_t i = 0; i < end - begin; ++i) {
+            const uint32_t member = rank[i];
+            rank[i] = seen;
+            if (member) { ids.push_back(begin + i); ++seen; }
+        }
         for (size_t q = 0; q < indices.size(); ++q) {
             std::vector<uint32_t>& v = indices[q];
             lists[q].reserve(taken[q]);
             for (size_t k = 0; k < taken[q]; ++k)
-                lists[q].push_back((int)(std::lower_bound(ids.begin(), ids.end(), v[k]) - ids.begin()));
+                if (v[k] >= begin) lists[q].push_back((int)rank[v[k] - begin]);
             v.erase(v.begin(), v.begin() + taken[q]);           // consumed, like the reference's createFilteredDatabase
         }
     }
@@ -86,7 +92,7 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
         const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunkBytes);
         databaseLog(part, part_gb, 0);
 
-        ChunkCandidates cand(indices, (uint32_t)database_length);
+        ChunkCandidates cand(indices, (uint32_t)chunk_begin, (uint32_t)database_length);
         std::vector<Chain*> pool(cand.ids.size());
         for (size_t k = 0; k < pool.size(); ++k) pool[k] = database[cand.ids[k]];
 

@@ -21,6 +21,8 @@ constexpr double kListChipRate = 8.3e12, kListWaveChipRate = 2.8e12;
 constexpr double kListCyclesPerRowCol = 64.0, kClockHz = 2.4e9;     // measured on the longest item of a launch at raised priority: one wave
                                                                     // issues a dependent packed op every ~8.5 clocks however idle its SIMD is
 constexpr double kListFixedCost = 250e-6;            // sort + item tables + gather + one host round trip
+constexpr uint32_t kListMaxTarget = 4096;            // longer targets always go to the pair waves: the block workspace is 2 KB per residue
+                                                     // of the longest member and block (6.4 GB at 4096 residues on 768 blocks)
 
 struct ListBuffers {
     uint64_t *keys_in, *keys_out, *vals_in, *vals_out, *dwords, *offs;
@@ -153,12 +155,13 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     uint32_t best_ls = 0;
     double best_t = lists_cost(cells_le, cells_all, lq_max, 0, lt_max);
     const double all_waves = best_t;
-    for (uint32_t ls = 127; ls < lt_max + 64; ls += 64) {
+    for (uint32_t ls = 127; ls < std::min(lt_max, kListMaxTarget) + 64; ls += 64) {
         const double t = lists_cost(cells_le, cells_all, lq_max, ls, lt_max);
         if (t < best_t) { best_t = t; best_ls = ls; }
     }
     if (force) best_ls = forced_split ? forced_split : std::max(lt_max, 1u);      // everything the window admits (up to the caller's cut)
     else if (best_ls == 0 || best_t > 0.9 * all_waves) return S4G_OK;       // the pair kernels take it all
+    best_ls = std::min(best_ls, kListMaxTarget);
 
     const auto t_h = now();
     // ---- one pass: which pairs go where, and per query how many list entries ----

@@ -378,3 +378,27 @@ def test_evalue_row_convention_and_missing_rows(capfd):
     one(10, 1, name="BLOSUM_30")                                 # the CLI's spelling of PAM_30 (main.cpp:310): 10/1 has a row there
     assert "WARNING" not in capfd.readouterr().err
     L.chainDelete(q); L.chainDelete(t)
+
+
+def test_evalue_reaches_the_textbook_limit_for_long_sequences():
+    """Far from the finite-size regime the corrected e-value must reduce to the classic Karlin-Altschul form E = K m n exp(-lambda S)
+    (= m n 2^-S' with the bit score S' = (lambda S - ln K) / ln 2): both the library and the restatement, for query and target of
+    10^6 residues, agree with it to the size of the correction itself ((1 - l/m)(1 - l/n), l = a S + b ~ 200 residues)."""
+    from math import exp, log
+    from oracle import evalue_ref as er
+    m = n = 1_000_000
+    s = sw.scorer(11, 1)
+    q = sw.chain("q", np.zeros(m, dtype=np.uint8))
+    t = sw.chain("t", np.zeros(n, dtype=np.uint8))
+    ev = L.createEValueParams(n, s)                       # database = the one target: scale factor 1
+    P = er.gumbel_parameters("BLOSUM_62", 11, 1)
+    for score in (60, 100, 150):
+        v = (cd * 1)()
+        L.eValues(v, (ci * 1)(score), q, sw.chain_array([t]), 1, None, 0, ev)
+        classic = P["K"] * m * n * exp(-P["lam"] * score)
+        assert classic == pytest.approx(m * n * 2.0 ** (-er.bit_score(score, P)), rel=1e-12)
+        ell = P["a"] * score + P["b"]
+        assert v[0] == pytest.approx(classic * (1 - ell / m) * (1 - ell / n), rel=2e-6)
+        assert er.evalue(score, m, n, n, P) == pytest.approx(v[0], rel=1e-12)
+        assert 0.999 < v[0] / classic < 1.0
+    L.deleteEValueParams(ev); L.chainDelete(q); L.chainDelete(t); L.scorerDelete(s)
