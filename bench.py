@@ -37,7 +37,7 @@ TOPK = 400                     # max_alignments default (/root/reference/sift4g/
 LANES_PER_CLK_PER_SIMD = 16    # a wave64 vector instruction occupies its SIMD for 4 clocks (profiles/r01_valu_rates.txt)
 # algorithmic vector ops per DP cell of each scan kernel (counted from the recurrence, not from the ISA)
 VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75, "sw_scan_pk<ArithF16,32>": 3.75,
-                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5}
+                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5, "sw_scan_i32d<32>": 6.5}
 WORKLOADS = {
     "configs1": dict(cfg=2, queries=1000, targets=100_000, qlen=(300, 400), label="BASELINE configs[1]"),
     "configs2": dict(cfg=3, queries=1000, targets=570_000, qlen=(300, 400), label="BASELINE configs[2] (Swiss-Prot scale)"),
@@ -264,7 +264,7 @@ def main():
     cells_rank = s4gd.scan_cells(db, allq, q_begin, q_count) if q_count else 0
     plan = s4gd.scan_plan(db, allq, scorer)
     if args.force_i32:
-        plan["kernel"], plan["strip_rows"] = "sw_scan_i32<32>", 32
+        plan["kernel"], plan["strip_rows"] = ("sw_scan_i32<32>" if args.no_drift else "sw_scan_i32d<32>"), 32   # BLOSUM62 10/1 fits the drifting int32 frame
     elif args.no_f16 and ("M3" in plan["kernel"] or "pkd" in plan["kernel"]):
         plan["kernel"] = "sw_scan_pk<ArithI16,32>"
     elif args.no_drift and "pkd" in plan["kernel"]:
@@ -437,8 +437,8 @@ def main():
                 ms32.append(e0.elapsed_time(e1))
             k32 = float(np.mean(ms32))
             g32 = cells_rank / (k32 * 1e-3) / 1e9
-            out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32<32>", "steps": 2,
-                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
+            out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32d<32>", "steps": 2,
+                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
                             tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
         if world == 1 and not args.no_cpu_baseline and cfg is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)

@@ -202,6 +202,140 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
 
 
 // =====================================================================================================
+// sw_scan_i32d: the int32 kernel in a DRIFTING FRAME (see sw_scan_pkd below for the algebra): every stored value carries
+// (i + j) * ext, which removes the two saturating "- ext" of the gap recurrences and lets them share one add:
+//     H~ = max3(diag~ + (s + 2e), E~, F~);   E~' = max3(E~, H~ + (e - o), z');   F~' = max(F~, H~ + (e - o));
+//     best = max3(best, H~ - z  [two rows per instruction])
+// = 6.5 vector ops per cell against sw_scan_i32's 7.5.  int32 has room for any frame (no bias, no window, no tiers): exact
+// for every scorer whose shifted scores s + 2e still fit the int8 strip profile (max score + 2 ext <= 127); the host falls
+// back to sw_scan_i32 otherwise.  z(i, j) is uniform over the wave and lives in SGPRs.
+// =====================================================================================================
+template <int R>
+__device__ __forceinline__ void sw_column_d(int (&H)[R], int (&E)[R], const v4i (&sc)[R / 16], int diag, int F, int& best,
+                                            int eo, int zcur, int e, int& h_last, int& f_last) {
+    int tprev = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int w = sc[r / 16][(r % 16) / 4];
+        const int s = (int)(signed char)(w >> (8 * (r % 4)));
+        const int h = imax(imax(diag + s, E[r]), F);
+        const int t = h - zcur;                                   // true H
+        if (r & 1) best = imax(imax(best, tprev), t); else tprev = t;
+        zcur += e;                                                // scalar: z(i+1, j) = z(i, j+1)
+        const int hm = h + eo;
+        E[r] = imax(imax(E[r], hm), zcur);
+        F = imax(F, hm);
+        diag = H[r];
+        H[r] = h;
+    }
+    h_last = H[R - 1];
+    f_last = F;
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
+    static_assert(R % 16 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 32);
+
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const unsigned n_items = a.n_groups * a.q_count;
+    const int e = (int)a.ext;
+    const int eo = (int)a.ext - (int)a.open;
+    const int two_e = 2 * e;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const unsigned g = item / a.q_count;
+        const unsigned qi = item - g * a.q_count;
+        const unsigned q = a.q_list ? a.q_list[qi] : a.q_begin + qi;
+        const unsigned len4 = a.grp_len4[g];
+        const uint32_t* res = a.db_res + a.grp_off[g] + lane;
+        const uint8_t* qc = a.q_codes + a.q_off[q];
+        const unsigned lq = a.q_len[q];
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        int best = 0;
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            // ---- strip profile: prof[k][t][b] = M[q_{sR+16k+b}][t] + 2e  (int8) ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 2 * R; e0 += 64) {
+                const int en = e0 + lane;
+                const int k = en >> 5, t = en & 31;
+                const v4i q16 = *reinterpret_cast<const v4i*>(qc + s * R + 16 * k);
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const unsigned code = ((unsigned)q16[d] >> (8 * b)) & 31u;
+                        w |= (unsigned)(unsigned char)(lmat[code * 32 + t] + two_e) << (8 * b);
+                    }
+                    out[d] = (int)w;
+                }
+                *reinterpret_cast<v4i*>(prof + en * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+            const int zrow0 = (int)(s * R) * e;                     // z(i0, 0) for the strip's first row i0
+            int H[R];
+            int E[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = zrow0 + (r - 1) * e; E[r] = zrow0 + r * e; }     // H~(i,-1), E~(i,0) for H = E = 0
+            int zcol = zrow0;                                        // z(i0, j) of the current column
+            int hdiag = zrow0 - 2 * e;                               // H~(i0-1, -1)
+
+            uint32_t res_n = res[0];
+            v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+            if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
+            v4i sc_n[R / 16];
+            load_scores<R>(sc_n, prof, res_n, 0);
+            for (unsigned c = 0; c < len4; ++c) {
+                const uint32_t r4 = res_n;
+                const v4i hb = hb_n, fb = fb_n;
+                const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+                res_n = res[(uint64_t)cn * 64];
+                if (!first) { hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
+                v4i ho, fo;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    v4i sc[R / 16];
+#pragma unroll
+                    for (int k = 0; k < R / 16; ++k) sc[k] = sc_n[k];
+                    if (cc < 3) load_scores<R>(sc_n, prof, r4, cc + 1); else load_scores<R>(sc_n, prof, res_n, 0);
+                    int hl, fl;
+                    sw_column_d<R>(H, E, sc, hdiag, first ? zcol : fb[cc], best, eo, zcol, e, hl, fl);   // first strip: F~(0,j) = z(0,j)
+                    hdiag = first ? zcol - e : hb[cc];               // first strip: H~(-1, j) = z(0,j) - e
+                    zcol += e;
+                    ho[cc] = hl; fo[cc] = fl;
+                    asm volatile("" : "+v"(best));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
+            }
+        }
+        const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
+        if (p != 0xFFFFFFFFu) a.scores[(uint64_t)(q - a.q_begin) * a.score_stride + p] = best;
+    }
+}
+
+
+// =====================================================================================================
 // Packed int16 x 2 kernel: the two halves of every 32-bit register carry two DIFFERENT QUERIES against the
 // same database sequence (lane).  v_pk_add_u16 / v_pk_max_i16 / v_pk_sub_u16 clamp update both cells per
 // instruction: 9 VALU ops per pair of cells = 4.5 per cell (no packed max3 exists, so H costs add+max+max and the

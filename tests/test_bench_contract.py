@@ -66,7 +66,7 @@ def test_bench_prints_one_contract_json_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "GCUPS" and cb["sample"]
     # the same line carries the int32-only figure (north_star: "int32 scores") and the oracle re-score of the run's own results
-    assert d["tiers"]["int32"]["gcups"] > 0 and d["tiers"]["int32"]["kernel"] == "sw_scan_i32<32>"
+    assert d["tiers"]["int32"]["gcups"] > 0 and d["tiers"]["int32"]["kernel"] == "sw_scan_i32d<32>"
     chk = d["selfcheck"]
     assert chk["random_pairs"] == 2000 and chk["top_list_entries"] > 0 and chk["mismatches"] == 0
     assert d["speculative"] == {"queries": 0, "rechecked": 0}

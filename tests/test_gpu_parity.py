@@ -28,7 +28,9 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     # default plan (fastest exact kernel per query: drifting-frame int16 / maximum3-int16 / plain packed int16 / int32),
     # without the drift kernel, the f16-arithmetic form of the maximum3 tier, no maximum3 at all, int32 alone
     # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
-    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+    # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
+    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True),
+                 dict(force_i32=True, no_drift=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
@@ -410,7 +412,9 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         if tile_seqs == 64:
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 12288-residue sequences form their own tile (side stream)
         # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
-    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True)):
+    # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
+    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True),
+                 dict(force_i32=True, no_drift=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
