@@ -6,6 +6,8 @@
 
 #include <cctype>
 #include <cstring>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <deque>
 
 #include "../matrices.h"
@@ -116,7 +118,55 @@ struct FastaState {              // one per open handle; keeps the look-ahead he
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     std::vector<char> seq;       // raw sequence bytes of the pending record
+    // serialized cache (S4G_FASTA_CACHE=1): this handle READS the cache file instead of FASTA text ...
+    bool serialized_in = false;
+    // ... or it reads FASTA text and WRITES the cache beside it, renamed into place when the whole file has been read
+    FILE* cache_out = NULL;
+    std::string cache_tmp, cache_final;
 };
+
+// ---- serialized chain cache ------------------------------------------------------------------------------------------
+// swsharp's FASTA readers hand the caller a `serialized` flag (database_search.cpp:80-82,96-97; database_alignment.cpp:36,47):
+// upstream can read a binary dump of the chains instead of parsing text.  sift4g reads its database TWICE per run (prefilter,
+// then alignment), so with S4G_FASTA_CACHE=1 the first complete pass over a FASTA file leaves `<path>.s4gchains` beside it and
+// every later pass -- the alignment stage of the same run included -- reads that: header (magic, size and mtime of the FASTA
+// file it was made from), then per record {name length, sequence length, name, raw sequence bytes}.  Records and part
+// boundaries are exactly those of the text reader (same bytes through the same residue table, a part ends with the record
+// that reaches maxBytes), so the reference's results do not depend on which of the two it was given.  Off by default:
+// nothing is written next to the user's database unless asked.
+const char kCacheMagic[8] = {'S', '4', 'G', 'C', 'H', 'N', '1', 0};
+struct CacheHeader { char magic[8]; uint64_t fasta_size; int64_t fasta_mtime; };
+
+bool fasta_cache_enabled() { const char* v = getenv("S4G_FASTA_CACHE"); return v && *v && strcmp(v, "0") != 0; }
+
+bool stat_file(const char* path, uint64_t* size, int64_t* mtime) {
+    struct stat sb;
+    if (stat(path, &sb) != 0) return false;
+    *size = (uint64_t)sb.st_size; *mtime = (int64_t)sb.st_mtime;
+    return true;
+}
+
+// the cache of `path` if it exists and was made from the file as it is now
+FILE* open_valid_cache(const char* path) {
+    uint64_t size; int64_t mtime;
+    if (!stat_file(path, &size, &mtime)) return NULL;
+    const std::string cache = std::string(path) + ".s4gchains";
+    FILE* fh = fopen(cache.c_str(), "rb");
+    if (!fh) return NULL;
+    CacheHeader h;
+    if (fread(&h, sizeof h, 1, fh) != 1 || memcmp(h.magic, kCacheMagic, 8) != 0 || h.fasta_size != size || h.fasta_mtime != mtime) {
+        fclose(fh);
+        return NULL;
+    }
+    return fh;
+}
+
+void cache_abandon(FastaState* st) {       // the reader was dropped before EOF: no half-written cache stays behind
+    if (!st->cache_out) return;
+    fclose(st->cache_out);
+    st->cache_out = NULL;
+    remove(st->cache_tmp.c_str());
+}
 std::vector<FastaState*> g_fasta;
 pthread_mutex_t g_fasta_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -124,7 +174,7 @@ FastaState* fasta_state(FILE* fh, bool create) {
     pthread_mutex_lock(&g_fasta_mu);
     FastaState* st = NULL;
     for (auto* s : g_fasta) if (s->fh == fh) st = s;
-    if (!st && create) { st = new FastaState{fh, "", false, false}; g_fasta.push_back(st); }
+    if (!st && create) { st = new FastaState(); st->fh = fh; st->have_pending = false; st->eof = false; g_fasta.push_back(st); }
     pthread_mutex_unlock(&g_fasta_mu);
     return st;
 }
@@ -132,7 +182,7 @@ FastaState* fasta_state(FILE* fh, bool create) {
 void fasta_forget(FILE* fh) {
     pthread_mutex_lock(&g_fasta_mu);
     for (size_t i = 0; i < g_fasta.size(); ++i)
-        if (g_fasta[i]->fh == fh) { delete g_fasta[i]; g_fasta.erase(g_fasta.begin() + i); break; }
+        if (g_fasta[i]->fh == fh) { cache_abandon(g_fasta[i]); delete g_fasta[i]; g_fasta.erase(g_fasta.begin() + i); break; }
     pthread_mutex_unlock(&g_fasta_mu);
 }
 
@@ -157,6 +207,13 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
         chain_data_append(d, st->seq.data(), st->seq.size());
         d->chars[d->length] = 0;
         push_chain(chains, len, &cap, make_chain(d, 0, d->length, false));
+        if (st->cache_out) {
+            const uint32_t hdr[2] = {(uint32_t)st->pending_name.size(), (uint32_t)st->seq.size()};
+            if (fwrite(hdr, sizeof hdr, 1, st->cache_out) != 1 ||
+                (hdr[0] && fwrite(st->pending_name.data(), hdr[0], 1, st->cache_out) != 1) ||
+                (hdr[1] && fwrite(st->seq.data(), hdr[1], 1, st->cache_out) != 1))
+                cache_abandon(st);            // disk full, read-only directory ...: the run goes on without a cache
+        }
         consumed += st->seq.size();
         st->seq.clear();
         st->have_pending = false;
@@ -207,6 +264,40 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
             st->have_pending = true;
         }
         flush();
+        if (st->cache_out) {              // the whole file has been read: the cache becomes visible under its final name
+            const bool ok = fclose(st->cache_out) == 0;
+            st->cache_out = NULL;
+            if (!ok || rename(st->cache_tmp.c_str(), st->cache_final.c_str()) != 0) remove(st->cache_tmp.c_str());
+        }
+    }
+    if (*len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
+    return st->eof ? 0 : 1;
+}
+
+// The same from the serialized cache: records until >= max_bytes of sequence were consumed (0 = unlimited) or EOF.
+int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
+    int cap = *len;
+    size_t consumed = 0;
+    std::string name;
+    std::vector<char> seq;
+    for (;;) {
+        uint32_t hdr[2];
+        const size_t got = fread(hdr, 1, sizeof hdr, st->fh);
+        if (got == 0) { st->eof = true; break; }
+        SW_ASSERT(got == sizeof hdr, "truncated serialized database cache");
+        name.resize(hdr[0]); seq.resize(hdr[1]);
+        SW_ASSERT((!hdr[0] || fread(&name[0], hdr[0], 1, st->fh) == 1) && (!hdr[1] || fread(seq.data(), hdr[1], 1, st->fh) == 1),
+                  "truncated serialized database cache");
+        ChainData* d = chain_data_alloc(name.data(), name.size(), seq.size());
+        chain_data_append(d, seq.data(), seq.size());
+        d->chars[d->length] = 0;
+        push_chain(chains, len, &cap, make_chain(d, 0, d->length, false));
+        consumed += seq.size();
+        if (max_bytes && consumed >= max_bytes) {           // as the text reader: the record that reaches the limit ends the part --
+            const int c = fgetc(st->fh);                    // unless it was the last one
+            if (c == EOF) st->eof = true; else ungetc(c, st->fh);
+            break;
+        }
     }
     if (*len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
     return st->eof ? 0 : 1;
@@ -215,19 +306,37 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
 }  // namespace
 
 SW_API void readFastaChainsPartInit(Chain*** chains, int* chainsLen, FILE** handle, int* serialized, const char* path) {
-    *handle = fopen(path, "r");
-    SW_ASSERT(*handle != NULL, "cannot open file '%s'", path);
     *chains = NULL;
     *chainsLen = 0;
-    *serialized = 0;          // no serialized-database cache in this implementation
+    *serialized = 0;
+    const bool cache = fasta_cache_enabled();
+    if (cache && (*handle = open_valid_cache(path)) != NULL) {       // a cache made from this very file: read that
+        *serialized = 1;
+        fasta_forget(*handle);
+        fasta_state(*handle, true)->serialized_in = true;
+        return;
+    }
+    *handle = fopen(path, "r");
+    SW_ASSERT(*handle != NULL, "cannot open file '%s'", path);
     fasta_forget(*handle);    // a caller that closed an earlier handle before EOF may get the same FILE* again
-    fasta_state(*handle, true);
+    FastaState* st = fasta_state(*handle, true);
+    uint64_t size; int64_t mtime;
+    if (cache && stat_file(path, &size, &mtime)) {                   // this pass writes the cache (if the directory lets it)
+        st->cache_final = std::string(path) + ".s4gchains";
+        st->cache_tmp = st->cache_final + ".tmp" + std::to_string((long long)getpid());
+        st->cache_out = fopen(st->cache_tmp.c_str(), "wb");
+        if (st->cache_out) {
+            CacheHeader h;
+            memcpy(h.magic, kCacheMagic, 8); h.fasta_size = size; h.fasta_mtime = mtime;
+            if (fwrite(&h, sizeof h, 1, st->cache_out) != 1) cache_abandon(st);
+        }
+    }
 }
 
 SW_API int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, int serialized, const size_t maxBytes) {
-    (void)serialized;
     FastaState* st = fasta_state(handle, true);
-    int more = fasta_read(st, chains, chainsLen, maxBytes);
+    SW_ASSERT((serialized != 0) == st->serialized_in, "readFastaChainsPart: `serialized` does not belong to this handle");
+    int more = st->serialized_in ? cache_read(st, chains, chainsLen, maxBytes) : fasta_read(st, chains, chainsLen, maxBytes);
     if (!more) fasta_forget(handle);   // caller fclose()s the handle itself (database_alignment.cpp:122)
     return more;
 }

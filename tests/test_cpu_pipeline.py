@@ -109,3 +109,26 @@ def test_fullscan_build_on_the_cpu_oracle(tmp_path):
     parts = tmp_path / "parts"                     # the database in ~17 parts: dbAlignmentsMerge across parts, chain deletion
     parts.mkdir()
     assert dropin_synth.run(FULLSCAN, str(parts), env=dict(env, S4G_CHUNK_BYTES="30000")) == got
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+def test_reference_cli_with_the_serialized_database_cache(tmp_path):
+    """S4G_FASTA_CACHE=1: the prefilter's pass over the database (database_search.cpp:81-96) leaves `<db>.s4gchains`, the alignment
+    stage of the SAME run reads it (database_alignment.cpp:36-47, serialized = 1), and so does a second run: both write the files
+    of the uncached run, byte for byte."""
+    import shutil
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""), S4G_FASTA_CACHE="1")
+    files = os.path.join(GOLDEN, "test_files")
+    db = tmp_path / "db.fa"
+    shutil.copy(os.path.join(files, "sample_protein_database.fa"), db)
+    for run in ("first", "second"):
+        out = tmp_path / run
+        out.mkdir()
+        r = subprocess.run([DROPIN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep, "-d", str(db), "--cards", "0",
+                            "--out", str(out), "--sub-results"], env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert (tmp_path / "db.fa.s4gchains").exists()
+        for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+            assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), (run, n)
+    assert sorted(p.name for p in tmp_path.iterdir() if p.is_file()) == ["db.fa", "db.fa.s4gchains"]

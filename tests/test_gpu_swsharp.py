@@ -290,3 +290,31 @@ def test_fullscan_build_is_a_superset_of_the_prefiltered_build(tmp_path):
     a, b = set(hit_lines(outs["prefiltered (batched wrapper)"])), set(hit_lines(outs["full scan"]))
     assert a <= b, sorted(a - b)[:3]
     print(f"\n60 queries x 20000 targets, whole CLI incl. FASTA generation: " + ", ".join(f"{k} {v:.2f} s ({len(hit_lines(outs[k]))} hits)" for k, v in times.items()))
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in binary not built (needs /root/reference at build time: make dropin)")
+@pytest.mark.parametrize("args", [("--matrix", "BLOSUM_45", "-g", "14", "-e", "2"), ("--matrix", "BLOSUM_30", "-g", "9", "-e", "1"),
+                                  ("--matrix", "BLOSUM_80", "-g", "10", "-e", "1", "--evalue", "1e-10")])
+def test_reference_cli_other_matrices_gpu_equals_oracle_pipeline(tmp_path, args):
+    """`--matrix` / `-g` / `-e` / `--evalue` of the reference CLI (main.cpp:101-121,304-314) with tables other than the default --
+    BLOSUM_45 14/2, the help text's "BLOSUM_30" (= PAM 30) 9/1, BLOSUM_80 10/1 with a tighter cut: the MI355X run and the same
+    binary on the oracle stand-in (tests/cpu_shim) must write the same alignments.txt and the same .SIFTprediction files, byte
+    for byte (scores, e-values from each matrix's own Gumbel row, paths, selection, SIFT statistics)."""
+    tf = os.path.join(GOLDEN, "test_files")
+    shim = os.path.join(ROOT, "tests", "cpu_shim")
+    subprocess.run(["make", "-s", "-C", shim], check=True, capture_output=True, timeout=300)
+    outs = {}
+    for name, env in (("gpu", dict(os.environ)),
+                      ("oracle", dict(os.environ, LD_LIBRARY_PATH=os.path.join(shim, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", "")))):
+        d = tmp_path / name
+        d.mkdir()
+        r = subprocess.run([DROPIN, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d", os.path.join(tf, "sample_protein_database.fa"),
+                            "--out", str(d), "--cards", "0", "--sub-results", *args], env=env, capture_output=True, text=True, timeout=600, cwd=str(d))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "[WARNING]" not in r.stderr, r.stderr[-500:]            # every one of these penalty pairs has a published row
+        outs[name] = {n: (d / n).read_bytes() for n in sorted(os.listdir(d)) if n.endswith((".SIFTprediction", "alignments.txt"))}
+    assert outs["gpu"] and outs["gpu"].keys() == outs["oracle"].keys()
+    for n in outs["gpu"]:
+        assert outs["gpu"][n] == outs["oracle"][n], n
+    assert outs["gpu"]["alignments.txt"].count(b"\n") >= 8
+    assert outs["gpu"]["alignments.txt"] != open(os.path.join(GOLDEN, "dropin_predictions", "alignments.txt"), "rb").read()

@@ -402,3 +402,71 @@ def test_evalue_reaches_the_textbook_limit_for_long_sequences():
         assert er.evalue(score, m, n, n, P) == pytest.approx(v[0], rel=1e-12)
         assert 0.999 < v[0] / classic < 1.0
     L.deleteEValueParams(ev); L.chainDelete(q); L.chainDelete(t); L.scorerDelete(s)
+
+
+def _read_parts(path, chunk):
+    """-> (serialized flag, [[(name, codes) of part 1], [... part 2], ...]) through readFastaChainsPartInit / Part"""
+    chains, n, fh, ser = pvp(), ci(0), vp(), ci(0)
+    L.readFastaChainsPartInit(ctypes.byref(chains), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), str(path).encode())
+    parts, start = [], 0
+    while True:
+        more = L.readFastaChainsPart(ctypes.byref(chains), ctypes.byref(n), fh, ser.value, chunk)
+        parts.append([(L.chainGetName(chains[i]).decode(), tuple(sw.chain_codes(chains[i]))) for i in range(start, n.value)])
+        start = n.value
+        if not more:
+            break
+    sw.libc.fclose.argtypes = [vp]
+    sw.libc.fclose(fh)
+    L.deleteFastaChains(chains, n.value)
+    return ser.value, parts
+
+
+def test_serialized_database_cache(tmp_path, monkeypatch):
+    """the `serialized` flag of the FASTA readers (database_search.cpp:80-82,96-97; database_alignment.cpp:36,47): with
+    S4G_FASTA_CACHE=1 the first complete pass over a file writes `<path>.s4gchains`, later passes read it (serialized = 1) and
+    return the same chains in the same parts; a pass abandoned half-way leaves nothing behind; a cache whose FASTA file changed is
+    ignored and rewritten; without the variable nothing is written and serialized stays 0."""
+    rng = np.random.default_rng(5)
+    recs = [(f"sp|P{i:05d}|X{i} some description {i}", "".join(chr(65 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(0, 400)))))
+            for i in range(60)]
+    recs[7] = ("empty_record", "")
+    text = ""
+    for k, (name, seq) in enumerate(recs):
+        eol = "\r\n" if k % 3 == 0 else "\n"
+        width = [60, 7, 1000][k % 3]
+        text += ">" + name + eol + "".join(seq[i:i + width] + eol for i in range(0, len(seq), width))
+    fa = tmp_path / "db.fa"
+    fa.write_text(text)
+    cache = tmp_path / "db.fa.s4gchains"
+    monkeypatch.delenv("S4G_FASTA_CACHE", raising=False)
+    for chunk in (0, 1000, 257, 100000):
+        ser, want = _read_parts(fa, chunk)
+        assert ser == 0 and not cache.exists()
+        assert [n for p in want for n, _ in p] == [n for n, _ in recs]
+        assert [c for p in want for _, c in p] == [tuple(ord(x) - 65 for x in s) for _, s in recs]
+        monkeypatch.setenv("S4G_FASTA_CACHE", "1")
+        ser1, first = _read_parts(fa, chunk)               # writes the cache
+        assert ser1 == 0 and cache.exists() and first == want
+        ser2, second = _read_parts(fa, chunk)              # reads it
+        assert ser2 == 1 and second == want, chunk          # same records, same part boundaries
+        cache.unlink()
+        monkeypatch.delenv("S4G_FASTA_CACHE")
+    monkeypatch.setenv("S4G_FASTA_CACHE", "1")
+    # abandoned half-way: no cache, no temporary file
+    chains, n, fh, ser = pvp(), ci(0), vp(), ci(0)
+    L.readFastaChainsPartInit(ctypes.byref(chains), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), str(fa).encode())
+    assert L.readFastaChainsPart(ctypes.byref(chains), ctypes.byref(n), fh, ser.value, 500) == 1
+    sw.libc.fclose(fh)
+    L.deleteFastaChains(chains, n.value)
+    L.readFastaChainsPartInit(ctypes.byref(chains), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), str(fa).encode())   # drops the old state
+    L.readFastaChainsPart(ctypes.byref(chains), ctypes.byref(n), fh, ser.value, 0)
+    sw.libc.fclose(fh); L.deleteFastaChains(chains, n.value)
+    assert cache.exists() and sorted(p.name for p in tmp_path.iterdir()) == ["db.fa", "db.fa.s4gchains"]
+    # the FASTA file changes: the stale cache is not used, and is replaced
+    os.utime(cache, None)
+    fa.write_text(text + ">late\nACDEFGHIK\n")
+    os.utime(fa, (1_700_000_000, 1_700_000_000))
+    ser, parts = _read_parts(fa, 0)
+    assert ser == 0 and parts[0][-1] == ("late", tuple(ord(x) - 65 for x in "ACDEFGHIK"))
+    ser, again = _read_parts(fa, 0)
+    assert ser == 1 and again == parts
