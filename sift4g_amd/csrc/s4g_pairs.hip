@@ -477,7 +477,11 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
         if (!(flags & S4G_PAIRS_FORCE_WAVE) && ((flags & S4G_PAIRS_FORCE_LISTS) || n_wave >= kListsMinPairs)) {
             int rc = score_lists_device(db, q, scorer, all_wave ? nullptr : wave_sel.data(), (uint32_t)n_wave, pair_q, pair_t, h_scores,
                                         (flags & S4G_PAIRS_FORCE_LISTS) != 0, (flags & S4G_PAIRS_FORCE_LISTS) ? (flags >> 8) : 0u, &used);
-            if (rc) return rc;
+            if (rc && (flags & S4G_PAIRS_FORCE_LISTS)) return rc;
+            if (rc) {       // the list route needs gigabytes of workspace; if it cannot have them the pair waves still can do the job
+                (void)hipGetLastError();
+                used = false;
+            }
         }
         if (!used) {
             if (all_wave) { wave_sel.resize(n_wave); std::iota(wave_sel.begin(), wave_sel.end(), 0u); }
