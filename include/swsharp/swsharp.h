@@ -62,7 +62,11 @@ const char* chainGetCodes(Chain* chain);                                    /* r
 void readFastaChains(Chain*** chains, int* chainsLen, const char* path);
 void readFastaChainsPartInit(Chain*** chains, int* chainsLen, FILE** handle, int* serialized, const char* path);
 int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, int serialized, const size_t maxBytes);
-void deleteFastaChains(Chain** chains, int chainsLen);                      /* skips NULL entries */
+void deleteFastaChains(Chain** chains, int chainsLen);
+/* Extension: totals of a FASTA file (records, residues as chainGetLength counts them) without keeping any chain: from the header of
+ * the serialized cache when there is a valid one (S4G_FASTA_CACHE=1), else by one pass over the file.  Used by the full-scan
+ * build in place of the k-mer prefilter's pass (sift4g_amd/csrc/dropin/count_database_search.cpp). */
+void fastaResidueCount(const char* path, long long* records, long long* residues);                      /* skips NULL entries */
 
 /* ---- Scorer (main.cpp:208,223; names main.cpp:304-314) ---- */
 void scorerCreateMatrix(Scorer** scorer, char* name, int gapOpen, int gapExtend);

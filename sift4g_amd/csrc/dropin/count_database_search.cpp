@@ -18,29 +18,12 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
                         int32_t queries_length, uint32_t kmer_length, uint32_t max_candidates, uint32_t num_threads) {
     (void)queries; (void)kmer_length; (void)max_candidates; (void)num_threads;
     fprintf(stderr, "** Searching database for candidate sequences **\n");
-    Chain** database = nullptr;
-    int database_length = 0;
-    FILE* handle = nullptr;
-    int serialized = 0;
-    readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
-    const size_t kChunk = 250000000;          // the reference's own part size for this stage (database_search.cpp:17)
-    uint64_t cells = 0;
-    int start = 0;
-    for (uint32_t part = 1;; ++part) {
-        const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunk);
-        databaseLog(part, kChunk / 1e9f, 0);
-        for (int i = start; i < database_length; ++i) {
-            cells += (uint64_t)chainGetLength(database[i]);
-            chainDelete(database[i]);
-            database[i] = nullptr;
-        }
-        databaseLog(part, kChunk / 1e9f, 100);
-        start = database_length;
-        if (!more) break;
-    }
+    long long records = 0, residues = 0;
+    databaseLog(1, 0.25f, 0);
+    fastaResidueCount(database_path.c_str(), &records, &residues);     // one pass over the file -- or the header of its serialized cache
+    databaseLog(1, 0.25f, 100);
     fprintf(stderr, "\n\n");
-    fclose(handle);
-    deleteFastaChains(database, database_length);
+    const uint64_t cells = (uint64_t)residues;
     dst.assign((size_t)queries_length, std::vector<uint32_t>());
     return cells;
 }

@@ -108,6 +108,10 @@ SW_API char chainGetCode(Chain* chain, int index) { return chainGetCodes(chain)[
 // ------------------------------------------------------------------------------------------------ FASTA
 namespace {
 
+// header of the serialized chain cache (see below)
+// records / residues: totals of the file, patched into the header when the writing pass completes (fastaResidueCount reads them)
+struct CacheHeader { char magic[8]; uint64_t fasta_size; int64_t fasta_mtime; uint64_t records, residues; };
+
 struct FastaState {              // one per open handle; keeps the look-ahead header and the read buffer between parts
     FILE* fh;
     std::string pending_name;
@@ -123,6 +127,8 @@ struct FastaState {              // one per open handle; keeps the look-ahead he
     // ... or it reads FASTA text and WRITES the cache beside it, renamed into place when the whole file has been read
     FILE* cache_out = NULL;
     std::string cache_tmp, cache_final;
+    uint64_t cache_records = 0, cache_residues = 0;      // written so far (residues as the chains count them: after the residue table)
+    CacheHeader cache_header;
 };
 
 // ---- serialized chain cache ------------------------------------------------------------------------------------------
@@ -134,8 +140,8 @@ struct FastaState {              // one per open handle; keeps the look-ahead he
 // boundaries are exactly those of the text reader (same bytes through the same residue table, a part ends with the record
 // that reaches maxBytes), so the reference's results do not depend on which of the two it was given.  Off by default:
 // nothing is written next to the user's database unless asked.
-const char kCacheMagic[8] = {'S', '4', 'G', 'C', 'H', 'N', '1', 0};
-struct CacheHeader { char magic[8]; uint64_t fasta_size; int64_t fasta_mtime; };
+const char kCacheMagic[8] = {'S', '4', 'G', 'C', 'H', 'N', '2', 0};
+
 
 bool fasta_cache_enabled() { const char* v = getenv("S4G_FASTA_CACHE"); return v && *v && strcmp(v, "0") != 0; }
 
@@ -147,7 +153,7 @@ bool stat_file(const char* path, uint64_t* size, int64_t* mtime) {
 }
 
 // the cache of `path` if it exists and was made from the file as it is now
-FILE* open_valid_cache(const char* path) {
+FILE* open_valid_cache(const char* path, CacheHeader* header = NULL) {
     uint64_t size; int64_t mtime;
     if (!stat_file(path, &size, &mtime)) return NULL;
     const std::string cache = std::string(path) + ".s4gchains";
@@ -158,6 +164,7 @@ FILE* open_valid_cache(const char* path) {
         fclose(fh);
         return NULL;
     }
+    if (header) *header = h;
     return fh;
 }
 
@@ -208,6 +215,8 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
         d->chars[d->length] = 0;
         push_chain(chains, len, &cap, make_chain(d, 0, d->length, false));
         if (st->cache_out) {
+            ++st->cache_records;
+            st->cache_residues += (uint64_t)d->length;
             const uint32_t hdr[2] = {(uint32_t)st->pending_name.size(), (uint32_t)st->seq.size()};
             if (fwrite(hdr, sizeof hdr, 1, st->cache_out) != 1 ||
                 (hdr[0] && fwrite(st->pending_name.data(), hdr[0], 1, st->cache_out) != 1) ||
@@ -264,8 +273,11 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
             st->have_pending = true;
         }
         flush();
-        if (st->cache_out) {              // the whole file has been read: the cache becomes visible under its final name
-            const bool ok = fclose(st->cache_out) == 0;
+        if (st->cache_out) {              // the whole file has been read: totals into the header, then the cache becomes visible under its final name
+            st->cache_header.records = st->cache_records;
+            st->cache_header.residues = st->cache_residues;
+            bool ok = fseek(st->cache_out, 0, SEEK_SET) == 0 && fwrite(&st->cache_header, sizeof(CacheHeader), 1, st->cache_out) == 1;
+            ok = (fclose(st->cache_out) == 0) && ok;
             st->cache_out = NULL;
             if (!ok || rename(st->cache_tmp.c_str(), st->cache_final.c_str()) != 0) remove(st->cache_tmp.c_str());
         }
@@ -326,8 +338,8 @@ SW_API void readFastaChainsPartInit(Chain*** chains, int* chainsLen, FILE** hand
         st->cache_tmp = st->cache_final + ".tmp" + std::to_string((long long)getpid());
         st->cache_out = fopen(st->cache_tmp.c_str(), "wb");
         if (st->cache_out) {
-            CacheHeader h;
-            memcpy(h.magic, kCacheMagic, 8); h.fasta_size = size; h.fasta_mtime = mtime;
+            CacheHeader& h = st->cache_header;
+            memcpy(h.magic, kCacheMagic, 8); h.fasta_size = size; h.fasta_mtime = mtime; h.records = h.residues = 0;
             if (fwrite(&h, sizeof h, 1, st->cache_out) != 1) cache_abandon(st);
         }
     }
@@ -339,6 +351,37 @@ SW_API int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, in
     int more = st->serialized_in ? cache_read(st, chains, chainsLen, maxBytes) : fasta_read(st, chains, chainsLen, maxBytes);
     if (!more) fasta_forget(handle);   // caller fclose()s the handle itself (database_alignment.cpp:122)
     return more;
+}
+
+// Totals of a FASTA file: records and residues (as chainGetLength counts them).  With a valid serialized cache beside the
+// file (S4G_FASTA_CACHE=1) they come out of its header; otherwise the file is read once, part by part (which writes the cache
+// if caching is on).  What the full-scan build's "prefilter" stage needs from the database (total residues for the e-value
+// statistics, main.cpp:204,210) and nothing else.
+SW_API void fastaResidueCount(const char* path, long long* records, long long* residues) {
+    CacheHeader h;
+    if (fasta_cache_enabled()) {
+        FILE* fh = open_valid_cache(path, &h);
+        if (fh) {
+            fclose(fh);
+            if (records) *records = (long long)h.records;
+            if (residues) *residues = (long long)h.residues;
+            return;
+        }
+    }
+    Chain** chains = NULL; int n = 0; FILE* handle = NULL; int serialized = 0;
+    readFastaChainsPartInit(&chains, &n, &handle, &serialized, path);
+    long long cells = 0;
+    int start = 0;
+    for (;;) {
+        const int more = readFastaChainsPart(&chains, &n, handle, serialized, 250000000);
+        for (int i = start; i < n; ++i) { cells += chainGetLength(chains[i]); chainDelete(chains[i]); chains[i] = NULL; }
+        start = n;
+        if (!more) break;
+    }
+    fclose(handle);
+    if (records) *records = n;
+    if (residues) *residues = cells;
+    deleteFastaChains(chains, n);
 }
 
 SW_API void readFastaChains(Chain*** chains, int* chainsLen, const char* path) {

@@ -12,6 +12,7 @@ from conftest import GOLDEN, ROOT
 import dropin_synth
 
 DROPIN = os.path.join(ROOT, "build", "dropin", "sift4g")
+FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
 SHIM = os.path.join(ROOT, "tests", "cpu_shim")
 
 
@@ -132,3 +133,13 @@ def test_reference_cli_with_the_serialized_database_cache(tmp_path):
         for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
             assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), (run, n)
     assert sorted(p.name for p in tmp_path.iterdir() if p.is_file()) == ["db.fa", "db.fa.s4gchains"]
+    # the full-scan build with the cache: its counting stage takes the totals from the cache header (fastaResidueCount), its
+    # alignment stage reads the cached chains: the files of the uncached full-scan run
+    if os.path.exists(FULLSCAN):
+        out = tmp_path / "fullscan"
+        out.mkdir()
+        r = subprocess.run([FULLSCAN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep, "-d", str(db), "--cards", "0",
+                            "--out", str(out), "--sub-results"], env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+            assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_fullscan", n), "rb").read(), n

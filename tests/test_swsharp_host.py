@@ -470,3 +470,11 @@ def test_serialized_database_cache(tmp_path, monkeypatch):
     assert ser == 0 and parts[0][-1] == ("late", tuple(ord(x) - 65 for x in "ACDEFGHIK"))
     ser, again = _read_parts(fa, 0)
     assert ser == 1 and again == parts
+    # totals of the file (what the full-scan build's counting stage asks for): from the cache header, or by a pass over the text
+    want_res = sum(len(c) for _, c in parts[0])
+    for env in ("1", None):
+        if env is None:
+            monkeypatch.delenv("S4G_FASTA_CACHE")
+        rec, res = ctypes.c_longlong(-1), ctypes.c_longlong(-1)
+        L.fastaResidueCount(str(fa).encode(), ctypes.byref(rec), ctypes.byref(res))
+        assert (rec.value, res.value) == (len(parts[0]), want_res), env
