@@ -81,7 +81,7 @@ int warm_list_kernels(DeviceCtx* cx) {
 int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used) {
     *used = false;
-    if (n_sel == 0) return S4G_OK;
+    if (n_sel == 0 || n_sel >= (1u << 31)) return S4G_OK;        // (the device sort counts its entries in an int)
     // the pairs of this call: sel_idx[0 .. n_sel), or 0 .. n_sel when sel_idx is NULL (every pair of the caller's arrays)
     struct Sel {
         const uint32_t* idx; uint32_t n;

@@ -181,3 +181,33 @@ def test_configs4_long_queries_full_size(s4g, oracle_mod):
     assert torch.equal(got, by_bound)
     planted = [(a, b) for a, b in cfg["planted"] if a < 8]
     _oracle_sample(oracle_mod, cfg, got, 1500, planted, 31)
+
+
+def test_streaming_topk_over_several_query_batches(s4g):
+    """s4g_scan_topk cuts the queries into batches when a [queries][tile columns] buffer would pass 4 GB (configs[3] has 10 000
+    queries): 2 500 short queries x 600 000 short targets need two batches (1 789 + 711).  Every list must equal the top-50 of the
+    full score matrix, which itself is compared with the int32 kernel on a query range."""
+    from sift4g_amd import synth
+    rng = np.random.default_rng(77)
+    nq, nt = 2500, 600_000
+    ql = rng.integers(30, 61, nq)
+    tl = rng.integers(20, 61, nt)
+    q_codes, q_off = synth.random_set(synth.SEED_BASE + 0x77, ql)
+    t_codes, t_off = synth.random_set(synth.SEED_BASE + 0x78, tl)
+    for i in range(0, nq, 25):                                            # a copy of every 25th query somewhere in the database
+        t = int(rng.integers(0, nt))
+        m = min(int(ql[i]), int(tl[t]))
+        t_codes[int(t_off[t]):int(t_off[t]) + m] = q_codes[int(q_off[i]):int(q_off[i]) + m]
+    db = s4g.Database(codes=t_codes, offsets=t_off)
+    q = s4g.QuerySet(codes=q_codes, offsets=q_off)
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    full = torch.empty((nq, nt), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, full)
+    part = torch.empty((64, nt), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, part, q_begin=1780, q_count=64, force_i32=True, no_drift=True)
+    assert torch.equal(part, full[1780:1844])
+    ids, sc, cnt = s4g.topk_device(db, full, 50, 1)
+    del full, part
+    sids, ssc, scnt = s4g.scan_topk(db, q, scorer, 50, 1)
+    assert torch.equal(cnt, scnt) and torch.equal(sc, ssc) and torch.equal(ids, sids)
+    assert int(sc[:, 0].max()) > 150
