@@ -15,11 +15,13 @@ namespace {
 
 constexpr int kListRows = 32;                        // strip height of sw_scan_lists
 constexpr uint64_t kListResSlack = 1024;             // dwords behind the gathered residues (an item of empty targets still reads one row)
-// Rates the split is chosen with (tools/lists_bench.py, profiles/r02_lists): cells per second of a chip full of list items
-// and of pair waves, and the cycles one resident list wave needs per row pair and column when it shares its SIMD.
-constexpr double kListChipRate = 8.3e12, kListWaveChipRate = 2.8e12;
-constexpr double kListCyclesPerRowCol = 64.0, kClockHz = 2.4e9;     // measured on the longest item of a launch at raised priority: one wave
-                                                                    // issues a dependent packed op every ~8.5 clocks however idle its SIMD is
+// Rates the split is chosen with (tools/lists_bench.py on 70k .. 729k pairs, profiles/r02_lists): cells per second of a chip full
+// of list items -- PADDED cells: a 128-candidate item runs to its longest member -- and of pair waves; the clocks per row and
+// column the block that holds the launch's longest item needs (four waves pipelining its strips); the items it takes to fill
+// the chip.
+constexpr double kListChipRate = 9.0e12, kListWaveChipRate = 2.8e12;
+constexpr double kListCyclesPerRowCol = 20.0, kListCyclesPerQueuedItem = 5.5, kClockHz = 2.4e9;
+constexpr double kListItemsToFill = 700.0;
 constexpr double kListFixedCost = 250e-6;            // sort + item tables + gather + one host round trip
 constexpr uint32_t kListMaxTarget = 4096;            // longer targets always go to the pair waves: the block workspace is 2 KB per residue
                                                      // of the longest member and block (6.4 GB at 4096 residues on 768 blocks)
@@ -37,15 +39,25 @@ inline uint64_t align256(uint64_t x) { return (x + 255) / 256 * 256; }
 }  // namespace
 
 // How long would the call take if pairs with targets up to `ls` residues went to the list kernel and the rest to pair waves?
-// cells_le[b] = cells of all eligible pairs with target length < 64 (b + 1); everything else goes to waves.
-static double lists_cost(const std::vector<double>& cells_le, double cells_all, uint32_t lq_max, uint32_t ls, uint32_t lt_max_all) {
-    const size_t b = std::min<size_t>(cells_le.size() - 1, ls / 64);
-    const double c_list = ls == 0 ? 0.0 : cells_le[b];
-    const double c_wave = cells_all - c_list;
-    const double chip = c_list / kListChipRate + c_wave / kListWaveChipRate;          // both parts share the chip
-    // a launch cannot end before the wave that holds its longest item has walked all rows x columns of it
-    const double lat_list = c_list > 0 ? (double)lq_max * std::min<double>(ls, lt_max_all) * kListCyclesPerRowCol / kClockHz : 0.0;
-    return std::max(chip, lat_list) + (c_list > 0 ? kListFixedCost : 0.0);
+//   cells_le[b] / pad_le[b] / pairs_le[b] = true cells, padding cells and pairs of all eligible pairs with target length
+//   < 64 (b + 1); everything else goes to waves.  The padding estimate: a query's candidates sorted by length and cut into
+//   items of 128 -- an item at length L spans 128 / (that query's candidates per residue of length around L), and its members
+//   run half that span longer than they are, on average.
+struct ListHist { std::vector<double> cells_le, pad_le, pairs_le; double cells_all = 0; uint32_t lq_max = 0, lt_max = 0; };
+static double lists_cost(const ListHist& h, uint32_t ls) {
+    const size_t b = std::min<size_t>(h.cells_le.size() - 1, ls / 64);
+    const double c_list = ls == 0 ? 0.0 : h.cells_le[b];
+    const double c_wave = h.cells_all - c_list;
+    if (c_list <= 0) return c_wave / kListWaveChipRate;
+    const double items = h.pairs_le[b] / 128.0;
+    const double fill = std::min(1.0, items / kListItemsToFill);            // fewer items than blocks: part of the chip idles
+    const double chip = (c_list + h.pad_le[b]) / (kListChipRate * fill) + c_wave / kListWaveChipRate;     // both parts share the chip
+    // a launch cannot end before the block that holds its longest item has walked all rows x columns of it
+    // ... at a rate that falls as the queue fills: with one item per block its four waves have their SIMDs nearly to themselves,
+    // with seven they share them three ways for the whole launch (fitted: forced splits of 70k / 200k / 250k / 729k pairs)
+    const double clocks = kListCyclesPerRowCol + kListCyclesPerQueuedItem * items / kListItemsToFill;
+    const double lat_list = (double)h.lq_max * std::min<double>(ls, h.lt_max) * clocks / kClockHz;
+    return std::max(chip, lat_list) + kListFixedCost;
 }
 
 int warm_list_kernels(DeviceCtx* cx) {
@@ -151,12 +163,26 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
             for (size_t b = 0; b < n_buckets; ++b) { cells_le[b] += P.cells[b]; pairs_in[b] += P.pairs[b]; }
         }
     }
-    for (size_t b = 1; b < cells_le.size(); ++b) cells_le[b] += cells_le[b - 1];
+    ListHist hist;
+    hist.cells_all = cells_all; hist.lq_max = lq_max; hist.lt_max = lt_max;
+    hist.cells_le = cells_le; hist.pad_le.assign(n_buckets, 0.0); hist.pairs_le.assign(n_buckets, 0.0);
+    {
+        uint32_t nq_used = 0;
+        for (uint32_t i = 0; i < q->n; ++i) nq_used += lt_cap[i] != 0;
+        const double lq_mean = rows_all / (double)n_sel;
+        for (size_t b = 0; b < n_buckets; ++b) {
+            // span of an item around this length: 128 candidates at (pairs_in[b] / 64 residues / queries) candidates per residue
+            const double span = pairs_in[b] ? std::min<double>(64.0 * b + 64.0, 128.0 * 64.0 * std::max(1u, nq_used) / (double)pairs_in[b]) : 0.0;
+            hist.pad_le[b] = (double)pairs_in[b] * lq_mean * span * 0.5 + (b ? hist.pad_le[b - 1] : 0.0);
+            hist.pairs_le[b] = (double)pairs_in[b] + (b ? hist.pairs_le[b - 1] : 0.0);
+            if (b) hist.cells_le[b] += hist.cells_le[b - 1];
+        }
+    }
     uint32_t best_ls = 0;
-    double best_t = lists_cost(cells_le, cells_all, lq_max, 0, lt_max);
+    double best_t = lists_cost(hist, 0);
     const double all_waves = best_t;
     for (uint32_t ls = 127; ls < std::min(lt_max, kListMaxTarget) + 64; ls += 64) {
-        const double t = lists_cost(cells_le, cells_all, lq_max, ls, lt_max);
+        const double t = lists_cost(hist, ls);
         if (t < best_t) { best_t = t; best_ls = ls; }
     }
     if (force) best_ls = forced_split ? forced_split : std::max(lt_max, 1u);      // everything the window admits (up to the caller's cut)
