@@ -66,6 +66,15 @@ dropin-fullscan: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/fullscan_databas
 	    sift4g_amd/csrc/dropin/fullscan_database_alignment.cpp sift4g_amd/csrc/dropin/count_database_search.cpp \
 	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
+# The reference's own prefilter (database_search.cpp, hash.cpp, utils.cpp: compiled where they lie) behind a main that prints
+# the candidate lists: the generator of tests/golden/prefilter/ (tools/ref_prefilter_dump.cpp explains what it is and is not).
+dropin-prefilter-dump: $(LIBDIR)/libswsharp.so tools/ref_prefilter_dump.cpp
+	@test -d $(REF)/sift4g/src || { echo "no reference tree at $(REF): skipping drop-in build"; exit 0; }
+	@mkdir -p build/dropin
+	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -I$(REF)/sift4g/src -o build/dropin/ref_prefilter_dump \
+	    $(REF)/sift4g/src/database_search.cpp $(REF)/sift4g/src/hash.cpp $(REF)/sift4g/src/utils.cpp tools/ref_prefilter_dump.cpp \
+	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
 oracle:
 	$(MAKE) -s -C oracle
 
@@ -77,4 +86,4 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan
+.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan dropin-prefilter-dump

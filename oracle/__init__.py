@@ -50,6 +50,17 @@ def lib():
         L.s4g_oracle_scan_simd.argtypes = [_u8p, _u64p, ctypes.c_uint32, _u8p, _u64p, ctypes.c_uint32,
                                            _i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p]
         L.s4g_oracle_scan_simd.restype = ctypes.c_int
+        _f32p = ctypes.POINTER(ctypes.c_float)
+        L.s4g_oracle_prefilter_create.argtypes = [_u8p, _u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        L.s4g_oracle_prefilter_create.restype = ctypes.c_void_p
+        L.s4g_oracle_prefilter_add.argtypes = [ctypes.c_void_p, _u8p, _u64p, ctypes.c_uint32, ctypes.c_uint32]
+        L.s4g_oracle_prefilter_add.restype = None
+        L.s4g_oracle_prefilter_finish.argtypes = [ctypes.c_void_p, _u32p, _u32p, _f32p, _f32p]
+        L.s4g_oracle_prefilter_finish.restype = None
+        L.s4g_oracle_prefilter_lis.argtypes = [ctypes.c_void_p, _u8p, _u64p, ctypes.c_uint32, _i32p]
+        L.s4g_oracle_prefilter_lis.restype = None
+        L.s4g_oracle_prefilter_destroy.argtypes = [ctypes.c_void_p]
+        L.s4g_oracle_prefilter_destroy.restype = None
         _LIB = L
     return _LIB
 
@@ -140,3 +151,47 @@ def pairs_flat(qcodes, qoff, tcodes, toff, pair_q, pair_t, M, gap_open=10, gap_e
                                len(toff) - 1, _p(pair_q, _u32p), _p(pair_t, _u32p), len(pair_q),
                                _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p))
     return out
+
+
+class Prefilter:
+    """The k-mer prefilter restated (oracle/kmer_prefilter.c; /root/reference/sift4g/src/database_search.cpp:66-280,
+    hash.cpp:21-90).  add() takes database chunks in order; finish() -> (ids, counts, scores, cut): rows of max_candidates,
+    ids ascending, ties at the cut to the lower database index."""
+
+    def __init__(self, queries, kmer_length=5, max_candidates=5000):
+        qc, qo = _flat(queries)
+        self.nq, self.max_candidates = len(queries), int(max_candidates)
+        self._h = lib().s4g_oracle_prefilter_create(_p(qc, _u8p), _p(qo, _u64p), self.nq, kmer_length, self.max_candidates)
+        if not self._h:
+            raise ValueError("kmer_length must be 3, 4 or 5")
+        self.next_id = 0
+
+    def add(self, targets):
+        tc, to = _flat(targets)
+        lib().s4g_oracle_prefilter_add(self._h, _p(tc, _u8p), _p(to, _u64p), len(targets), self.next_id)
+        self.next_id += len(targets)
+
+    def lis(self, targets):
+        """dense [nq, nt] LIS lengths of one chunk (0 = no hit); does not touch the candidate lists"""
+        tc, to = _flat(targets)
+        out = np.zeros((self.nq, len(targets)), dtype=np.int32)
+        if self.nq and len(targets):
+            lib().s4g_oracle_prefilter_lis(self._h, _p(tc, _u8p), _p(to, _u64p), len(targets), _p(out, _i32p))
+        return out
+
+    def finish(self):
+        f32p = ctypes.POINTER(ctypes.c_float)
+        ids = np.zeros((self.nq, max(self.max_candidates, 1)), dtype=np.uint32)
+        scores = np.zeros(ids.shape, dtype=np.float32)
+        counts = np.zeros(max(self.nq, 1), dtype=np.uint32)
+        cut = np.zeros(max(self.nq, 1), dtype=np.float32)
+        lib().s4g_oracle_prefilter_finish(self._h, _p(ids, _u32p), _p(counts, _u32p), _p(scores, f32p), _p(cut, f32p))
+        return ids, counts[: self.nq], scores, cut[: self.nq]
+
+    def close(self):
+        if self._h:
+            lib().s4g_oracle_prefilter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

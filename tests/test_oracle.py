@@ -4,11 +4,18 @@ The reference holds no golden vectors for this path: the oracle i
 against swsharp and is pinned instead by hand-computed known answers, the published
 Karlin-Altschul statistics of BLOSUM62, and identities on the reference's own input fixtures.
 """
+import json
+import os
+import sys
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
 
-from conftest import rand_seqs
+from conftest import ROOT, rand_seqs
+
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
 
 
 def test_micro_known_answers(oracle_mod, blosum62, micro):
@@ -225,3 +232,71 @@ def test_simd_port_equals_scalar_oracle(oracle_mod, blosum62):
         b = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, go, ge, threads=3)
         assert np.array_equal(a, b), (go, ge, np.argwhere(a != b)[:5])
     assert a[7, 83] == 3100 * 11          # > 32767: went through the scalar recheck
+
+
+# ---- the k-mer prefilter: oracle/kmer_prefilter.c against what the reference's own code printed ----
+
+def _prefilter_case(c):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_prefilter_golden as g
+    queries, targets = g.make_case(c["seed"], c["nq"], c["nt"], c["repeats"])
+    return [oracle.encode(q) for q in queries], [oracle.encode(t) for t in targets]
+
+
+def test_prefilter_matches_the_reference_code():
+    """tests/golden/prefilter.json holds the candidate lists the reference's database_search.cpp + hash.cpp returned (at 1 and
+    4 threads) on seeded inputs (tests/golden/make_prefilter_golden.py).  Where max_candidates did not bind the restatement
+    must return exactly that list; where it did, the same number of candidates, every one the reference keeps regardless of
+    its thread count, and nothing below the cut."""
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "prefilter.json")))
+    assert len(cases) >= 6
+    for c in cases:
+        queries, targets = _prefilter_case(c)
+        assert sum(len(t) for t in targets) == c["cells"]
+        for chunks in (1, 3):                                  # the same lists whether the database arrives whole or in chunks
+            pf = oracle.Prefilter(queries, c["k"], c["max_candidates"])
+            step = (len(targets) + chunks - 1) // chunks
+            for o in range(0, len(targets), step):
+                pf.add(targets[o:o + step])
+            ids, counts, scores, cut = pf.finish()
+            for q, want in enumerate(c["lists"]):
+                got = [int(x) for x in ids[q, :counts[q]]]
+                assert got == sorted(got)
+                if "exact" in want:
+                    assert got == want["exact"], (c["name"], q)
+                else:
+                    assert len(got) == want["size"], (c["name"], q)
+                    assert set(want["must"]) <= set(got), (c["name"], q)
+                    assert (scores[q, :counts[q]] >= cut[q]).all()
+
+
+def test_prefilter_hand_cases():
+    """Small cases worked by hand from the reference's text."""
+    enc = oracle.encode
+    # one shared 5-mer -> LIS 1; score 1 / len(target)
+    pf = oracle.Prefilter([enc("AAAAACDEFGAAAAA")], 5, 10)
+    L = pf.lis([enc("WWWCDEFGWWW"), enc("CDEF"), enc("WWWWWWWW")])
+    assert L.tolist() == [[1, 0, 0]]
+    # consecutive equal k-mers of the TARGET are looked up once (database_search.cpp:212): poly-A target of 30 has 26 k-mers,
+    # all equal -> one lookup, which hits every poly-A position of the query: positions 0..5 ascending -> LIS 6
+    pf = oracle.Prefilter([enc("AAAAAAAAAA")], 5, 10)              # 6 k-mers, all AAAAA, positions 0..5
+    assert pf.lis([enc("A" * 30)]).tolist() == [[6]]
+    # ... but an alternating repeat is not skipped: target k-mers QAQAQ, AQAQA, QAQAQ, ... each hit all matching positions
+    pf = oracle.Prefilter([enc("QAQAQAQA")], 5, 10)                # k-mers: QAQAQ@0, AQAQA@1, QAQAQ@2, AQAQA@3
+    # target QAQAQAQ: k-mers QAQAQ, AQAQA, QAQAQ -> hit list [0,2, 1,3, 0,2] -> strict LIS = 0,1,2 or 0,2,3 -> 3
+    assert pf.lis([enc("QAQAQAQ")]).tolist() == [[3]]
+    # the LIS is strict and taken over query positions in target order: a reversed arrangement scores 1 per block
+    q = "ACDEFGHIKLMNPQRSTVWY"
+    pf = oracle.Prefilter([enc(q)], 5, 10)
+    assert pf.lis([enc(q)]).tolist() == [[16]]                     # 16 k-mers in order
+    assert pf.lis([enc(q[10:] + q[:10])]).tolist() == [[6]]        # two blocks of 6 k-mers each, second block lower -> 6
+    # ties at the cut go to the lower database index; the score is a float division
+    pf = oracle.Prefilter([enc("CDEFGHIK")], 5, 2)
+    pf.add([enc("WWCDEFGWW"), enc("WWDEFGHWW"), enc("WWEFGHIWW"), enc("CDEFGHIK")])
+    ids, counts, scores, cut = pf.finish()
+    assert counts.tolist() == [2] and ids[0, :2].tolist() == [0, 3]
+    assert scores[0, 0] == np.float32(1) / np.float32(9) and scores[0, 1] == np.float32(4) / np.float32(8)
+    assert cut[0] == np.float32(1) / np.float32(9)
+    # k outside 3..5 is refused (main.cpp:169)
+    with pytest.raises(ValueError):
+        oracle.Prefilter([enc("ACDEFG")], 6, 10)
