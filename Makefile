@@ -1,7 +1,7 @@
 # Builds every native artefact in-tree (the .so files travel to the GPU box with the snapshot).
 #   make            -> sift4g_amd/lib/libs4g_hip.so (HIP, gfx950), sift4g_amd/lib/libswsharp.so (C++ host API),
 #                      oracle/libsw_oracle.so (test infrastructure)
-#   make dropin-batched / dropin-fullscan -> the same CLI with one / two of the reference's source files replaced (see below)
+#   make dropin-batched / dropin-fullscan / dropin-devsearch -> the same CLI with some of the reference's source files replaced (see below)
 #   make dropin     -> build/sift4g : the reference's own sift4g sources compiled IN PLACE from /root/reference
 #                      against include/swsharp/*.h and linked with our libraries (only where /root/reference exists)
 HIPCC   ?= /opt/rocm/bin/hipcc
@@ -22,7 +22,7 @@ build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 # libs4g_hip.so: one object per translation unit (make -j builds them side by side), every unit depends on every header
-HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip $(CSRC)/s4g_diag.hip $(CSRC)/s4g_lists.hip
+HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip $(CSRC)/s4g_diag.hip $(CSRC)/s4g_lists.hip $(CSRC)/s4g_prefilter.hip
 HIPOBJ  := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIPSRC))
 HIPHDR  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/s4g_hip.h
 
@@ -66,6 +66,17 @@ dropin-fullscan: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/fullscan_databas
 	    sift4g_amd/csrc/dropin/fullscan_database_alignment.cpp sift4g_amd/csrc/dropin/count_database_search.cpp \
 	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
+# The device-prefilter build: the k-mer prefilter's source files (database_search.cpp, hash.cpp) replaced by
+# device_database_search.cpp (index, hit lists, LIS and best lists on the device: s4g_prefilter_*) and the alignment wrapper by
+# the batched one.  main, selection and SIFT are the reference's own code.
+dropin-devsearch: $(LIBDIR)/libswsharp.so sift4g_amd/csrc/dropin/device_database_search.cpp sift4g_amd/csrc/dropin/batched_database_alignment.cpp
+	@test -d $(REF)/sift4g/src || { echo "no reference tree at $(REF): skipping drop-in build"; exit 0; }
+	@mkdir -p build/dropin
+	$(CXX) -std=c++11 -O2 -Wno-write-strings -Iinclude -I$(REF)/sift4g/src -o build/dropin/sift4g_devsearch \
+	    $(filter-out %/database_alignment.cpp %/database_search.cpp %/hash.cpp,$(wildcard $(REF)/sift4g/src/*.cpp)) \
+	    sift4g_amd/csrc/dropin/batched_database_alignment.cpp sift4g_amd/csrc/dropin/device_database_search.cpp \
+	    -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
 # The reference's own prefilter (database_search.cpp, hash.cpp, utils.cpp: compiled where they lie) behind a main that prints
 # the candidate lists: the generator of tests/golden/prefilter/ (tools/ref_prefilter_dump.cpp explains what it is and is not).
 dropin-prefilter-dump: $(LIBDIR)/libswsharp.so tools/ref_prefilter_dump.cpp
@@ -86,4 +97,4 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan dropin-prefilter-dump
+.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan dropin-devsearch dropin-prefilter-dump

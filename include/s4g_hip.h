@@ -251,6 +251,34 @@ int s4g_warmup(int device);
  * out[3] = the runtime's nominal clock in MHz, out[4] = duration of the probe kernel in ms.  cap >= 5.  ~50 ms. */
 int s4g_clock_probe(int device, double* out, uint32_t cap);
 
+/* ---- k-mer prefilter ------------------------------------------------------------------------------
+ * Replaces searchDatabase's compute (/root/reference/sift4g/src/database_search.cpp:66-253 with hash.cpp:21-90): the CSR
+ * index of the queries' k-mers (createHash, database_search.cpp:71-72), per database chunk the hit lists of every target
+ * against every query, their longest increasing subsequence, score = LIS / (float) target length (threadSearchDatabase,
+ * :185-253), and the running best max_candidates per query across chunks (:129-150).  All of it runs on the device; the
+ * caller keeps reading FASTA.  Results are the reference's for every candidate strictly above the score at the cut; among
+ * candidates whose score EQUALS it the reference's choice depends on its thread count and on std::sort, here the lower
+ * database index wins (one of the lists the reference can return).
+ *
+ *   s4g_prefilter_create   queries: codes 0..25, CSR offsets; kmer_length 3..5 (main.cpp:169); max_candidates >= 1
+ *   s4g_prefilter_add      one database chunk of host memory (may be freed on return): targets first_id .. first_id+n-1.
+ *                          Chunks must arrive in ascending id order.  Synchronous.
+ *   s4g_prefilter_add_device  the same with the chunk already in device memory (d_offsets: n+1 uint64)
+ *   s4g_prefilter_finish   h_ids / h_scores: n_queries rows of max_candidates; the first h_counts[q] of row q are valid, ids
+ *                          ascending as searchDatabase returns them (database_search.cpp:166-178).  h_scores may be NULL.
+ *                          May be called more than once; adding after it is allowed (it only reads the running lists).
+ *   s4g_prefilter_stats    out[0] = k-mer hits looked up so far, out[1] = (query, target) pairs with at least one hit,
+ *                          out[2] = of those, pairs whose LIS ran on a whole wave (more than 32 hits), out[3] = chunks. cap >= 4. */
+typedef struct s4g_prefilter s4g_prefilter;
+int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_queries,
+                         uint32_t kmer_length, uint32_t max_candidates);
+int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint64_t* offsets, uint32_t n_targets, uint32_t first_id);
+int s4g_prefilter_add_device(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_targets,
+                             uint32_t first_id);
+int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores);
+int s4g_prefilter_stats(const s4g_prefilter* p, uint64_t* out, uint32_t cap);
+int s4g_prefilter_destroy(s4g_prefilter* p);
+
 #ifdef __cplusplus
 }
 #endif

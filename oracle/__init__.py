@@ -189,8 +189,8 @@ class Prefilter:
         return ids, counts[: self.nq], scores, cut[: self.nq]
 
     def close(self):
-        if self._h:
-            lib().s4g_oracle_prefilter_destroy(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:       # module globals are already cleared at interpreter exit
+            _LIB.s4g_oracle_prefilter_destroy(self._h)
             self._h = None
 
     def __del__(self):

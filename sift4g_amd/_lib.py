@@ -79,6 +79,12 @@ SIGNATURES = {
     "s4g_clock_probe": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_u64p]),
+    "s4g_prefilter_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "s4g_prefilter_add": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_uint32]),
+    "s4g_prefilter_add_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
+    "s4g_prefilter_finish": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.POINTER(ctypes.c_float)]),
+    "s4g_prefilter_stats": (ctypes.c_int, [ctypes.c_void_p, c_u64p, ctypes.c_uint32]),
+    "s4g_prefilter_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  If our

@@ -1,0 +1,134 @@
+// device_database_search.cpp -- MI355X replacement for the reference's k-mer prefilter stage.
+//
+// Defines `searchDatabase(...)` with the signature the reference declares in
+// /root/reference/sift4g/src/database_search.hpp:17-19 and replaces the reference's database_search.cpp + hash.cpp in
+// `make dropin-devsearch`: a maintainer swaps these source files, nothing else.
+//
+// What it keeps (reference database_search.cpp:66-183): the database is read in ~250 MB parts with the swsharp FASTA
+// readers; every sequence of a part is scored against every query by shared k-mers (longest increasing subsequence of the
+// hit positions over the sequence's length); the best `max_candidates` per query survive across parts; the lists come back
+// as ascending database indices, and the function returns the number of database residues (the e-value search space,
+// main.cpp:204,210).  Same banner and progress lines on stderr.
+//
+// What it changes: the k-mer index of the queries, the hit lists, the LIS and the running best lists live on the device
+// (include/s4g_hip.h: s4g_prefilter_*), one submission per part, overlapped with the reading of the next part -- the host
+// threads of the reference's thread pool (:101-123) are not used, so `num_threads` no longer changes the result: among
+// candidates whose score EQUALS the score at the cut the reference's choice depends on it (and on std::sort), here the lower
+// database index always wins.  Every candidate strictly above the cut is the same.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <string>
+#include <vector>
+
+#include "utils.hpp"              // the reference's own: databaseLog
+#include "database_search.hpp"    // the reference's own: the declaration this file implements
+#include "s4g_hip.h"
+
+namespace {
+
+// ~250 MB of sequence per part, as the reference reads it (database_search.cpp:17); S4G_PREFILTER_CHUNK_BYTES overrides it
+// (the tests use it to run the several-parts logic -- running lists across parts, the overlap of reading and device work --
+// on small inputs)
+uint32_t chunk_bytes() {
+    const char* v = getenv("S4G_PREFILTER_CHUNK_BYTES");
+    const long long n = v ? atoll(v) : 0;
+    return n > 0 ? (uint32_t)n : 250000000u;
+}
+
+void die(const char* what) {
+    fprintf(stderr, "[ERROR] %s: %s\n", what, s4g_last_error());
+    exit(1);
+}
+
+struct Part {                       // one part of the database, flattened for the device
+    std::vector<uint8_t> codes;
+    std::vector<uint64_t> off;
+    uint32_t first_id = 0;
+};
+
+int device_of_choice() {
+    const char* v = getenv("S4G_PREFILTER_DEVICE");
+    return v ? atoi(v) : 0;
+}
+
+}  // namespace
+
+uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::string& database_path, Chain** queries,
+                        int32_t queries_length, uint32_t kmer_length, uint32_t max_candidates, uint32_t num_threads) {
+    (void)num_threads;
+    fprintf(stderr, "** Searching database for candidate sequences **\n");
+
+    // the queries, flattened: createHash's input (database_search.cpp:71-72)
+    Part q;
+    q.off.push_back(0);
+    for (int32_t i = 0; i < queries_length; ++i) {
+        const char* c = chainGetCodes(queries[i]);
+        const int n = chainGetLength(queries[i]);
+        q.codes.insert(q.codes.end(), (const uint8_t*)c, (const uint8_t*)c + n);
+        q.off.push_back(q.codes.size());
+    }
+    s4g_prefilter* filter = nullptr;
+    if (s4g_prefilter_create(&filter, device_of_choice(), q.codes.data(), q.off.data(), (uint32_t)queries_length, kmer_length,
+                             max_candidates) != S4G_OK) die("prefilter");
+
+    Chain** database = nullptr;
+    int database_length = 0, database_start = 0;
+    FILE* handle = nullptr;
+    int serialized = 0;
+    readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
+
+    const uint32_t database_chunk = chunk_bytes();
+    uint64_t database_cells = 0;
+    uint32_t part = 1;
+    const float part_size = database_chunk / (float)1000000000;
+    Part parts[2];
+    std::future<int> pending;                        // the device's work on the previous part
+    while (true) {
+        const int status = readFastaChainsPart(&database, &database_length, handle, serialized, database_chunk);
+        databaseLog(part, part_size, 0);
+
+        Part& p = parts[part & 1];                   // the other one may still be on its way to the device
+        p.first_id = (uint32_t)database_start;
+        p.off.assign(1, 0);
+        size_t residues = 0;
+        for (int i = database_start; i < database_length; ++i) residues += (size_t)chainGetLength(database[i]);
+        p.codes.resize(residues ? residues : 1);
+        size_t at = 0;
+        for (int i = database_start; i < database_length; ++i) {
+            const int n = chainGetLength(database[i]);
+            memcpy(p.codes.data() + at, chainGetCodes(database[i]), (size_t)n);
+            at += (size_t)n;
+            p.off.push_back(at);
+            chainDelete(database[i]);                // database_search.cpp:125-129
+            database[i] = nullptr;
+        }
+        database_cells += residues;
+
+        if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
+        pending = std::async(std::launch::async, [filter, &p]() {
+            return s4g_prefilter_add(filter, p.codes.data(), p.off.data(), (uint32_t)(p.off.size() - 1), p.first_id);
+        });
+
+        databaseLog(part, part_size, 100);
+        ++part;
+        if (status == 0) break;
+        database_start = database_length;
+    }
+    if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
+    fprintf(stderr, "\n\n");
+
+    fclose(handle);
+    deleteFastaChains(database, database_length);
+
+    // dst (database_search.cpp:166-178): ascending ids per query
+    std::vector<uint32_t> ids((size_t)std::max(1, queries_length) * max_candidates), counts((size_t)std::max(1, queries_length));
+    if (s4g_prefilter_finish(filter, ids.data(), counts.data(), nullptr) != S4G_OK) die("prefilter");
+    s4g_prefilter_destroy(filter);
+    dst.clear();
+    dst.resize(queries_length);
+    for (int32_t i = 0; i < queries_length; ++i)
+        dst[i].assign(ids.begin() + (size_t)i * max_candidates, ids.begin() + (size_t)i * max_candidates + counts[i]);
+    return database_cells;
+}

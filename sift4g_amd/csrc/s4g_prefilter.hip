@@ -1,0 +1,379 @@
+// s4g_prefilter.hip -- host side of the k-mer prefilter on the device (include/s4g_hip.h: s4g_prefilter_*).
+//
+// Replaces the compute of /root/reference/sift4g/src/database_search.cpp:66-253 (with hash.cpp:21-90); the kernels and the
+// pass structure are described in kmer_prefilter.hip.h.  One handle owns a stream and grow-only buffers: the CSR index of the
+// queries' k-mers, the chunk being processed, the work arena of one pass and the running candidate lists.  A chunk whose
+// hits would not fit the arena budget is processed in several passes over ranges of its targets.
+#include "s4g_internal.hpp"
+#include "kmer_prefilter.hip.h"
+
+#include <hipcub/hipcub.hpp>
+
+#define S4G_TRY(expr) do { const int rc_ = (expr); if (rc_ != S4G_OK) return rc_; } while (0)
+
+namespace {
+
+constexpr uint64_t kPassHits = 1ull << 26;          // hits per pass the arena is sized for (about 5 GB at 76 B per hit)
+constexpr uint64_t kMaxPassHits = (1ull << 31) - 64; // rocPRIM takes int sizes: one target with more hits than this is refused
+
+inline uint64_t align256(uint64_t v) { return (v + 255) & ~255ull; }
+inline uint32_t bits_for(uint64_t n_values) { uint32_t b = 1; while (b < 63 && (1ull << b) < n_values) ++b; return b; }
+using Clock = std::chrono::steady_clock;
+inline double us(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+
+}  // namespace
+
+struct s4g_prefilter {
+    int device = 0;
+    uint32_t nq = 0, k = 0, max_c = 0;
+    uint32_t q_bits = 1;            // bits of a query index inside a hit key
+    uint32_t list_q_bits = 1;       // bits of the query field of a candidate key that take part in the sort (covers the empty mark)
+    uint64_t n_slots = 0;           // 32^k + 1
+    hipStream_t stream = nullptr;
+    uint32_t* d_starts = nullptr;   // [n_slots + 1]
+    uint32_t* d_hit_q = nullptr;
+    uint32_t* d_hit_p = nullptr;
+    uint32_t* d_q_kmers = nullptr;
+    uint64_t n_hash_hits = 0;
+    uint64_t* d_list_key = nullptr; // [nq * max_c] running lists: query << 32 | ~bits(score); kPfNoEntry = empty
+    uint32_t* d_list_val = nullptr; //                              database index
+    uint8_t* d_codes = nullptr;  uint64_t codes_cap = 0;        // the chunk (s4g_prefilter_add)
+    uint64_t* d_off = nullptr;   uint64_t off_cap = 0;
+    char* h_stage = nullptr;     uint64_t stage_cap = 0;        // pinned: chunk on its way up, offsets of hits on their way down
+    char* d_work = nullptr;      uint64_t work_cap = 0;         // arena of one pass
+    unsigned* d_flags = nullptr;                                // [0] bad code, [1] long segments, [3] segments
+    unsigned* h_flags = nullptr;                                // pinned
+    uint32_t grid_waves = 0;
+    uint64_t pass_hits = kPassHits;  // S4G_PREFILTER_PASS_HITS overrides (tests: several passes on a small chunk)
+    uint32_t last_first_id = 0, last_n = 0;
+    bool any_chunk = false;
+    uint64_t stat_hits = 0, stat_pairs = 0, stat_long = 0, stat_chunks = 0;
+};
+
+namespace {
+
+int ensure_stage(s4g_prefilter* p, uint64_t bytes) {
+    if (p->stage_cap >= bytes) return S4G_OK;
+    if (p->h_stage) { HIP_TRY(hipStreamSynchronize(p->stream)); HIP_TRY(hipHostFree(p->h_stage)); p->h_stage = nullptr; p->stage_cap = 0; }
+    const uint64_t want = bytes + bytes / 8;
+    HIP_TRY(hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault));
+    p->stage_cap = want;
+    return S4G_OK;
+}
+
+template <typename T>
+int ensure_dev(s4g_prefilter* p, T** ptr, uint64_t* cap, uint64_t n) {
+    if (*cap >= n) return S4G_OK;
+    if (*ptr) { HIP_TRY(hipStreamSynchronize(p->stream)); HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
+    const uint64_t want = n + n / 8;
+    if (hipMalloc((void**)ptr, want * sizeof(T)) != hipSuccess) return fail(S4G_ERR_NOMEM, "prefilter: cannot allocate %llu bytes of device memory", (unsigned long long)(want * sizeof(T)));
+    *cap = want;
+    return S4G_OK;
+}
+
+// bump allocator over the arena
+struct Arena {
+    char* base; uint64_t at = 0;
+    template <typename T> T* take(uint64_t n) { T* r = (T*)(base + at); at += align256(n * sizeof(T)); return r; }
+};
+
+// Builds the CSR index of the queries' k-mers on the device (hash.cpp:56-85).
+int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
+    const uint64_t total = off[p->nq] - off[0];
+    p->n_slots = (1ull << (p->k * s4g::kKmerBits)) + 1;
+    HIP_TRY(hipMalloc((void**)&p->d_starts, (p->n_slots + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&p->d_q_kmers, (uint64_t)std::max(1u, p->nq) * 4));
+    std::vector<uint32_t> q_kmers(std::max(1u, p->nq), 0);
+    std::vector<uint64_t> rel(p->nq + 1);
+    for (uint32_t q = 0; q <= p->nq; ++q) rel[q] = off[q] - off[0];
+    for (uint32_t q = 0; q < p->nq; ++q) {
+        const uint64_t len = off[q + 1] - off[q];
+        if (off[q + 1] < off[q] || len > 0x7FFFFFF0ull) return fail(S4G_ERR_INVALID, "bad query offsets at %u", q);
+        q_kmers[q] = len >= p->k ? (uint32_t)(len - p->k + 1) : 0;
+        p->n_hash_hits += q_kmers[q];
+    }
+    if (total >= (1ull << 32)) return fail(S4G_ERR_INVALID, "prefilter: more than 2^32 query residues");
+    HIP_TRY(hipMemcpyAsync(p->d_q_kmers, q_kmers.data(), q_kmers.size() * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_hit_q, std::max<uint64_t>(1, p->n_hash_hits) * 4));
+    HIP_TRY(hipMalloc((void**)&p->d_hit_p, std::max<uint64_t>(1, p->n_hash_hits) * 4));
+    DevBuf<uint32_t> count;                              // [n_slots + 1]: bucket sizes, then scanned into d_starts
+    HIP_TRY(count.alloc(p->n_slots + 1));
+    HIP_TRY(hipMemsetAsync(count.p, 0, (p->n_slots + 1) * 4, p->stream));
+    size_t cub_scan = 0, cub_sort = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(p->n_slots + 1), p->stream));
+    if (total) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                                          (uint32_t*)nullptr, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
+    DevBuf<char> tmp;
+    HIP_TRY(tmp.alloc(std::max(cub_scan, cub_sort)));
+    DevBuf<uint8_t> d_codes; DevBuf<uint64_t> d_off; DevBuf<uint32_t> key, val, key2, val2, pos_q, pos_j;
+    if (total) {
+        HIP_TRY(d_codes.alloc(total)); HIP_TRY(d_off.alloc(p->nq + 1));
+        HIP_TRY(key.alloc(total)); HIP_TRY(val.alloc(total)); HIP_TRY(key2.alloc(total)); HIP_TRY(val2.alloc(total));
+        HIP_TRY(pos_q.alloc(total)); HIP_TRY(pos_j.alloc(total));
+        HIP_TRY(hipMemcpyAsync(d_codes.p, codes + off[0], total, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, p->stream));
+        hipLaunchKernelGGL(s4g::pf_query_kmers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, d_codes.p, d_off.p, p->nq, total, p->k,
+                           key.p, val.p, pos_q.p, pos_j.p, count.p, p->d_flags);
+        size_t t = std::max(cub_scan, cub_sort);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
+        if (p->n_hash_hits)
+            hipLaunchKernelGGL(s4g::pf_hash_hits, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, val2.p, pos_q.p, pos_j.p,
+                               p->n_hash_hits, p->d_hit_q, p->d_hit_p);
+    }
+    size_t t = std::max(cub_scan, cub_sort);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, count.p, p->d_starts, (int)(p->n_slots + 1), p->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));            // the temporaries above go out of scope here
+    if (p->h_flags[0]) return fail(S4G_ERR_INVALID, "prefilter: query residue code out of range (5-bit codes, hash.cpp:16-17)");
+    return S4G_OK;
+}
+
+// Candidates [list | n_new new ones] in cand_key/val (n = list slots + n_new) -> the best max_c per query back into the lists.
+int merge_candidates(s4g_prefilter* p, uint64_t* cand_key, uint32_t* cand_val, uint64_t* out_key, uint32_t* out_val, uint32_t* first,
+                     void* cub, size_t cub_bytes, uint64_t n) {
+    const uint64_t slots = (uint64_t)p->nq * p->max_c;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, cand_key, out_key, cand_val, out_val, (int)n, 0, (int)(32 + p->list_q_bits), p->stream));
+    hipLaunchKernelGGL(s4g::pf_fill, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, p->stream, p->d_list_key, slots);
+    hipLaunchKernelGGL(s4g::pf_query_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, out_key, n, p->nq, first);
+    hipLaunchKernelGGL(s4g::pf_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, out_key, out_val, n, p->nq, p->max_c, first,
+                       p->d_list_key, p->d_list_val);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id) {
+    if (p->any_chunk && first_id < p->last_first_id + p->last_n)
+        return fail(S4G_ERR_INVALID, "prefilter: chunks must arrive in ascending id order (ties at the cut go to the lower index)");
+    p->any_chunk = true; p->last_first_id = first_id; p->last_n = nt;
+    ++p->stat_chunks;
+    if (!nt || !p->nq) return S4G_OK;
+    const bool profile = getenv("S4G_PROFILE") != nullptr;
+    const auto t_begin = Clock::now();
+    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_hit_q, p->d_hit_p, p->k, nt};
+
+    // ---- pass 0: hits per target, their offsets, down to the host (which cuts the chunk into passes) ----
+    size_t cub_scan = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(nt + 1), p->stream));
+    const uint64_t b_cnt = align256((uint64_t)(nt + 1) * 8);
+    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, 2 * b_cnt + align256(cub_scan)));
+    S4G_TRY(ensure_stage(p, b_cnt));
+    uint64_t* d_count = (uint64_t*)p->d_work;
+    uint64_t* d_hit_off = (uint64_t*)(p->d_work + b_cnt);
+    HIP_TRY(hipMemsetAsync(p->d_flags, 0, 16, p->stream));
+    HIP_TRY(hipMemsetAsync(d_count + nt, 0, 8, p->stream));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nt + 3) / 4, p->grid_waves / 4);
+    hipLaunchKernelGGL(s4g::pf_target_count, dim3(grid), dim3(256), 0, p->stream, c, d_count, p->d_flags);
+    size_t tmp = cub_scan;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(p->d_work + 2 * b_cnt, tmp, d_count, d_hit_off, (int)(nt + 1), p->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(p->h_stage, d_hit_off, (uint64_t)(nt + 1) * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->h_flags[0]) return fail(S4G_ERR_INVALID, "prefilter: database residue code out of range (5-bit codes, hash.cpp:16-17)");
+    std::vector<uint64_t> hit_off((const uint64_t*)p->h_stage, (const uint64_t*)p->h_stage + nt + 1);
+    const uint64_t chunk_hits = hit_off[nt];
+    p->stat_hits += chunk_hits;
+    const auto t_counted = Clock::now();
+    if (!chunk_hits) return S4G_OK;
+
+    // ---- passes over ranges of targets ----
+    const uint64_t slots = (uint64_t)p->nq * p->max_c;
+    uint32_t t0 = 0, passes = 0;
+    uint64_t chunk_pairs = 0, chunk_long = 0;
+    while (t0 < nt) {
+        uint32_t t1 = (uint32_t)(std::upper_bound(hit_off.begin() + t0, hit_off.end(), hit_off[t0] + p->pass_hits) - hit_off.begin()) - 1;
+        t1 = std::min(nt, std::max(t1, t0 + 1));
+        const uint64_t H = hit_off[t1] - hit_off[t0];
+        if (!H) { t0 = t1; continue; }
+        if (H > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: target %u alone has %llu k-mer hits", first_id + t0, (unsigned long long)H);
+        ++passes;
+        const int key_bits = (int)(p->q_bits + bits_for(t1 - t0));
+        size_t cub_sort = 0, cub_rle = 0, cub_scan32 = 0, cub_cand = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                                   (uint32_t*)nullptr, (int)H, 0, key_bits, p->stream));
+        HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, cub_rle, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                                      (uint32_t*)nullptr, (int)H, p->stream));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)H, p->stream));
+        // the candidate sort is sized for the worst case (every hit a pair of its own); it almost never is
+        const uint64_t cand_cap = slots + H;
+        if (cand_cap > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidate slots exceed what one sort takes", (unsigned long long)cand_cap);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_cand, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                                   (uint32_t*)nullptr, (int)cand_cap, 0, (int)(32 + p->list_q_bits), p->stream));
+        const uint64_t b_cub = align256(std::max(std::max(cub_sort, cub_rle), std::max(cub_scan32, cub_cand)));
+        const uint64_t need = 2 * b_cnt + 2 * align256(H * 8) + 2 * align256(H * 4)            // hit keys / values, in and out
+                            + align256(H * 8) + 3 * align256(H * 4)                              // segments: key, length, offset, long list
+                            + align256((2 * H + 1) * 4)                                          // tails of the long segments
+                            + 2 * align256(cand_cap * 8) + 2 * align256(cand_cap * 4)            // candidates, in and out
+                            + align256((uint64_t)p->nq * 4) + b_cub;
+        if (p->work_cap < need) {
+            // the per-target offsets live at the front of the arena: they are on the host already, the device copy is re-uploaded
+            S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+            d_count = (uint64_t*)p->d_work; d_hit_off = (uint64_t*)(p->d_work + b_cnt);
+            HIP_TRY(hipMemcpyAsync(d_hit_off, hit_off.data(), (uint64_t)(nt + 1) * 8, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+        Arena A{p->d_work + 2 * b_cnt};
+        uint64_t* key_in = A.take<uint64_t>(H);  uint64_t* key_out = A.take<uint64_t>(H);
+        uint32_t* val_in = A.take<uint32_t>(H);  uint32_t* val_out = A.take<uint32_t>(H);
+        uint64_t* seg_key = A.take<uint64_t>(H); uint32_t* seg_len = A.take<uint32_t>(H); uint32_t* seg_off = A.take<uint32_t>(H);
+        uint32_t* long_list = A.take<uint32_t>(H);
+        int32_t* tails = A.take<int32_t>(2 * H + 1);
+        uint64_t* cand_key = A.take<uint64_t>(cand_cap); uint64_t* cand_key2 = A.take<uint64_t>(cand_cap);
+        uint32_t* cand_val = A.take<uint32_t>(cand_cap); uint32_t* cand_val2 = A.take<uint32_t>(cand_cap);
+        uint32_t* first = A.take<uint32_t>(p->nq);
+        void* cub = A.take<char>(b_cub);
+
+        const uint32_t g_emit = (uint32_t)std::min<uint64_t>(((uint64_t)(t1 - t0) + 3) / 4, p->grid_waves / 4);
+        hipLaunchKernelGGL(s4g::pf_target_emit, dim3(g_emit), dim3(256), 0, p->stream, c, t0, t1, d_hit_off, hit_off[t0], p->q_bits, key_in, val_in);
+        size_t t = b_cub;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, t, key_in, key_out, val_in, val_out, (int)H, 0, key_bits, p->stream));
+        t = b_cub;
+        HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(cub, t, key_out, seg_key, seg_len, p->d_flags + 3, (int)H, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->h_flags + 3, p->d_flags + 3, 4, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        const uint32_t n_seg = p->h_flags[3];
+        t = b_cub;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, t, seg_len, seg_off, (int)n_seg, p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_flags + 1, 0, 8, p->stream));
+        HIP_TRY(hipMemcpyAsync(cand_key, p->d_list_key, slots * 8, hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(cand_val, p->d_list_val, slots * 4, hipMemcpyDeviceToDevice, p->stream));
+        s4g::PfLisArgs la{seg_key, seg_len, seg_off, p->d_flags + 3, val_out, d_off, t0, first_id, p->q_bits,
+                          cand_key + slots, cand_val + slots, long_list, p->d_flags + 1, tails, p->d_q_kmers};
+        hipLaunchKernelGGL(s4g::pf_lis_small, dim3((unsigned)std::min<uint64_t>(((uint64_t)n_seg + 255) / 256, 8192)), dim3(256), 0, p->stream, la);
+        hipLaunchKernelGGL(s4g::pf_lis_long, dim3(p->grid_waves), dim3(64), 0, p->stream, la);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(p->h_flags + 1, p->d_flags + 1, 4, hipMemcpyDeviceToHost, p->stream));
+        S4G_TRY(merge_candidates(p, cand_key, cand_val, cand_key2, cand_val2, first, cub, b_cub, slots + n_seg));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        chunk_pairs += n_seg; chunk_long += p->h_flags[1];
+        t0 = t1;
+    }
+    p->stat_pairs += chunk_pairs; p->stat_long += chunk_long;
+    if (profile)
+        fprintf(stderr, "[s4g profile] prefilter chunk: %u targets from %u, %llu hits, %llu pairs (%llu on a wave), %u pass%s: count %.0f us, rest %.0f us\n",
+                nt, first_id, (unsigned long long)chunk_hits, (unsigned long long)chunk_pairs, (unsigned long long)chunk_long, passes,
+                passes == 1 ? "" : "es", us(t_begin, t_counted), us(t_counted, Clock::now()));
+    return S4G_OK;
+}
+
+}  // namespace
+
+S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_queries,
+                                 uint32_t kmer_length, uint32_t max_candidates) {
+    if (!out || !offsets || (!codes && n_queries && offsets[n_queries] != offsets[0])) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (kmer_length < 3 || kmer_length > 5) return fail(S4G_ERR_INVALID, "kmer_length possible values = 3,4,5 (main.cpp:169), got %u", kmer_length);
+    if (max_candidates == 0) return fail(S4G_ERR_INVALID, "max_candidates must be at least 1");
+    if ((uint64_t)n_queries * max_candidates > (1ull << 30)) return fail(S4G_ERR_INVALID, "prefilter: n_queries x max_candidates above 2^30");
+    const int have = device_count_raw();
+    if (have <= 0) return fail(S4G_ERR_NO_DEVICE, "no HIP device available (libs4g_hip has no CPU fallback)");
+    if (device < 0 || device >= have) return fail(S4G_ERR_INVALID, "device %d out of range [0,%d)", device, have);
+    DeviceGuard guard(device);
+    s4g_prefilter* p = new s4g_prefilter();
+    p->device = device; p->nq = n_queries; p->k = kmer_length; p->max_c = max_candidates;
+    p->q_bits = bits_for(std::max(1u, n_queries));
+    p->list_q_bits = std::min(32u, bits_for((uint64_t)n_queries + 1));
+    if (const char* e = getenv("S4G_PREFILTER_PASS_HITS")) { const long long v = atoll(e); if (v > 0) p->pass_hits = (uint64_t)v; }
+    auto body = [&]() -> int {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        p->grid_waves = (uint32_t)prop.multiProcessorCount * 32;
+        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void**)&p->d_flags, 64));
+        HIP_TRY(hipHostMalloc((void**)&p->h_flags, 64, hipHostMallocDefault));
+        HIP_TRY(hipMemsetAsync(p->d_flags, 0, 64, p->stream));
+        const uint64_t slots = std::max<uint64_t>(1, (uint64_t)n_queries * max_candidates);
+        HIP_TRY(hipMalloc((void**)&p->d_list_key, slots * 8));
+        HIP_TRY(hipMalloc((void**)&p->d_list_val, slots * 4));
+        hipLaunchKernelGGL(s4g::pf_fill, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, p->stream, p->d_list_key, slots);
+        HIP_TRY(hipGetLastError());
+        return build_index(p, codes, offsets);
+    };
+    const int rc = body();
+    if (rc != S4G_OK) { s4g_prefilter_destroy(p); return rc; }
+    *out = p;
+    return S4G_OK;
+}
+
+S4G_API int s4g_prefilter_add_device(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_offsets, uint32_t n_targets, uint32_t first_id) {
+    if (!p || (n_targets && (!d_codes || !d_offsets))) return fail(S4G_ERR_INVALID, "NULL argument");
+    if ((uint64_t)first_id + n_targets > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "prefilter: database index beyond 32 bits");
+    DeviceGuard guard(p->device);
+    return add_chunk(p, d_codes, d_offsets, n_targets, first_id);
+}
+
+S4G_API int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint64_t* offsets, uint32_t n_targets, uint32_t first_id) {
+    if (!p || (n_targets && (!codes || !offsets))) return fail(S4G_ERR_INVALID, "NULL argument");
+    if ((uint64_t)first_id + n_targets > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "prefilter: database index beyond 32 bits");
+    DeviceGuard guard(p->device);
+    if (!n_targets) return add_chunk(p, nullptr, nullptr, 0, first_id);
+    for (uint32_t t = 0; t < n_targets; ++t)
+        if (offsets[t + 1] < offsets[t] || offsets[t + 1] - offsets[t] > 0x7FFFFFF0ull) return fail(S4G_ERR_INVALID, "bad offsets at %u", t);
+    const uint64_t residues = offsets[n_targets] - offsets[0];
+    const uint64_t b_off = (uint64_t)(n_targets + 1) * 8;
+    S4G_TRY(ensure_stage(p, align256(b_off) + residues));
+    S4G_TRY(ensure_dev(p, &p->d_codes, &p->codes_cap, std::max<uint64_t>(1, residues)));
+    S4G_TRY(ensure_dev(p, &p->d_off, &p->off_cap, (uint64_t)n_targets + 1));
+    uint64_t* h_off = (uint64_t*)p->h_stage;
+    uint8_t* h_codes = (uint8_t*)p->h_stage + align256(b_off);
+    for (uint32_t t = 0; t <= n_targets; ++t) h_off[t] = offsets[t] - offsets[0];
+    const uint8_t* src = codes + offsets[0];
+    parallel_for(residues, parallel_parts(residues, 1u << 22), [&](unsigned, unsigned, uint64_t b, uint64_t e) { memcpy(h_codes + b, src + b, e - b); });
+    HIP_TRY(hipMemcpyAsync(p->d_off, h_off, b_off, hipMemcpyHostToDevice, p->stream));
+    if (residues) HIP_TRY(hipMemcpyAsync(p->d_codes, h_codes, residues, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));            // the staging buffer is reused for the offsets coming back down
+    return add_chunk(p, p->d_codes, p->d_off, n_targets, first_id);
+}
+
+S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores) {
+    if (!p || (p->nq && (!h_ids || !h_counts))) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (!p->nq) return S4G_OK;
+    DeviceGuard guard(p->device);
+    const uint64_t slots = (uint64_t)p->nq * p->max_c;
+    size_t cub_sort = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                               (uint32_t*)nullptr, (int)slots, 0, (int)(32 + p->list_q_bits), p->stream));
+    const uint64_t need = 2 * align256(slots * 8) + 4 * align256(slots * 4) + 2 * align256((uint64_t)p->nq * 4) + align256(cub_sort);
+    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+    Arena A{p->d_work};
+    uint64_t* key = A.take<uint64_t>(slots); uint64_t* key2 = A.take<uint64_t>(slots);
+    uint32_t* val = A.take<uint32_t>(slots); uint32_t* val2 = A.take<uint32_t>(slots);
+    uint32_t* ids = A.take<uint32_t>(slots); float* scores = A.take<float>(slots);
+    uint32_t* first = A.take<uint32_t>(p->nq); uint32_t* counts = A.take<uint32_t>(p->nq);
+    void* cub = A.take<char>(cub_sort);
+    const dim3 g((unsigned)((slots + 255) / 256)), b(256);
+    hipLaunchKernelGGL(s4g::pf_by_id, g, b, 0, p->stream, p->d_list_key, p->d_list_val, slots, key, val);
+    size_t t = cub_sort;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, t, key, key2, val, val2, (int)slots, 0, (int)(32 + p->list_q_bits), p->stream));
+    HIP_TRY(hipMemsetAsync(counts, 0, (uint64_t)p->nq * 4, p->stream));
+    HIP_TRY(hipMemsetAsync(ids, 0, slots * 4, p->stream));
+    HIP_TRY(hipMemsetAsync(scores, 0, slots * 4, p->stream));
+    hipLaunchKernelGGL(s4g::pf_query_first, g, b, 0, p->stream, key2, slots, p->nq, first);
+    hipLaunchKernelGGL(s4g::pf_rows, g, b, 0, p->stream, key2, val2, slots, p->nq, p->max_c, first, ids, scores, counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_ids, ids, slots * 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(h_counts, counts, (uint64_t)p->nq * 4, hipMemcpyDeviceToHost, p->stream));
+    if (h_scores) HIP_TRY(hipMemcpyAsync(h_scores, scores, slots * 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return S4G_OK;
+}
+
+S4G_API int s4g_prefilter_stats(const s4g_prefilter* p, uint64_t* out, uint32_t cap) {
+    if (!p || !out || cap < 4) return fail(S4G_ERR_INVALID, "s4g_prefilter_stats: out[4] needed");
+    out[0] = p->stat_hits; out[1] = p->stat_pairs; out[2] = p->stat_long; out[3] = p->stat_chunks;
+    return S4G_OK;
+}
+
+S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
+    if (!p) return S4G_OK;
+    DeviceGuard guard(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(p->d_starts); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
+    (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
+    if (p->h_flags) (void)hipHostFree(p->h_flags);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return S4G_OK;
+}

@@ -322,3 +322,57 @@ def traceback(db, queries, scorer, pair_q, pair_t, pair_score, route=None):
                                        {None: 0, "wave": 1, "scan": 2}[route]), "s4g_traceback_host")
     return [dict(score=int(pair_score[i]), q_start=int(out[i, 0]), q_end=int(out[i, 1]), t_start=int(out[i, 2]),
                  t_end=int(out[i, 3]), path=paths[int(off[i]):int(off[i]) + int(out[i, 4])].copy()) for i in range(n)]
+
+
+class Prefilter:
+    """searchDatabase's compute on the device (database_search.cpp:66-253, hash.cpp:21-90): the queries' k-mer index, then
+    database chunks in ascending id order through add(); finish() -> (ids [nq, max_candidates], counts [nq], scores) with the
+    ids of a row ascending.  Ties at the cut go to the lower database index (include/s4g_hip.h)."""
+
+    def __init__(self, queries, kmer_length=5, max_candidates=5000, device=0):
+        codes, offsets = flatten(queries)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.nq, self.max_candidates, self.next_id = len(offsets) - 1, int(max_candidates), 0
+        self._h = ctypes.c_void_p()
+        check(lib.s4g_prefilter_create(ctypes.byref(self._h), device, _ptr(codes, c_u8p), _ptr(offsets, c_u64p), self.nq,
+                                       int(kmer_length), self.max_candidates), "s4g_prefilter_create")
+
+    def add(self, targets=None, codes=None, offsets=None, first_id=None):
+        if codes is None:
+            codes, offsets = flatten(targets)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        first = self.next_id if first_id is None else int(first_id)
+        check(lib.s4g_prefilter_add(self._h, _ptr(codes, c_u8p), _ptr(offsets, c_u64p), n, first), "s4g_prefilter_add")
+        self.next_id = first + n
+
+    def add_device(self, codes, offsets, first_id=None):
+        """codes: uint8 device tensor, offsets: int64 device tensor of n + 1 entries (relative to codes)"""
+        n = offsets.numel() - 1
+        first = self.next_id if first_id is None else int(first_id)
+        check(lib.s4g_prefilter_add_device(self._h, codes.data_ptr(), offsets.data_ptr(), n, first), "s4g_prefilter_add_device")
+        self.next_id = first + n
+
+    def finish(self):
+        shape = (max(self.nq, 1), self.max_candidates)
+        ids = np.zeros(shape, dtype=np.uint32)
+        scores = np.zeros(shape, dtype=np.float32)
+        counts = np.zeros(max(self.nq, 1), dtype=np.uint32)
+        check(lib.s4g_prefilter_finish(self._h, _ptr(ids, c_u32p), _ptr(counts, c_u32p), _ptr(scores, ctypes.POINTER(ctypes.c_float))),
+              "s4g_prefilter_finish")
+        return ids[: self.nq], counts[: self.nq], scores[: self.nq]
+
+    def stats(self):
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.s4g_prefilter_stats(self._h, _ptr(out, c_u64p), 4), "s4g_prefilter_stats")
+        return dict(hits=int(out[0]), pairs=int(out[1]), long_pairs=int(out[2]), chunks=int(out[3]))
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.s4g_prefilter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -22,6 +22,13 @@ int s4g_oracle_sw_align(const uint8_t* q, int lq, const uint8_t* t, int lt, cons
                         int* q_start, int* q_end, int* t_start, int* t_end, uint8_t* path_out, int* path_len);
 }
 
+extern "C" {
+void* s4g_oracle_prefilter_create(const uint8_t* qcodes, const uint64_t* qoff, uint32_t nq, uint32_t k, uint32_t max_candidates);
+void s4g_oracle_prefilter_add(void* h, const uint8_t* tcodes, const uint64_t* toff, uint32_t nt, uint32_t first_id);
+void s4g_oracle_prefilter_finish(void* h, uint32_t* ids, uint32_t* counts, float* scores, float* cut);
+void s4g_oracle_prefilter_destroy(void* h);
+}
+
 struct s4g_scorer { int32_t table[26 * 26]; int open, ext; };
 struct Seqs { std::vector<uint8_t> codes; std::vector<uint64_t> off; uint32_t n = 0; uint32_t len(uint32_t i) const { return (uint32_t)(off[i + 1] - off[i]); } };
 struct s4g_db : Seqs {};
@@ -113,3 +120,21 @@ API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_sco
     }
     return S4G_OK;
 }
+
+// the k-mer prefilter (device_database_search.cpp): answered by oracle/kmer_prefilter.c
+struct s4g_prefilter { void* h; };
+API int s4g_prefilter_create(s4g_prefilter** out, int, const uint8_t* codes, const uint64_t* offsets, uint32_t n, uint32_t k, uint32_t max_candidates) {
+    void* h = s4g_oracle_prefilter_create(codes, offsets, n, k, max_candidates);
+    if (!h) return fail(S4G_ERR_INVALID, "kmer_length possible values = 3,4,5");
+    *out = new s4g_prefilter{h};
+    return S4G_OK;
+}
+API int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint64_t* offsets, uint32_t n, uint32_t first_id) {
+    s4g_oracle_prefilter_add(p->h, codes, offsets, n, first_id);
+    return S4G_OK;
+}
+API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* ids, uint32_t* counts, float* scores) {
+    s4g_oracle_prefilter_finish(p->h, ids, counts, scores, nullptr);
+    return S4G_OK;
+}
+API int s4g_prefilter_destroy(s4g_prefilter* p) { if (p) { s4g_oracle_prefilter_destroy(p->h); delete p; } return S4G_OK; }

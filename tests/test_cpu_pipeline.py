@@ -73,6 +73,36 @@ def test_batched_wrapper_on_the_cpu_oracle_reproduces_the_same_outputs(tmp_path)
     assert dropin_synth.run(BATCHED, str(parts), env=dict(env, S4G_CHUNK_BYTES="30000")) == want
 
 
+DEVSEARCH = os.path.join(ROOT, "build", "dropin", "sift4g_devsearch")
+
+
+@pytest.mark.skipif(not os.path.exists(DEVSEARCH), reason="device-prefilter drop-in not built (needs /root/reference at build time: make dropin-devsearch)")
+def test_device_prefilter_build_on_the_cpu_oracle_reproduces_the_same_outputs(tmp_path):
+    """the reference CLI with its k-mer prefilter (database_search.cpp, hash.cpp) replaced by
+    sift4g_amd/csrc/dropin/device_database_search.cpp and its alignment wrapper by the batched one: the same files as the
+    reference's own prefilter gives (its candidates differ from the replacement's only in ties at the cut, and on these inputs
+    no such tie decides a reported hit), here with the oracle stand-in answering s4g_prefilter_* (oracle/kmer_prefilter.c)."""
+    subprocess.run(["make", "-s", "-C", SHIM], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(SHIM, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    files = os.path.join(GOLDEN, "test_files")
+    out = tmp_path / "fixture"
+    out.mkdir()
+    r = subprocess.run([DEVSEARCH, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep,
+                        "-d", os.path.join(files, "sample_protein_database.fa"), "--cards", "0", "--out", str(out), "--sub-results"],
+                       env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
+        assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    want = open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+    assert dropin_synth.run(DEVSEARCH, str(syn), env=env) == want
+    # the database read in ~17 parts by both stages: running candidate lists across parts, reading overlapped with the prefilter
+    parts = tmp_path / "parts"
+    parts.mkdir()
+    assert dropin_synth.run(DEVSEARCH, str(parts), env=dict(env, S4G_PREFILTER_CHUNK_BYTES="30000", S4G_CHUNK_BYTES="30000")) == want
+
+
 FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
 
 

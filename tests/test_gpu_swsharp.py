@@ -247,6 +247,42 @@ def test_batched_wrapper_gives_the_reference_flows_alignments(tmp_path):
     assert dropin_synth.run(BATCHED, str(parts), env=dict(os.environ, S4G_CHUNK_BYTES="30000")) == want
 
 
+DEVSEARCH = os.path.join(ROOT, "build", "dropin", "sift4g_devsearch")
+
+
+@pytest.mark.skipif(not os.path.exists(DEVSEARCH), reason="device-prefilter drop-in not built (needs /root/reference at build time: make dropin-devsearch)")
+def test_device_prefilter_build_gives_the_reference_flows_outputs(tmp_path):
+    """build/dropin/sift4g_devsearch = the reference CLI with its k-mer prefilter on the device (database_search.cpp and
+    hash.cpp replaced by sift4g_amd/csrc/dropin/device_database_search.cpp -> s4g_prefilter_*) and the batched alignment
+    wrapper.  Same alignments and predictions, byte for byte, as the build that runs the reference's own prefilter: on the
+    fixture, on the synthetic set, with the database read in many parts, and at the other k-mer lengths."""
+    import dropin_synth
+    tf = os.path.join(GOLDEN, "test_files")
+
+    def fixture(exe, name, extra=(), env=None):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run([exe, "-q", os.path.join(tf, "query.fasta"), "--subst", tf, "-d",
+                            os.path.join(tf, "sample_protein_database.fa"), "--out", str(out), "--cards", "0", "--sub-results", *extra],
+                           capture_output=True, text=True, timeout=600, cwd=str(out), env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return {n: (out / n).read_bytes() for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction")}
+
+    got = fixture(DEVSEARCH, "fixture")
+    for n, data in got.items():
+        assert data == open(os.path.join(GOLDEN, "dropin_predictions", n), "rb").read(), n
+    assert fixture(DEVSEARCH, "fixture_parts", env=dict(os.environ, S4G_PREFILTER_CHUNK_BYTES="20000")) == got
+    for k in ("3", "4"):
+        assert fixture(DEVSEARCH, "dev_k" + k, ("--kmer-length", k)) == fixture(DROPIN, "ref_k" + k, ("--kmer-length", k)), k
+    syn = tmp_path / "synth"
+    syn.mkdir()
+    want = open(os.path.join(GOLDEN, "dropin_synth", "alignments.txt"), "rb").read()
+    assert dropin_synth.run(DEVSEARCH, str(syn)) == want
+    parts = tmp_path / "parts"
+    parts.mkdir()
+    assert dropin_synth.run(DEVSEARCH, str(parts), env=dict(os.environ, S4G_PREFILTER_CHUNK_BYTES="30000", S4G_CHUNK_BYTES="30000")) == want
+
+
 FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
 
 
