@@ -108,6 +108,52 @@ def cpu_baseline(cfg, n_threads, target_seconds=12.0):
                        f"{impl}, {n_threads} pthreads")
 
 
+def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
+    """The stage in front of the scan: sift4g's k-mer prefilter over the same database on the device
+    (s4g_prefilter_*: k = 5, 5000 candidates per query, the CLI's defaults, main.cpp:68-69), database already in HBM; the first
+    `check_targets` targets are also run through oracle/kmer_prefilter.c and the two candidate lists compared."""
+    import torch
+    import oracle
+    import sift4g_amd.device as s4gd
+    q_off, t_off = cfg["q_off"], cfg["t_off"]
+    nq, nt = len(q_off) - 1, len(t_off) - 1
+    queries = [cfg["q_codes"][int(q_off[i]):int(q_off[i + 1])] for i in range(nq)]
+    residues = int(t_off[-1])
+    d_codes = torch.from_numpy(cfg["t_codes"][:max(residues, 1)]).cuda(dev_index)
+    d_off = torch.from_numpy(np.asarray(t_off).astype(np.int64)).cuda(dev_index)
+    best = dict(index=1e9, add=1e9, finish=1e9)
+    stats = None
+    for _ in range(reps + 1):                          # the first round grows the buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); p = s4gd.Prefilter(queries, 5, 5000, device=dev_index); t1 = time.perf_counter()
+        p.add_device(d_codes, d_off, first_id=0); t2 = time.perf_counter()
+        p.finish(); t3 = time.perf_counter()
+        stats = p.stats()
+        p.close()
+        best = dict(index=min(best["index"], t1 - t0), add=min(best["add"], t2 - t1), finish=min(best["finish"], t3 - t2))
+    m = min(check_targets, nt)
+    sample = [cfg["t_codes"][int(t_off[i]):int(t_off[i + 1])] for i in range(m)]
+    t0 = time.perf_counter()
+    r = oracle.Prefilter(queries, 5, 5000)
+    r.add(sample)
+    r_ids, r_counts, r_scores, _ = r.finish()
+    cpu_s = time.perf_counter() - t0
+    p = s4gd.Prefilter(queries, 5, 5000, device=dev_index)
+    p.add(sample)
+    ids, counts, scores = p.finish()
+    p.close()
+    bad = int((counts != r_counts).sum())
+    for q in range(nq):
+        n = int(min(counts[q], r_counts[q]))
+        bad += int((ids[q, :n] != r_ids[q, :n]).sum()) + int((scores[q, :n].view(np.uint32) != r_scores[q, :n].view(np.uint32)).sum())
+    return {"stage": "k-mer prefilter (database_search.cpp:66-253) on the device, database resident in HBM",
+            "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues,
+            "index_ms": round(best["index"] * 1e3, 3), "add_ms": round(best["add"] * 1e3, 3), "finish_ms": round(best["finish"] * 1e3, 3),
+            "residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],
+            "check": {"targets": m, "mismatches": bad, "against": "oracle/kmer_prefilter.c (CPU restatement, 1 thread)",
+                      "cpu_residues_per_s": round(int(t_off[m]) / cpu_s, 1)}}
+
+
 def oracle_selfcheck(q_codes, q_off, fetch_target, pairs, gpu_scores, n_threads):
     """Re-score (query, target) pairs with the CPU oracle (outside the timed region) and compare with what the GPU reported."""
     import oracle
@@ -141,6 +187,7 @@ def main():
     ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-prefilter", action="store_true", help="skip the k-mer prefilter leg after the timed region")
     ap.add_argument("--no-tiers", action="store_true", help="skip the two extra int32-only steps after the timed region")
     args = ap.parse_args()
 
@@ -440,6 +487,10 @@ def main():
             out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32d<32>", "steps": 2,
                                       "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
                             tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
+        if world == 1 and not db_shard and not args.no_prefilter and cfg is not None:
+            out["prefilter"] = prefilter_leg(cfg, dev_index)
+            if out["prefilter"]["check"]["mismatches"]:
+                log(f"PREFILTER CHECK FAILED: {out['prefilter']['check']}")
         if world == 1 and not args.no_cpu_baseline and cfg is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
         line = json.dumps(out)
@@ -455,7 +506,7 @@ def main():
         except OSError:
             pass
         print(line, flush=True)
-        if json.loads(line).get("selfcheck", {}).get("mismatches"):
+        if json.loads(line).get("selfcheck", {}).get("mismatches") or json.loads(line).get("prefilter", {}).get("check", {}).get("mismatches"):
             sys.exit(3)
 
 

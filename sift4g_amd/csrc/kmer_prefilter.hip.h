@@ -36,10 +36,12 @@ __device__ __forceinline__ uint32_t pf_kmer(const uint8_t* __restrict__ c, uint3
 }
 
 // One thread per query residue g (flat over all queries).  key[g] = k-mer starting there, or the invalid key 1 << 5k when fewer
-// than k residues are left in that query; val[g] = g; pos_q[g] / pos_j[g] = query index / position of g; count[kmer] += 1.
+// than k residues are left in that query; val[g] = g; pos_q[g] / pos_j[g] = query index / position of g; count[kmer] += 1;
+// bit kmer of `present` set.
 __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ off, uint32_t nq, uint64_t total,
                                uint32_t k, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos_q,
-                               uint32_t* __restrict__ pos_j, uint32_t* __restrict__ count, unsigned* __restrict__ bad) {
+                               uint32_t* __restrict__ pos_j, uint32_t* __restrict__ count, uint32_t* __restrict__ present,
+                               unsigned* __restrict__ bad) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     uint32_t lo = 0, hi = nq;                   // last q with off[q] <= g  (queries of length 0 share an offset: take the last)
@@ -52,6 +54,7 @@ __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t
         const uint32_t v = pf_kmer(codes + g, k);
         key[g] = v;
         atomicAdd(&count[v], 1u);
+        atomicOr(&present[v >> 5], 1u << (v & 31));
     } else {
         key[g] = 1u << (k * kKmerBits);
     }
@@ -70,6 +73,8 @@ struct PfChunk {
     const uint8_t* codes;       // residues of the chunk, flat
     const uint64_t* off;        // [nt + 1]
     const uint32_t* starts;     // [32^k + 1] CSR index of the queries' k-mers
+    const uint32_t* present;    // one bit per k-mer: does any query hold it?  (4 MB at k = 5: answers nine lookups in ten from L2
+                                // instead of a random 64-byte fetch from the 134 MB of `starts`)
     const uint32_t* hit_q;      // bucket contents
     const uint32_t* hit_p;
     uint32_t k, nt;
@@ -83,6 +88,7 @@ __device__ __forceinline__ uint32_t pf_bucket(const PfChunk& a, const uint8_t* _
         const uint32_t prev = ((uint32_t)c[j - 1] << ((a.k - 1) * kKmerBits)) | (v >> kKmerBits);
         if (prev == v) return 0;
     }
+    if (!((a.present[v >> 5] >> (v & 31)) & 1u)) return 0;
     const uint32_t s = a.starts[v];
     *first = s;
     return a.starts[v + 1] - s;
@@ -291,7 +297,7 @@ __global__ void pf_rows(const uint64_t* __restrict__ key, const uint32_t* __rest
     const uint64_t r = i - first[q];
     ids[(uint64_t)q * max_candidates + r] = (uint32_t)key[i];
     scores[(uint64_t)q * max_candidates + r] = __uint_as_float(val[i]);
-    atomicMax(&counts[q], (uint32_t)r + 1);
+    if (i + 1 == n || (uint32_t)(key[i + 1] >> 32) != q) counts[q] = (uint32_t)r + 1;      // the query's last entry knows the count
 }
 
 }  // namespace s4g

@@ -31,6 +31,7 @@ struct s4g_prefilter {
     uint64_t n_slots = 0;           // 32^k + 1
     hipStream_t stream = nullptr;
     uint32_t* d_starts = nullptr;   // [n_slots + 1]
+    uint32_t* d_present = nullptr;  // [n_slots / 32 + 1] bitmap of the k-mers any query holds
     uint32_t* d_hit_q = nullptr;
     uint32_t* d_hit_p = nullptr;
     uint32_t* d_q_kmers = nullptr;
@@ -83,6 +84,8 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     p->n_slots = (1ull << (p->k * s4g::kKmerBits)) + 1;
     HIP_TRY(hipMalloc((void**)&p->d_starts, (p->n_slots + 1) * 4));
     HIP_TRY(hipMalloc((void**)&p->d_q_kmers, (uint64_t)std::max(1u, p->nq) * 4));
+    HIP_TRY(hipMalloc((void**)&p->d_present, (p->n_slots / 32 + 1) * 4));
+    HIP_TRY(hipMemsetAsync(p->d_present, 0, (p->n_slots / 32 + 1) * 4, p->stream));
     std::vector<uint32_t> q_kmers(std::max(1u, p->nq), 0);
     std::vector<uint64_t> rel(p->nq + 1);
     for (uint32_t q = 0; q <= p->nq; ++q) rel[q] = off[q] - off[0];
@@ -113,7 +116,7 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
         HIP_TRY(hipMemcpyAsync(d_codes.p, codes + off[0], total, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, p->stream));
         hipLaunchKernelGGL(s4g::pf_query_kmers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, d_codes.p, d_off.p, p->nq, total, p->k,
-                           key.p, val.p, pos_q.p, pos_j.p, count.p, p->d_flags);
+                           key.p, val.p, pos_q.p, pos_j.p, count.p, p->d_present, p->d_flags);
         size_t t = std::max(cub_scan, cub_sort);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
         if (p->n_hash_hits)
@@ -150,7 +153,7 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
     if (!nt || !p->nq) return S4G_OK;
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_hit_q, p->d_hit_p, p->k, nt};
+    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->k, nt};
 
     // ---- pass 0: hits per target, their offsets, down to the host (which cuts the chunk into passes) ----
     size_t cub_scan = 0;
@@ -368,7 +371,7 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     if (!p) return S4G_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_starts); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_starts); (void)hipFree(p->d_present); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_q_kmers);
     (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
     if (p->h_stage) (void)hipHostFree(p->h_stage);

@@ -70,6 +70,10 @@ def test_bench_prints_one_contract_json_line():
     chk = d["selfcheck"]
     assert chk["random_pairs"] == 2000 and chk["top_list_entries"] > 0 and chk["mismatches"] == 0
     assert d["speculative"] == {"queries": 0, "rechecked": 0}
+    # ... and the stage in front of the scan, checked against its own restatement
+    pf = d["prefilter"]
+    assert pf["targets"] == 3000 and pf["residues_per_s"] > 0 and pf["kmer_hits"] >= pf["pairs_with_a_hit"] > 0
+    assert pf["check"] == dict(pf["check"], targets=2000, mismatches=0)
 
 
 @pytest.mark.gpu
