@@ -17,6 +17,7 @@
 // database index always wins.  Every candidate strictly above the cut is the same.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <future>
 #include <string>
@@ -48,6 +49,10 @@ struct Part {                       // one part of the database, flattened for t
     uint32_t first_id = 0;
 };
 
+double seconds_since(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+}
+
 int device_of_choice() {
     const char* v = getenv("S4G_PREFILTER_DEVICE");
     return v ? atoi(v) : 0;
@@ -69,9 +74,12 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
         q.codes.insert(q.codes.end(), (const uint8_t*)c, (const uint8_t*)c + n);
         q.off.push_back(q.codes.size());
     }
+    // the index is built while the first part of the database is being read (and while the device finishes warming up)
     s4g_prefilter* filter = nullptr;
-    if (s4g_prefilter_create(&filter, device_of_choice(), q.codes.data(), q.off.data(), (uint32_t)queries_length, kmer_length,
-                             max_candidates) != S4G_OK) die("prefilter");
+    std::future<int> created = std::async(std::launch::async, [&]() {
+        return s4g_prefilter_create(&filter, device_of_choice(), q.codes.data(), q.off.data(), (uint32_t)queries_length, kmer_length,
+                                    max_candidates);
+    });
 
     Chain** database = nullptr;
     int database_length = 0, database_start = 0;
@@ -80,14 +88,18 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
 
     const uint32_t database_chunk = chunk_bytes();
+    double t_read = 0, t_flatten = 0, t_wait = 0;        // S4G_PROFILE=1: where the stage's time goes
     uint64_t database_cells = 0;
     uint32_t part = 1;
     const float part_size = database_chunk / (float)1000000000;
     Part parts[2];
     std::future<int> pending;                        // the device's work on the previous part
     while (true) {
+        auto t0 = std::chrono::steady_clock::now();
         const int status = readFastaChainsPart(&database, &database_length, handle, serialized, database_chunk);
+        t_read += seconds_since(t0);
         databaseLog(part, part_size, 0);
+        t0 = std::chrono::steady_clock::now();
 
         Part& p = parts[part & 1];                   // the other one may still be on its way to the device
         p.first_id = (uint32_t)database_start;
@@ -105,18 +117,25 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
             database[i] = nullptr;
         }
         database_cells += residues;
+        t_flatten += seconds_since(t0);
 
+        t0 = std::chrono::steady_clock::now();
+        if (created.valid() && created.get() != S4G_OK) die("prefilter");
         if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
         pending = std::async(std::launch::async, [filter, &p]() {
             return s4g_prefilter_add(filter, p.codes.data(), p.off.data(), (uint32_t)(p.off.size() - 1), p.first_id);
         });
+        t_wait += seconds_since(t0);
 
         databaseLog(part, part_size, 100);
         ++part;
         if (status == 0) break;
         database_start = database_length;
     }
+    auto t0 = std::chrono::steady_clock::now();
     if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
+    t_wait += seconds_since(t0);
+    t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "\n\n");
 
     fclose(handle);
@@ -126,6 +145,9 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     std::vector<uint32_t> ids((size_t)std::max(1, queries_length) * max_candidates), counts((size_t)std::max(1, queries_length));
     if (s4g_prefilter_finish(filter, ids.data(), counts.data(), nullptr) != S4G_OK) die("prefilter");
     s4g_prefilter_destroy(filter);
+    if (getenv("S4G_PROFILE"))
+        fprintf(stderr, "[s4g profile] prefilter stage: reading FASTA %.3f s, flattening chains %.3f s, waiting for the device %.3f s, lists to the host %.3f s\n",
+                t_read, t_flatten, t_wait, seconds_since(t0));
     dst.clear();
     dst.resize(queries_length);
     for (int32_t i = 0; i < queries_length; ++i)

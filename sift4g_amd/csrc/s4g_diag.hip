@@ -116,7 +116,7 @@ static void warm_device(int device) {
         (void)hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming);
     }
-    if (warm_core_kernels(cx) || warm_pair_kernels(cx) || warm_list_kernels(cx) || warm_scan_kernels(cx)) return;
+    if (warm_core_kernels(cx) || warm_prefilter_kernels(cx) || warm_pair_kernels(cx) || warm_list_kernels(cx) || warm_scan_kernels(cx)) return;
 }
 
 S4G_API int s4g_warmup(int device) {

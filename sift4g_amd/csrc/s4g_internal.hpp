@@ -201,6 +201,7 @@ int warm_scan_kernels(DeviceCtx* cx);      // s4g_scan.hip
 int warm_pair_kernels(DeviceCtx* cx);      // s4g_pairs.hip
 int warm_list_kernels(DeviceCtx* cx);      // s4g_lists.hip
 int warm_core_kernels(DeviceCtx* cx);      // s4g_core.hip
+int warm_prefilter_kernels(DeviceCtx* cx); // s4g_prefilter.hip
 int pair_stage(DeviceCtx* cx, uint64_t n, s4g::PairItem** out);
 // s4g_scan.hip
 void ensure_bounds(const s4g_queries* q, const s4g_scorer* scorer);

@@ -262,6 +262,24 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
 
 }  // namespace
 
+// s4g_warmup: load this unit's code object (the occupancy query resolves the kernels) and rocPRIM's run-length encoder
+int warm_prefilter_kernels(DeviceCtx* cx) {
+    (void)cx;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)s4g::pf_target_count, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)s4g::pf_lis_long, 64, 0));
+    DevBuf<uint64_t> buf;
+    HIP_TRY(buf.alloc(4 * 64 + 8192));
+    HIP_TRY(hipMemset(buf.p, 0, (4 * 64 + 8192) * 8));
+    size_t tmp = 8192 * 8 - 512;
+    uint64_t* p = buf.p;
+    HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(p + 256, tmp, p, p + 64, (uint32_t*)(p + 128), (uint32_t*)(p + 192), 64, nullptr));
+    tmp = 8192 * 8 - 512;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p + 256, tmp, p, p + 64, (uint32_t*)(p + 128), (uint32_t*)(p + 192), 64, 0, 40, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return S4G_OK;
+}
+
 S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_queries,
                                  uint32_t kmer_length, uint32_t max_candidates) {
     if (!out || !offsets || (!codes && n_queries && offsets[n_queries] != offsets[0])) return fail(S4G_ERR_INVALID, "NULL argument");
