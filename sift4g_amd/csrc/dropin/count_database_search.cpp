@@ -3,8 +3,9 @@
 // Defines `searchDatabase(...)` with the signature the reference declares in
 // /root/reference/sift4g/src/database_search.hpp:17-19 and replaces the reference's database_search.cpp (k-mer hash of the
 // queries, per-thread scan of the database, longest increasing subsequence of hit positions, 5000 best candidates per query:
-// database_search.cpp:66-253, hash.cpp:21-90) in `make dropin-fullscan`.  On an MI355X scoring EVERY target is cheaper than
-// choosing which ones to score (1.2 ms per query and 100 000 targets), so this stage only does the one
+// database_search.cpp:66-253, hash.cpp:21-90) in `make dropin-fullscan`.  For inputs of modest size scoring EVERY target on an MI355X is cheaper than
+// choosing which ones to score on the CPU (1.2 ms per query and 100 000 targets; for large ones the prefilter on
+// the device, device_database_search.cpp, is the better trade), so this stage only does the one
 // thing the rest of the pipeline still needs from it: the total number of database residues, which main.cpp:204,210 hands
 // to createEValueParams.  `dst` comes back with one EMPTY list per query; fullscan_database_alignment.cpp ignores it.
 #include <cstdio>

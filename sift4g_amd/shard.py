@@ -133,3 +133,23 @@ def scan_db_shard(db_shard, global_ids, queries, scorer, k, min_score=1, group=N
     from . import device as dev
     ids, sc, cnt = dev.scan_topk(db_shard, queries, scorer, k, min_score)
     return gather_db_shards(ids, sc, cnt, torch.as_tensor(global_ids), k, group)
+
+
+def merge_candidate_shards(ids, counts, scores, global_ids, max_candidates, group=None):
+    """The k-mer prefilter in DB-shard mode: every rank has filtered its own slice of the database
+    (device.Prefilter / s4g_prefilter_*: ids [Q, max_candidates] index the rank's slice, the first counts[q] of a row valid, float
+    scores).  One all-gather of the lists and a merge per query under (score descending, global index ascending) give what one
+    prefilter over the whole database returns -- the cross-part merge of database_search.cpp:129-150 applied across GPUs.
+    global_ids as in gather_db_shards; it must be ascending, so that a rank's own tie rule (lower local index) is the global
+    one.  -> (ids [Q, max_candidates] int32 ascending, -1 = unused; counts [Q]) on every rank."""
+    ids = torch.as_tensor(ids)
+    q, m = ids.shape
+    slot = torch.arange(m, device=ids.device).unsqueeze(0)
+    valid = slot < torch.as_tensor(counts).to(ids.device).to(torch.int64).unsqueeze(1)
+    local = torch.where(valid, ids.to(torch.int64), torch.full((q, m), -1, dtype=torch.int64, device=ids.device)).to(torch.int32)
+    bits = torch.as_tensor(scores).to(ids.device).contiguous().view(torch.int32)        # positive floats order as their bit patterns
+    bits = torch.where(valid, bits, torch.zeros_like(bits))
+    g_ids, _, g_counts = gather_db_shards(local, bits, None, global_ids, max_candidates, group)
+    key = torch.where(g_ids >= 0, g_ids.to(torch.int64), torch.full_like(g_ids, 1 << 40, dtype=torch.int64))
+    out = torch.sort(key, dim=1).values
+    return torch.where(out < (1 << 40), out, torch.full_like(out, -1)).to(torch.int32), g_counts

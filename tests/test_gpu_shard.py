@@ -38,7 +38,16 @@ def _worker(rank, world, port, cfg, k, q):
         codes = np.concatenate([cfg["t_codes"][int(cfg["t_off"][i]):int(cfg["t_off"][i + 1])] for i in mine])
         part = s4g.Database(codes=codes, offsets=off, tile_seqs=256)
         b = [t.cpu().numpy() for t in shard.scan_db_shard(part, mine.astype(np.int64), queries, scorer, k)]
-        q.put((rank, a, b))
+        # the k-mer prefilter on the same slice (device), lists merged across the ranks
+        from sift4g_amd import device as s4gd
+        qs = [cfg["q_codes"][int(cfg["q_off"][i]):int(cfg["q_off"][i + 1])] for i in range(len(cfg["q_off"]) - 1)]
+        pf = s4gd.Prefilter(qs, 5, 15)
+        pf.add(codes=codes, offsets=off, first_id=0)
+        p_ids, p_counts, p_scores = pf.finish()
+        pf.close()
+        c = [t.numpy() for t in shard.merge_candidate_shards(torch.from_numpy(p_ids.astype(np.int64)), torch.from_numpy(p_counts.astype(np.int64)),
+                                                              torch.from_numpy(p_scores), torch.from_numpy(mine.astype(np.int64)), 15)]
+        q.put((rank, a, b, c))
     finally:
         dist.destroy_process_group()
 
@@ -66,7 +75,18 @@ def test_two_ranks_one_gpu_equal_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, a, b in res:
+    # the prefilter over the whole database in one process, for the merged lists of the two ranks
+    from sift4g_amd import device as s4gd
+    qs = [cfg["q_codes"][int(cfg["q_off"][i]):int(cfg["q_off"][i + 1])] for i in range(queries.n)]
+    pf = s4gd.Prefilter(qs, 5, 15)
+    pf.add(codes=cfg["t_codes"], offsets=cfg["t_off"], first_id=0)
+    w_ids, w_counts, _ = pf.finish()
+    pf.close()
+    assert w_counts.max() == 15                          # the cut binds
+    for rank, a, b, c in res:
+        assert c[1].tolist() == w_counts.tolist()
+        for i in range(queries.n):
+            assert c[0][i, :c[1][i]].tolist() == w_ids[i, :w_counts[i]].tolist(), (rank, i)
         for got in (a, b):
             gi = np.where(got[0] < 0, 0xFFFFFFFF, got[0]).astype(np.int64)
             assert np.array_equal(gi, want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2].astype(np.int64), want[2])

@@ -106,3 +106,60 @@ def test_single_process_paths_and_helpers(case):
     assert np.array_equal(out[0].numpy(), ids)
     m = shard.merge_topk(torch.from_numpy(np.concatenate([ids, ids], axis=1)), torch.from_numpy(np.concatenate([sc, sc], axis=1)), 24)
     assert (m[2].numpy() == np.minimum(2 * cnt, 24)).all()
+
+
+# ---- the k-mer prefilter in DB-shard mode: per-rank candidate lists (here from the CPU restatement), merged over gloo ----
+
+def _prefilter_worker(rank, world, port, queries, targets, k, max_candidates, contiguous, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from sift4g_amd import shard
+    try:
+        if contiguous:
+            b = shard.shard_bounds(len(targets), world)
+            mine, gmap = list(range(b[rank], b[rank + 1])), b[rank]
+        else:
+            gmap = shard.balanced_db_shards([len(t) for t in targets], world)[rank]
+            mine = [int(i) for i in gmap]
+        pf = oracle.Prefilter(queries, k, max_candidates)
+        pf.add([targets[i] for i in mine])
+        ids, counts, scores, _ = pf.finish()
+        out = shard.merge_candidate_shards(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(counts.astype(np.int64)),
+                                           torch.from_numpy(scores), gmap, max_candidates)
+        q.put((rank, [t.numpy() for t in out]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_prefilter_lists_merge_world2(contiguous):
+    import oracle
+    from conftest import rand_seqs
+    rng = np.random.default_rng(5)
+    queries = rand_seqs(rng, 6, 40, 200)
+    targets = rand_seqs(rng, 900, 20, 70)                   # short targets: many ties at the cut
+    for j in range(0, 900, 31):
+        targets[j] = queries[j % 6][: 30 + j % 25].copy()
+    k, max_candidates = 4, 25
+    whole = oracle.Prefilter(queries, k, max_candidates)
+    whole.add(targets)
+    w_ids, w_counts, _, cut = whole.finish()
+    assert (cut > 0).any()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prefilter_worker, args=(r, 2, port, queries, targets, k, max_candidates, contiguous, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        ids, counts = res[r]
+        assert counts.tolist() == w_counts.tolist()
+        for i in range(len(queries)):
+            assert ids[i, :counts[i]].tolist() == w_ids[i, :w_counts[i]].tolist(), (r, i)
+            assert (ids[i, counts[i]:] == -1).all()
