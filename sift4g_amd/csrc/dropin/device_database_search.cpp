@@ -43,11 +43,12 @@ void die(const char* what) {
     exit(1);
 }
 
-struct Part {                       // one part of the database, flattened for the device
-    std::vector<uint8_t> codes;
-    std::vector<uint64_t> off;
-    uint32_t first_id = 0;
+struct Part {                       // one part of the database as the device takes it
+    char* codes = nullptr;
+    size_t* off = nullptr;
+    uint32_t n = 0, first_id = 0;
 };
+static_assert(sizeof(size_t) == sizeof(uint64_t), "offsets are handed to the device ABI as they are");
 
 double seconds_since(std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
@@ -66,7 +67,7 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     fprintf(stderr, "** Searching database for candidate sequences **\n");
 
     // the queries, flattened: createHash's input (database_search.cpp:71-72)
-    Part q;
+    struct { std::vector<uint8_t> codes; std::vector<uint64_t> off; } q;
     q.off.push_back(0);
     for (int32_t i = 0; i < queries_length; ++i) {
         const char* c = chainGetCodes(queries[i]);
@@ -82,61 +83,53 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     });
 
     Chain** database = nullptr;
-    int database_length = 0, database_start = 0;
+    int database_length = 0;
     FILE* handle = nullptr;
     int serialized = 0;
     readFastaChainsPartInit(&database, &database_length, &handle, &serialized, database_path.c_str());
 
+    double t_read = 0, t_wait = 0;                       // S4G_PROFILE=1: where the stage's time goes
     const uint32_t database_chunk = chunk_bytes();
-    double t_read = 0, t_flatten = 0, t_wait = 0;        // S4G_PROFILE=1: where the stage's time goes
     uint64_t database_cells = 0;
+    uint32_t database_start = 0;
     uint32_t part = 1;
     const float part_size = database_chunk / (float)1000000000;
     Part parts[2];
-    std::future<int> pending;                        // the device's work on the previous part
+    std::future<int> pending;                            // the device's work on the previous part
     while (true) {
+        // the part as flat residue codes (readFastaCodesPart: the records and part boundaries of readFastaChainsPart, :93-97,
+        // without building the chains this stage would delete again at :125-129)
         auto t0 = std::chrono::steady_clock::now();
-        const int status = readFastaChainsPart(&database, &database_length, handle, serialized, database_chunk);
+        Part& p = parts[part & 1];                       // the other one may still be on its way to the device
+        free(p.codes); free(p.off);
+        p.codes = nullptr; p.off = nullptr;
+        int records = 0;
+        const int status = readFastaCodesPart(&p.codes, &p.off, &records, handle, serialized, database_chunk);
+        p.n = (uint32_t)records;
+        p.first_id = database_start;
+        database_cells += p.off[records];
         t_read += seconds_since(t0);
         databaseLog(part, part_size, 0);
-        t0 = std::chrono::steady_clock::now();
-
-        Part& p = parts[part & 1];                   // the other one may still be on its way to the device
-        p.first_id = (uint32_t)database_start;
-        p.off.assign(1, 0);
-        size_t residues = 0;
-        for (int i = database_start; i < database_length; ++i) residues += (size_t)chainGetLength(database[i]);
-        p.codes.resize(residues ? residues : 1);
-        size_t at = 0;
-        for (int i = database_start; i < database_length; ++i) {
-            const int n = chainGetLength(database[i]);
-            memcpy(p.codes.data() + at, chainGetCodes(database[i]), (size_t)n);
-            at += (size_t)n;
-            p.off.push_back(at);
-            chainDelete(database[i]);                // database_search.cpp:125-129
-            database[i] = nullptr;
-        }
-        database_cells += residues;
-        t_flatten += seconds_since(t0);
 
         t0 = std::chrono::steady_clock::now();
         if (created.valid() && created.get() != S4G_OK) die("prefilter");
         if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
         pending = std::async(std::launch::async, [filter, &p]() {
-            return s4g_prefilter_add(filter, p.codes.data(), p.off.data(), (uint32_t)(p.off.size() - 1), p.first_id);
+            return s4g_prefilter_add(filter, (const uint8_t*)p.codes, (const uint64_t*)p.off, p.n, p.first_id);
         });
         t_wait += seconds_since(t0);
 
         databaseLog(part, part_size, 100);
         ++part;
+        database_start += (uint32_t)records;
         if (status == 0) break;
-        database_start = database_length;
     }
     auto t0 = std::chrono::steady_clock::now();
     if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
     t_wait += seconds_since(t0);
     t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "\n\n");
+    for (Part& p : parts) { free(p.codes); free(p.off); }
 
     fclose(handle);
     deleteFastaChains(database, database_length);
@@ -146,8 +139,8 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     if (s4g_prefilter_finish(filter, ids.data(), counts.data(), nullptr) != S4G_OK) die("prefilter");
     s4g_prefilter_destroy(filter);
     if (getenv("S4G_PROFILE"))
-        fprintf(stderr, "[s4g profile] prefilter stage: reading FASTA %.3f s, flattening chains %.3f s, waiting for the device %.3f s, lists to the host %.3f s\n",
-                t_read, t_flatten, t_wait, seconds_since(t0));
+        fprintf(stderr, "[s4g profile] prefilter stage: reading FASTA into flat codes %.3f s, waiting for the device %.3f s, lists to the host %.3f s\n",
+                t_read, t_wait, seconds_since(t0));
     dst.clear();
     dst.resize(queries_length);
     for (int32_t i = 0; i < queries_length; ++i)

@@ -205,15 +205,40 @@ void push_chain(Chain*** chains, int* len, int* cap, Chain* c) {
     (*chains)[(*len)++] = c;
 }
 
+// Where a part's records go when the caller wants no Chain objects (readFastaCodesPart): residue codes back to back and
+// one offset per record.  Lines are converted straight out of the read buffer; `raw` counts the sequence bytes of the pending
+// record as the chain reader's st->seq would, so that parts end at the same records.
+struct FlatSink {
+    std::vector<char> codes;
+    std::vector<size_t> off;        // off[i] = first code of record i; a final entry is appended when the part ends
+    size_t raw = 0;
+    void line(const char* p, size_t n) {
+        const size_t at = codes.size();
+        codes.resize(at + n);
+        char* out = codes.data() + at;
+        size_t k = 0;
+        for (size_t i = 0; i < n; ++i) { const unsigned char c = kResidue.code[(unsigned char)p[i]]; out[k] = (char)c; k += (c != 0xFF); }
+        codes.resize(at + k);
+        raw += n;
+    }
+};
+
 // Reads records until >= max_bytes of sequence were consumed (0 = unlimited) or EOF. Returns 1 if more remain.
 // Block reads (4 MB) scanned with memchr; a record's residues go through the lookup table once, straight into the
 // chain's own storage (121 MB of UniProt-style FASTA: 1.1 s with the former line-by-line reader).
-int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
-    int cap = *len;
+int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, FlatSink* flat = nullptr) {
+    int cap = chains ? *len : 0;
     size_t consumed = 0;
     if (st->buf.empty()) st->buf.resize(4u << 20);
+    if (flat && st->have_pending) flat->off.push_back(flat->codes.size());       // the record whose header closed the part before
     auto flush = [&]() {
         if (!st->have_pending) return;
+        if (flat) {                              // the record's codes are in place already; it only has to be closed
+            consumed += flat->raw;
+            flat->raw = 0;
+            st->have_pending = false;
+            return;
+        }
         ChainData* d = chain_data_alloc(st->pending_name.data(), st->pending_name.size(), st->seq.size());
         chain_data_append(d, st->seq.data(), st->seq.size());
         d->chars[d->length] = 0;
@@ -261,11 +286,12 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
                 st->in_header = false;
                 st->have_pending = true;
                 if (max_bytes && consumed >= max_bytes) stop = true;       // this header opens the next part
+                else if (flat) flat->off.push_back(flat->codes.size());
             }
         } else if (st->have_pending) {
             size_t n = (size_t)(seg_end - p);
             if (nl && n && seg_end[-1] == '\r') --n;
-            st->seq.insert(st->seq.end(), p, p + n);
+            if (flat) flat->line(p, n); else st->seq.insert(st->seq.end(), p, p + n);
         }
         st->pos = nl ? (size_t)(nl + 1 - st->buf.data()) : st->end;
         st->at_line_start = nl != NULL;
@@ -275,6 +301,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
             while (!st->pending_name.empty() && st->pending_name.back() == '\r') st->pending_name.pop_back();
             st->in_header = false;
             st->have_pending = true;
+            if (flat) flat->off.push_back(flat->codes.size());
         }
         flush();
         if (st->cache_out) {              // the whole file has been read: totals into the header, then the cache becomes visible under its final name
@@ -286,13 +313,13 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
             if (!ok || rename(st->cache_tmp.c_str(), st->cache_final.c_str()) != 0) remove(st->cache_tmp.c_str());
         }
     }
-    if (*len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
+    if (chains && *len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
     return st->eof ? 0 : 1;
 }
 
 // The same from the serialized cache: records until >= max_bytes of sequence were consumed (0 = unlimited) or EOF.
-int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
-    int cap = *len;
+int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, FlatSink* flat = nullptr) {
+    int cap = chains ? *len : 0;
     size_t consumed = 0;
     std::string name;
     for (;;) {
@@ -302,6 +329,20 @@ int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
         SW_ASSERT(got == sizeof hdr, "truncated serialized database cache");
         name.resize(hdr[0]);
         SW_ASSERT(!hdr[0] || fread(&name[0], hdr[0], 1, st->fh) == 1, "truncated serialized database cache");
+        if (flat) {
+            const size_t at = flat->codes.size();
+            flat->off.push_back(at);
+            flat->codes.resize(at + hdr[1]);
+            SW_ASSERT(!hdr[1] || fread(flat->codes.data() + at, hdr[1], 1, st->fh) == 1, "truncated serialized database cache");
+            for (uint32_t i = 0; i < hdr[1]; ++i) flat->codes[at + i] = (char)(flat->codes[at + i] - 'A');
+            consumed += hdr[2];
+            if (max_bytes && consumed >= max_bytes) {
+                const int c = fgetc(st->fh);
+                if (c == EOF) st->eof = true; else ungetc(c, st->fh);
+                break;
+            }
+            continue;
+        }
         ChainData* d = chain_data_alloc(name.data(), name.size(), hdr[1]);
         SW_ASSERT(!hdr[1] || fread(d->chars, hdr[1], 1, st->fh) == 1, "truncated serialized database cache");
         for (uint32_t i = 0; i < hdr[1]; ++i) d->codes[i] = (char)(d->chars[i] - 'A');
@@ -315,7 +356,7 @@ int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes) {
             break;
         }
     }
-    if (*len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
+    if (chains && *len < cap) *chains = (Chain**)xrealloc(*chains, sizeof(Chain*) * (size_t)(*len ? *len : 1));
     return st->eof ? 0 : 1;
 }
 
@@ -355,6 +396,27 @@ SW_API int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, in
     SW_ASSERT((serialized != 0) == st->serialized_in, "readFastaChainsPart: `serialized` does not belong to this handle");
     int more = st->serialized_in ? cache_read(st, chains, chainsLen, maxBytes) : fasta_read(st, chains, chainsLen, maxBytes);
     if (!more) fasta_forget(handle);   // caller fclose()s the handle itself (database_alignment.cpp:122)
+    return more;
+}
+
+// Extension: the next part of the file as residue codes only -- no Chain objects, no names -- for callers that hand the
+// sequences straight to the device (the k-mer prefilter of dropin/device_database_search.cpp).  Same records, same residues
+// (chainGetCodes of the chains readFastaChainsPart would have returned, back to back) and the same part boundaries.  *codes and
+// *offsets (records + 1 entries, offsets[0] = 0) are malloc'ed; the caller frees them.  Returns 1 if more parts remain.  A handle
+// is read either with this function or with readFastaChainsPart, not both.
+SW_API int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes) {
+    FastaState* st = fasta_state(handle, true);
+    SW_ASSERT((serialized != 0) == st->serialized_in, "readFastaCodesPart: `serialized` does not belong to this handle");
+    cache_abandon(st);          // a pass that keeps no names cannot write the serialized cache (S4G_FASTA_CACHE=1): none is left behind
+    FlatSink flat;
+    const int more = st->serialized_in ? cache_read(st, NULL, NULL, maxBytes, &flat) : fasta_read(st, NULL, NULL, maxBytes, &flat);
+    flat.off.push_back(flat.codes.size());
+    *recordsLen = (int)flat.off.size() - 1;
+    *codes = (char*)xmalloc(flat.codes.size() ? flat.codes.size() : 1);
+    memcpy(*codes, flat.codes.data(), flat.codes.size());
+    *offsets = (size_t*)xmalloc(sizeof(size_t) * flat.off.size());
+    memcpy(*offsets, flat.off.data(), sizeof(size_t) * flat.off.size());
+    if (!more) fasta_forget(handle);
     return more;
 }
 

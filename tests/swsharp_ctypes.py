@@ -28,6 +28,7 @@ SIG = {
     "readFastaChainsPartInit": (None, [ctypes.POINTER(pvp), pi, pvp, pi, ctypes.c_char_p]),
     "readFastaChainsPart": (ci, [ctypes.POINTER(pvp), pi, vp, ci, ctypes.c_size_t]),
     "deleteFastaChains": (None, [pvp, ci]),
+    "readFastaCodesPart": (ci, [ctypes.POINTER(ctypes.POINTER(ctypes.c_ubyte)), ctypes.POINTER(ctypes.POINTER(ctypes.c_size_t)), pi, vp, ci, ctypes.c_size_t]),
     "fastaResidueCount": (None, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "scorerCreateMatrix": (None, [pvp, ctypes.c_char_p, ci, ci]),
     "scorerDelete": (None, [vp]),

@@ -102,6 +102,35 @@ def test_read_fasta_odd_files(tmp_path):
     assert parts >= 10
     check(chains, n)
     sw.libc.fclose(fh)
+    # the flat reader (readFastaCodesPart: what the device prefilter's wrapper reads with): the same records and residue codes,
+    # and parts that end at the same records as the chain reader's
+    for part_bytes in (300000, 700, 0):
+        c2, n2, fh2, ser2 = pvp(), ci(), vp(), ci()
+        L.readFastaChainsPartInit(ctypes.byref(c2), ctypes.byref(n2), ctypes.byref(fh2), ctypes.byref(ser2), str(path).encode())
+        d1, d2, fh1, ser1 = pvp(), ci(), vp(), ci()
+        L.readFastaChainsPartInit(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(fh1), ctypes.byref(ser1), str(path).encode())
+        rec = 0
+        while True:
+            codes, offs, k = ctypes.POINTER(ctypes.c_ubyte)(), ctypes.POINTER(ctypes.c_size_t)(), ci()
+            more = L.readFastaCodesPart(ctypes.byref(codes), ctypes.byref(offs), ctypes.byref(k), fh2, ser2, part_bytes)
+            more_chains = L.readFastaChainsPart(ctypes.byref(d1), ctypes.byref(d2), fh1, ser1, part_bytes)
+            assert more == more_chains and rec + k.value == d2.value          # the same part boundaries
+            assert offs[0] == 0
+            for i in range(k.value):
+                ln = offs[i + 1] - offs[i]
+                assert ln == len(want[rec + i][1]), (part_bytes, rec + i)
+                if ln < 10000 and ((rec + i) < 6 or (rec + i) % 11 == 0 or rec + i == len(want) - 1):
+                    assert [codes[offs[i] + j] for j in range(ln)] == want[rec + i][1], rec + i
+            if k.value > 3 and rec <= 3 < rec + k.value:          # the 5 MB record, sampled
+                o = offs[3 - rec]
+                assert [codes[o + j] for j in (0, 1, 4 * 1024 * 1024 - 40, len(want[3][1]) - 1)] == [want[3][1][j] for j in (0, 1, 4 * 1024 * 1024 - 40, len(want[3][1]) - 1)]
+            rec += k.value
+            sw.libc.free(ctypes.cast(codes, vp)); sw.libc.free(ctypes.cast(offs, vp))
+            if not more:
+                break
+        assert rec == len(want)
+        sw.libc.fclose(fh2); sw.libc.fclose(fh1)
+        L.deleteFastaChains(d1, d2)
     L.deleteFastaChains(chains, n)
 
 
@@ -470,6 +499,30 @@ def test_serialized_database_cache(tmp_path, monkeypatch):
     assert ser == 0 and parts[0][-1] == ("late", tuple(ord(x) - 65 for x in "ACDEFGHIK"))
     ser, again = _read_parts(fa, 0)
     assert ser == 1 and again == parts
+    # the flat reader on the cache (serialized = 1): the same codes, record by record, in the same parts; and a flat pass over
+    # the TEXT with caching on leaves no cache behind (it keeps no names to write)
+    def flat_parts(chunk):
+        c, n, fh, ser = pvp(), ci(0), vp(), ci(0)
+        L.readFastaChainsPartInit(ctypes.byref(c), ctypes.byref(n), ctypes.byref(fh), ctypes.byref(ser), str(fa).encode())
+        out = []
+        while True:
+            codes, offs, k = ctypes.POINTER(ctypes.c_ubyte)(), ctypes.POINTER(ctypes.c_size_t)(), ci()
+            more = L.readFastaCodesPart(ctypes.byref(codes), ctypes.byref(offs), ctypes.byref(k), fh, ser.value, chunk)
+            out.append([tuple(codes[j] for j in range(offs[i], offs[i + 1])) for i in range(k.value)])
+            sw.libc.free(ctypes.cast(codes, vp)); sw.libc.free(ctypes.cast(offs, vp))
+            if not more:
+                break
+        sw.libc.fclose(fh)
+        return ser.value, out
+    for chunk in (0, 300):
+        ser_c, chain_parts = _read_parts(fa, chunk)
+        ser_f, flat = flat_parts(chunk)
+        assert ser_c == ser_f == 1 and flat == [[c for _, c in p] for p in chain_parts]
+    cache.unlink()
+    ser_f, flat = flat_parts(300)
+    assert ser_f == 0 and not cache.exists() and sorted(p.name for p in tmp_path.iterdir()) == ["db.fa"]
+    assert [c for p in flat for c in p] == [c for _, c in parts[0]]
+    assert _read_parts(fa, 0)[0] == 0 and cache.exists()              # (a chain pass writes it again for the checks below)
     # totals of the file (what the full-scan build's counting stage asks for): from the cache header, or by a pass over the text
     want_res = sum(len(c) for _, c in parts[0])
     for env in ("1", None):
