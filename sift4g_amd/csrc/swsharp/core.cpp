@@ -9,6 +9,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <deque>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "../matrices.h"
 
@@ -209,16 +212,33 @@ void push_chain(Chain*** chains, int* len, int* cap, Chain* c) {
 // one offset per record.  Lines are converted straight out of the read buffer; `raw` counts the sequence bytes of the pending
 // record as the chain reader's st->seq would, so that parts end at the same records.
 struct FlatSink {
-    std::vector<char> codes;
+    char* codes = NULL;             // malloc'ed, handed to the caller as it is
+    size_t used = 0, cap = 0;
     std::vector<size_t> off;        // off[i] = first code of record i; a final entry is appended when the part ends
     size_t raw = 0;
+    void reserve(size_t n) {
+        if (used + n <= cap) return;
+        cap = std::max(used + n + (4u << 20), cap + cap / 2);
+        codes = (char*)xrealloc(codes, cap);
+    }
     void line(const char* p, size_t n) {
-        const size_t at = codes.size();
-        codes.resize(at + n);
-        char* out = codes.data() + at;
-        size_t k = 0;
-        for (size_t i = 0; i < n; ++i) { const unsigned char c = kResidue.code[(unsigned char)p[i]]; out[k] = (char)c; k += (c != 0xFF); }
-        codes.resize(at + k);
+        reserve(n + 16);
+        char* out = codes + used;
+        size_t k = 0, i = 0;
+#if defined(__SSE2__)
+        // a line of upper-case letters only (nearly every line of a protein database): 16 residues per step, code = letter - 'A';
+        // anything else in the line sends the whole line through the table below
+        const __m128i a = _mm_set1_epi8('A'), bias = _mm_set1_epi8((char)-128), top = _mm_set1_epi8((char)(25 - 128));
+        __m128i bad = _mm_setzero_si128();
+        for (; i + 16 <= n; i += 16) {
+            const __m128i t = _mm_sub_epi8(_mm_loadu_si128((const __m128i*)(p + i)), a);
+            bad = _mm_or_si128(bad, _mm_cmpgt_epi8(_mm_add_epi8(t, bias), top));       // unsigned t > 25
+            _mm_storeu_si128((__m128i*)(out + i), t);
+        }
+        if (_mm_movemask_epi8(bad)) i = 0; else k = i;
+#endif
+        for (; i < n; ++i) { const unsigned char c = kResidue.code[(unsigned char)p[i]]; out[k] = (char)c; k += (c != 0xFF); }
+        used += k;
         raw += n;
     }
 };
@@ -230,7 +250,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
     int cap = chains ? *len : 0;
     size_t consumed = 0;
     if (st->buf.empty()) st->buf.resize(4u << 20);
-    if (flat && st->have_pending) flat->off.push_back(flat->codes.size());       // the record whose header closed the part before
+    if (flat && st->have_pending) flat->off.push_back(flat->used);       // the record whose header closed the part before
     auto flush = [&]() {
         if (!st->have_pending) return;
         if (flat) {                              // the record's codes are in place already; it only has to be closed
@@ -286,7 +306,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
                 st->in_header = false;
                 st->have_pending = true;
                 if (max_bytes && consumed >= max_bytes) stop = true;       // this header opens the next part
-                else if (flat) flat->off.push_back(flat->codes.size());
+                else if (flat) flat->off.push_back(flat->used);
             }
         } else if (st->have_pending) {
             size_t n = (size_t)(seg_end - p);
@@ -301,7 +321,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
             while (!st->pending_name.empty() && st->pending_name.back() == '\r') st->pending_name.pop_back();
             st->in_header = false;
             st->have_pending = true;
-            if (flat) flat->off.push_back(flat->codes.size());
+            if (flat) flat->off.push_back(flat->used);
         }
         flush();
         if (st->cache_out) {              // the whole file has been read: totals into the header, then the cache becomes visible under its final name
@@ -330,11 +350,12 @@ int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
         name.resize(hdr[0]);
         SW_ASSERT(!hdr[0] || fread(&name[0], hdr[0], 1, st->fh) == 1, "truncated serialized database cache");
         if (flat) {
-            const size_t at = flat->codes.size();
+            const size_t at = flat->used;
             flat->off.push_back(at);
-            flat->codes.resize(at + hdr[1]);
-            SW_ASSERT(!hdr[1] || fread(flat->codes.data() + at, hdr[1], 1, st->fh) == 1, "truncated serialized database cache");
+            flat->reserve(hdr[1]);
+            SW_ASSERT(!hdr[1] || fread(flat->codes + at, hdr[1], 1, st->fh) == 1, "truncated serialized database cache");
             for (uint32_t i = 0; i < hdr[1]; ++i) flat->codes[at + i] = (char)(flat->codes[at + i] - 'A');
+            flat->used = at + hdr[1];
             consumed += hdr[2];
             if (max_bytes && consumed >= max_bytes) {
                 const int c = fgetc(st->fh);
@@ -410,10 +431,10 @@ SW_API int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, F
     cache_abandon(st);          // a pass that keeps no names cannot write the serialized cache (S4G_FASTA_CACHE=1): none is left behind
     FlatSink flat;
     const int more = st->serialized_in ? cache_read(st, NULL, NULL, maxBytes, &flat) : fasta_read(st, NULL, NULL, maxBytes, &flat);
-    flat.off.push_back(flat.codes.size());
+    flat.off.push_back(flat.used);
     *recordsLen = (int)flat.off.size() - 1;
-    *codes = (char*)xmalloc(flat.codes.size() ? flat.codes.size() : 1);
-    memcpy(*codes, flat.codes.data(), flat.codes.size());
+    flat.reserve(1);
+    *codes = flat.codes;
     *offsets = (size_t*)xmalloc(sizeof(size_t) * flat.off.size());
     memcpy(*offsets, flat.off.data(), sizeof(size_t) * flat.off.size());
     if (!more) fasta_forget(handle);
