@@ -267,6 +267,8 @@ int s4g_clock_probe(int device, double* out, uint32_t cap);
  *   s4g_prefilter_finish   h_ids / h_scores: n_queries rows of max_candidates; the first h_counts[q] of row q are valid, ids
  *                          ascending as searchDatabase returns them (database_search.cpp:166-178).  h_scores may be NULL.
  *                          May be called more than once; adding after it is allowed (it only reads the running lists).
+ * A handle is used by one thread at a time; an error other than S4G_ERR_INVALID on an argument leaves its lists undefined
+ * (destroy it).  Residue codes may be any 5-bit value (0..31); the 134 MB index at k = 5 is sized for that.
  *   s4g_prefilter_stats    out[0] = k-mer hits looked up so far, out[1] = (query, target) pairs with at least one hit,
  *                          out[2] = of those, pairs whose LIS ran on a whole wave (more than 32 hits), out[3] = chunks. cap >= 4. */
 typedef struct s4g_prefilter s4g_prefilter;

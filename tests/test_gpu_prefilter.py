@@ -195,3 +195,37 @@ def test_chunk_already_on_the_device():
     ref = oracle.Prefilter(queries, 5, 30)
     ref.add(targets)
     _assert_equal(got, ref.finish())
+
+
+def test_randomised_soak():
+    """a time-boxed run of random configurations (k, sizes, alphabets that make hits rare or dense, repeats, planted homologs,
+    empty and tiny sequences, chunking, pass size) against the restatement"""
+    import time
+    rng = np.random.default_rng(2024)
+    deadline = time.time() + 20.0
+    rounds = 0
+    while time.time() < deadline or rounds < 6:
+        k = int(rng.integers(3, 6))
+        alphabet = int(rng.choice([2, 4, 20, 25]))
+        nq, nt = int(rng.integers(1, 40)), int(rng.integers(1, 1500))
+        queries = [rng.integers(0, alphabet, size=int(n)).astype(np.uint8) for n in rng.integers(0, 300, size=nq)]
+        targets = [rng.integers(0, alphabet, size=int(n)).astype(np.uint8) for n in rng.integers(0, 400, size=nt)]
+        for _ in range(int(rng.integers(0, 12))):                  # homologs and exact copies
+            q = queries[int(rng.integers(0, nq))]
+            if len(q):
+                m = q.copy()
+                m[rng.integers(0, len(m), size=len(m) // 10)] = rng.integers(0, alphabet, size=len(m) // 10)
+                targets[int(rng.integers(0, nt))] = m
+        if alphabet == 2 and nq * nt > 20000:                      # dense hits: keep the hit count in the millions
+            queries, targets = queries[:6], targets[:300]
+        max_candidates = int(rng.choice([1, 3, 50, 5000]))
+        cuts = sorted(set(int(x) for x in rng.integers(0, len(targets) + 1, size=int(rng.integers(0, 4)))))
+        chunks = [targets[a:b] for a, b in zip([0] + cuts, cuts + [len(targets)])]
+        os.environ["S4G_PREFILTER_PASS_HITS"] = str(int(rng.choice([1000, 50000, 1 << 26])))
+        try:
+            dev, ref, _ = _both(queries, chunks, k, max_candidates)
+        finally:
+            del os.environ["S4G_PREFILTER_PASS_HITS"]
+        _assert_equal(dev, ref)
+        rounds += 1
+    assert rounds >= 6
