@@ -29,9 +29,10 @@ constexpr uint32_t kPfLdsTails = 4096;          // tails a wave keeps in LDS (16
 constexpr uint64_t kPfNoEntry = ~0ull;          // empty slot of a candidate list: sorts behind everything
 
 // the k-mer starting at codes[j] (hash.cpp:33-43: ((kmer << 5) | code) & mask, most significant residue first)
+// (codes are cut to 5 bits: a code of 32 or more is reported through the `bad` flag, and must not index past the tables first)
 __device__ __forceinline__ uint32_t pf_kmer(const uint8_t* __restrict__ c, uint32_t k) {
     uint32_t v = 0;
-    for (uint32_t i = 0; i < k; ++i) v = (v << kKmerBits) | c[i];
+    for (uint32_t i = 0; i < k; ++i) v = (v << kKmerBits) | (c[i] & 31u);
     return v;
 }
 
@@ -85,7 +86,7 @@ __device__ __forceinline__ uint32_t pf_bucket(const PfChunk& a, const uint8_t* _
     if (j >= n_kmers) return 0;
     const uint32_t v = pf_kmer(c + j, a.k);
     if (j != 0) {                                                       // database_search.cpp:212: equal to the k-mer before it
-        const uint32_t prev = ((uint32_t)c[j - 1] << ((a.k - 1) * kKmerBits)) | (v >> kKmerBits);
+        const uint32_t prev = ((uint32_t)(c[j - 1] & 31u) << ((a.k - 1) * kKmerBits)) | (v >> kKmerBits);
         if (prev == v) return 0;
     }
     if (!((a.present[v >> 5] >> (v & 31)) & 1u)) return 0;
