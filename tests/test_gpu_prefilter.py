@@ -202,7 +202,7 @@ def test_randomised_soak():
     empty and tiny sequences, chunking, pass size) against the restatement"""
     import time
     rng = np.random.default_rng(2024)
-    deadline = time.time() + 20.0
+    deadline = time.time() + float(os.environ.get("S4G_PREFILTER_SOAK_SECONDS", "20"))      # longer runs: set the variable
     rounds = 0
     while time.time() < deadline or rounds < 6:
         k = int(rng.integers(3, 6))
