@@ -211,3 +211,77 @@ def test_streaming_topk_over_several_query_batches(s4g):
     sids, ssc, scnt = s4g.scan_topk(db, q, scorer, 50, 1)
     assert torch.equal(cnt, scnt) and torch.equal(sc, ssc) and torch.equal(ids, sids)
     assert int(sc[:, 0].max()) > 150
+
+
+def test_configs3_prefilter_streams_one_gpus_share(s4g, oracle_mod):
+    """The k-mer prefilter over one GPU's share of configs[3]: the same 20 M device-generated targets (6.8e9
+    residues, offsets beyond 32 bits), handed to s4g_prefilter_add_device in parts of 700 000 targets where they lie.  The planted
+    copy of every query must be in its list with the score of an exact copy; the lists must not depend on how the database was
+    cut into parts; the candidates of four queries are re-scored by the CPU restatement (ids fetched back from the device) and
+    must carry bit-identical float scores; and no target of a 300 000-target sample that is missing from a list beats its cut."""
+    import oracle
+    from sift4g_amd import synth
+    from sift4g_amd import device as s4gd
+    N, Q, K, MAXC = 20_000_000, 64, 5, 5000
+    dev = torch.device("cuda", 0)
+    codes, offsets = synth.device_database(N, synth.SEED_BASE + 4 + 0x1000, dev)
+    ql = synth.query_lengths(synth.SEED_BASE + 4 + 0x100, Q)
+    q_codes, q_off = synth.random_set(synth.SEED_BASE + 4 + 0x200, ql)
+    queries = [q_codes[int(q_off[i]):int(q_off[i + 1])] for i in range(Q)]
+    lens = (offsets[1:] - offsets[:-1])
+    planted = []
+    for i in range(Q):
+        p = (i + 1) * (N // (Q + 1))
+        while int(lens[p]) < ql[i]:
+            p += 1
+        planted.append(p)
+        o = int(offsets[p])
+        codes[o:o + int(ql[i])] = torch.from_numpy(queries[i].copy()).to(dev)
+    torch.cuda.synchronize()
+
+    def run(part):
+        p = s4gd.Prefilter(queries, K, MAXC)
+        for t0 in range(0, N, part):
+            t1 = min(N, t0 + part)
+            p.add_device(codes, offsets[t0:t1 + 1], first_id=t0)          # offsets stay absolute: the part is read where it lies
+        out = p.finish()
+        st = p.stats()
+        p.close()
+        return out, st
+
+    (ids, counts, scores), st = run(700_000)
+    assert st["chunks"] == 29 and (counts == MAXC).all() and st["pairs"] > Q * MAXC
+    for i in range(Q):
+        row = ids[i, :MAXC].astype(np.int64)
+        assert (np.diff(row) > 0).all() and row[-1] < N                   # ascending, unique, in range
+        at = int(np.searchsorted(row, planted[i]))
+        assert row[at] == planted[i], i
+        lt = int(lens[planted[i]])
+        assert scores[i, at] >= np.float32(int(ql[i]) - K + 1) / np.float32(lt), i      # at least the copy's own k-mers, in order
+    (ids2, counts2, scores2), _ = run(1_300_000)
+    assert np.array_equal(ids, ids2) and np.array_equal(counts, counts2) and np.array_equal(scores.view(np.uint32), scores2.view(np.uint32))
+    # the restatement on the candidates of four queries
+    off_h = offsets.cpu().numpy()
+    fetch = lambda t: codes[int(off_h[t]):int(off_h[t + 1])].cpu().numpy()
+    for i in (0, 21, 42, 63):
+        seqs = [fetch(int(t)) for t in ids[i, :MAXC]]
+        ref = oracle.Prefilter([queries[i]], K, MAXC)
+        lis = ref.lis(seqs)[0]
+        want = lis.astype(np.float32) / np.array([len(s) for s in seqs], dtype=np.float32)
+        assert np.array_equal(want.view(np.uint32), scores[i, :MAXC].view(np.uint32)), i
+    # nothing outside a list beats its cut: a random sample of targets through the restatement
+    rng = np.random.default_rng(43)
+    sample = np.unique(rng.integers(0, N, 300_000))
+    seqs = [fetch(int(t)) for t in sample[:40_000]]                           # 40 000 sequences come back to the host
+    check = [0, 21, 42, 63]
+    ref = oracle.Prefilter([queries[i] for i in check], K, MAXC)
+    lis = ref.lis(seqs)
+    ln = np.array([len(s) for s in seqs], dtype=np.float32)
+    for r, i in enumerate(check):
+        sc = lis[r].astype(np.float32) / ln
+        cut = scores[i, :MAXC].min()
+        members = set(ids[i, :MAXC].tolist())
+        for j in np.nonzero(sc >= cut)[0]:
+            t = int(sample[j])
+            if t not in members:                                              # equal to the cut and a higher index than every kept tie
+                assert sc[j] == cut and t > max(int(x) for x, s_ in zip(ids[i, :MAXC], scores[i, :MAXC]) if s_ == cut), (i, t)
