@@ -67,6 +67,10 @@ def test_no_gpu_fails_loudly():
     assert e.value.code == S4G_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
     with pytest.raises(S4GError):
         s.QuerySet([np.zeros(4, dtype=np.uint8)])
+    from sift4g_amd import device as s4gd
+    with pytest.raises(S4GError) as e:                      # the k-mer prefilter has no CPU path either
+        s4gd.Prefilter([np.zeros(8, dtype=np.uint8)], 5, 10)
+    assert e.value.code == S4G_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
 
 
 def test_product_never_touches_the_oracle():
