@@ -85,7 +85,16 @@ CASES = [
     dict(name="k3_no_cut", seed=14, nq=4, nt=200, k=3, max_candidates=5000, repeats=True),
     dict(name="k3_cut_20", seed=15, nq=5, nt=400, k=3, max_candidates=20, repeats=False),
     dict(name="k5_cut_8", seed=16, nq=6, nt=2000, k=5, max_candidates=8, repeats=False),
+    # larger databases: where nothing is cut off, only a SHA-256 of the lists is stored (`digest`)
+    dict(name="k5_big_no_cut", seed=21, nq=30, nt=20000, k=5, max_candidates=5000, repeats=True, digest=True),
+    dict(name="k4_big_no_cut", seed=22, nq=12, nt=8000, k=4, max_candidates=8000, repeats=True, digest=True),
+    dict(name="k5_big_cut_100", seed=23, nq=24, nt=20000, k=5, max_candidates=100, repeats=False),
 ]
+
+
+def lists_digest(lists):
+    import hashlib
+    return hashlib.sha256(json.dumps([[int(x) for x in l] for l in lists], separators=(",", ":")).encode()).hexdigest()
 
 
 def main():
@@ -102,6 +111,13 @@ def main():
         pf.add([oracle.encode(t) for t in targets])
         ids, counts, scores, cut = pf.finish()
         entry = dict(c, cells=cells1, lists=[])
+        if c.get("digest"):
+            assert l1 == l4 and all(x == 0.0 for x in cut), c["name"]
+            entry["lists_sha256"] = lists_digest(l1)
+            entry["list_sizes"] = [len(x) for x in l1]
+            out.append(entry)
+            print(c["name"], "cells", cells1, "list sizes", entry["list_sizes"][:8], "...")
+            continue
         for q in range(c["nq"]):
             if cut[q] == 0.0:                              # nothing cut off: one answer
                 assert l1[q] == l4[q], (c["name"], q)
