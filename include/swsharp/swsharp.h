@@ -66,7 +66,7 @@ void deleteFastaChains(Chain** chains, int chainsLen);
 /* Extension: totals of a FASTA file (records, residues as chainGetLength counts them) without keeping any chain: from the header of
  * the serialized cache when there is a valid one (S4G_FASTA_CACHE=1), else by one pass over the file.  Used by the full-scan
  * build in place of the k-mer prefilter's pass (sift4g_amd/csrc/dropin/count_database_search.cpp). */
-int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes);   /* extension: a part as flat residue codes, no Chain objects; caller frees both arrays */
+int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes);   /* extension: the part readFastaChainsPart would return (database_search.cpp:93-97), as flat residue codes: no Chain objects to delete again (:125-129); caller frees both arrays */
 void fastaResidueCount(const char* path, long long* records, long long* residues);                      /* skips NULL entries */
 
 /* ---- Scorer (main.cpp:208,223; names main.cpp:304-314) ---- */
