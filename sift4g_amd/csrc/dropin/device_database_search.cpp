@@ -38,8 +38,14 @@ uint32_t chunk_bytes() {
     return n > 0 ? (uint32_t)n : 250000000u;
 }
 
+// the library's error text is kept per thread, and the device calls below run on helper threads: they hand the text back
+std::string g_async_error;
+int remember(int rc) {
+    if (rc != S4G_OK) g_async_error = s4g_last_error();
+    return rc;
+}
 void die(const char* what) {
-    fprintf(stderr, "[ERROR] %s: %s\n", what, s4g_last_error());
+    fprintf(stderr, "[ERROR] %s: %s\n", what, g_async_error.empty() ? s4g_last_error() : g_async_error.c_str());
     exit(1);
 }
 
@@ -78,8 +84,8 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     // the index is built while the first part of the database is being read (and while the device finishes warming up)
     s4g_prefilter* filter = nullptr;
     std::future<int> created = std::async(std::launch::async, [&]() {
-        return s4g_prefilter_create(&filter, device_of_choice(), q.codes.data(), q.off.data(), (uint32_t)queries_length, kmer_length,
-                                    max_candidates);
+        return remember(s4g_prefilter_create(&filter, device_of_choice(), q.codes.data(), q.off.data(), (uint32_t)queries_length,
+                                             kmer_length, max_candidates));
     });
 
     Chain** database = nullptr;
@@ -115,7 +121,7 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
         if (created.valid() && created.get() != S4G_OK) die("prefilter");
         if (pending.valid() && pending.get() != S4G_OK) die("prefilter");
         pending = std::async(std::launch::async, [filter, &p]() {
-            return s4g_prefilter_add(filter, (const uint8_t*)p.codes, (const uint64_t*)p.off, p.n, p.first_id);
+            return remember(s4g_prefilter_add(filter, (const uint8_t*)p.codes, (const uint64_t*)p.off, p.n, p.first_id));
         });
         t_wait += seconds_since(t0);
 
