@@ -488,9 +488,13 @@ def main():
                                       "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
                             tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
         if world == 1 and not db_shard and not args.no_prefilter and cfg is not None:
-            out["prefilter"] = prefilter_leg(cfg, dev_index)
-            if out["prefilter"]["check"]["mismatches"]:
-                log(f"PREFILTER CHECK FAILED: {out['prefilter']['check']}")
+            try:                                   # an extra leg must never cost the line the headline number
+                out["prefilter"] = prefilter_leg(cfg, dev_index)
+                if out["prefilter"]["check"]["mismatches"]:
+                    log(f"PREFILTER CHECK FAILED: {out['prefilter']['check']}")
+            except Exception as exc:               # reported, not hidden: the leg's absence shows in the line
+                out["prefilter"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"prefilter leg failed: {exc}")
         if world == 1 and not args.no_cpu_baseline and cfg is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
         line = json.dumps(out)
