@@ -153,10 +153,14 @@ def test_reference_cli_with_the_serialized_database_cache(tmp_path):
     files = os.path.join(GOLDEN, "test_files")
     db = tmp_path / "db.fa"
     shutil.copy(os.path.join(files, "sample_protein_database.fa"), db)
+    qdir = tmp_path / "q"                          # the query file too is read through the caching readers: keep its cache out of the fixtures
+    qdir.mkdir()
+    query = str(qdir / "query.fasta")
+    shutil.copy(os.path.join(files, "query.fasta"), query)
     for run in ("first", "second"):
         out = tmp_path / run
         out.mkdir()
-        r = subprocess.run([DROPIN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep, "-d", str(db), "--cards", "0",
+        r = subprocess.run([DROPIN, "-q", query, "--subst", files + os.sep, "-d", str(db), "--cards", "0",
                             "--out", str(out), "--sub-results"], env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert (tmp_path / "db.fa.s4gchains").exists()
@@ -168,8 +172,9 @@ def test_reference_cli_with_the_serialized_database_cache(tmp_path):
     if os.path.exists(FULLSCAN):
         out = tmp_path / "fullscan"
         out.mkdir()
-        r = subprocess.run([FULLSCAN, "-q", os.path.join(files, "query.fasta"), "--subst", files + os.sep, "-d", str(db), "--cards", "0",
+        r = subprocess.run([FULLSCAN, "-q", query, "--subst", files + os.sep, "-d", str(db), "--cards", "0",
                             "--out", str(out), "--sub-results"], env=env, cwd=str(out), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         for n in ("alignments.txt", "LACI_ECOLI.SIFTprediction", "PURR_SALTY.SIFTprediction"):
             assert (out / n).read_bytes() == open(os.path.join(GOLDEN, "dropin_fullscan", n), "rb").read(), n
+    assert not os.path.exists(os.path.join(files, "query.fasta.s4gchains"))
