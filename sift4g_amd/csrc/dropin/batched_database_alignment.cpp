@@ -16,6 +16,7 @@
 // submissions per chunk instead of two per query.  The alignments are identical (tests/test_gpu_swsharp.py compares the
 // two builds' outputs byte for byte).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -88,13 +89,23 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
     const size_t kChunkBytes = chunk_bytes();
     const float part_gb = kChunkBytes / 1e9f;
     int chunk_begin = 0;
+    double t_read = 0, t_cand = 0, t_lib = 0, t_rest = 0;           // S4G_PROFILE=1: where the stage's time goes
+    auto lap = [](std::chrono::steady_clock::time_point& t) {
+        const auto now = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(now - t).count();
+        t = now;
+        return s;
+    };
     for (uint32_t part = 1;; ++part) {
+        auto clock = std::chrono::steady_clock::now();
         const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunkBytes);
+        t_read += lap(clock);
         databaseLog(part, part_gb, 0);
 
         ChunkCandidates cand(indices, (uint32_t)chunk_begin, (uint32_t)database_length);
         std::vector<Chain*> pool(cand.ids.size());
         for (size_t k = 0; k < pool.size(); ++k) pool[k] = database[cand.ids[k]];
+        t_cand += lap(clock);
 
         DbAlignment*** found = nullptr;
         int* found_lengths = nullptr;
@@ -115,6 +126,7 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
                                       list_lens.data(), cards, cards_length, nullptr);
             chainDatabaseDelete(chunk_db);
         }
+        t_lib += lap(clock);
 
         // chains that carry an alignment stay alive (DbAlignment borrows them); the rest of this part goes
         std::vector<char> in_use(pool.size(), 0);
@@ -137,11 +149,15 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
                 database[i] = nullptr;
             }
 
+        t_rest += lap(clock);
         databaseLog(part, part_gb, 100);
         if (!more) break;
         chunk_begin = database_length;
     }
     fprintf(stderr, "\n\n");
+    if (getenv("S4G_PROFILE"))
+        fprintf(stderr, "[s4g profile] aligning stage: reading FASTA into chains %.3f s, candidate union %.3f s, library (database + scores + "
+                        "traceback) %.3f s, merge + deleting unused chains %.3f s\n", t_read, t_cand, t_lib, t_rest);
     fclose(handle);
     *database_out = database;
     *database_length_out = database_length;

@@ -40,6 +40,7 @@ struct Chain {
     int start;               // view window into data, inclusive
     int length;
     bool reverse;
+    bool embedded;           // this Chain object lives inside its ChainData's block (the chain the block was made for)
     char* rev_chars;         // materialised only for reverse views
     char* rev_codes;
 };
