@@ -13,12 +13,14 @@
 // (:61-95: createFilteredDatabase -> chainDatabaseCreate -> alignDatabase -> chainDatabaseDelete).  Here the candidates of
 // ALL queries inside a chunk form one ChainDatabase (each chain uploaded once, however many queries list it) and one
 // shotgunDatabaseCandidates call scores every (query, candidate) pair and traces every survivor back: two device
-// submissions per chunk instead of two per query.  The alignments are identical (tests/test_gpu_swsharp.py compares the
-// two builds' outputs byte for byte).
+// submissions per chunk instead of two per query -- and that call runs on a helper thread while the main thread reads the
+// next part of the file, so a database of many parts costs the longer of reading and aligning, not their sum.  The alignments
+// are identical (tests/test_gpu_swsharp.py compares the two builds' outputs byte for byte).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -72,6 +74,21 @@ struct ChunkCandidates {
     }
 };
 
+// One part of the database on its way through the library: the union of its candidates, every query's list as positions in
+// it, and what the library found.  The library call runs on a helper thread while the main thread reads the next part.
+struct PartJob {
+    int begin = 0, end = 0;                    // the part's range of database indices
+    ChunkCandidates cand;
+    std::vector<Chain*> pool;
+    DbAlignment*** found = nullptr;
+    int* found_lengths = nullptr;
+    std::future<void> running;
+    PartJob(std::vector<std::vector<uint32_t>>& indices, Chain** database, int begin_, int end_)
+        : begin(begin_), end(end_), cand(indices, (uint32_t)begin_, (uint32_t)end_), pool(cand.ids.size()) {
+        for (size_t k = 0; k < pool.size(); ++k) pool[k] = database[cand.ids[k]];
+    }
+};
+
 }  // namespace
 
 void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain*** database_out, int32_t* database_length_out,
@@ -88,76 +105,88 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
 
     const size_t kChunkBytes = chunk_bytes();
     const float part_gb = kChunkBytes / 1e9f;
-    int chunk_begin = 0;
-    double t_read = 0, t_cand = 0, t_lib = 0, t_rest = 0;           // S4G_PROFILE=1: where the stage's time goes
+    double t_read = 0, t_cand = 0, t_wait = 0, t_rest = 0;           // S4G_PROFILE=1: where the stage's time goes
     auto lap = [](std::chrono::steady_clock::time_point& t) {
         const auto now = std::chrono::steady_clock::now();
         const double s = std::chrono::duration<double>(now - t).count();
         t = now;
         return s;
     };
-    for (uint32_t part = 1;; ++part) {
-        auto clock = std::chrono::steady_clock::now();
-        const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunkBytes);
-        t_read += lap(clock);
-        databaseLog(part, part_gb, 0);
 
-        ChunkCandidates cand(indices, (uint32_t)chunk_begin, (uint32_t)database_length);
-        std::vector<Chain*> pool(cand.ids.size());
-        for (size_t k = 0; k < pool.size(); ++k) pool[k] = database[cand.ids[k]];
-        t_cand += lap(clock);
-
-        DbAlignment*** found = nullptr;
-        int* found_lengths = nullptr;
-        if (pool.empty()) {          // nothing to align in this part: empty lists, malloc domain like the library's
-            found = (DbAlignment***)calloc(queries_length ? queries_length : 1, sizeof(DbAlignment**));
-            found_lengths = (int*)calloc(queries_length ? queries_length : 1, sizeof(int));
-        } else {
-            ChainDatabase* chunk_db = chainDatabaseCreate(pool.data(), 0, (int)pool.size(), cards, cards_length);
-            std::vector<int*> list_ptrs(queries_length);
-            std::vector<int> list_lens(queries_length);
-            for (int32_t q = 0; q < queries_length; ++q) {
-                list_ptrs[q] = cand.lists[q].empty() ? nullptr : cand.lists[q].data();
-                list_lens[q] = (int)cand.lists[q].size();
-            }
-            databaseLog(part, part_gb, 50);
-            shotgunDatabaseCandidates(&found, &found_lengths, algorithm, queries, queries_length, chunk_db, scorer,
-                                      (int)max_alignments, evalue_callback, evalue_params, max_evalue, list_ptrs.data(),
-                                      list_lens.data(), cards, cards_length, nullptr);
-            chainDatabaseDelete(chunk_db);
-        }
-        t_lib += lap(clock);
-
-        // chains that carry an alignment stay alive (DbAlignment borrows them); the rest of this part goes
-        std::vector<char> in_use(pool.size(), 0);
+    // what remains to do with a part once the library is through with it: merge (in part order, database_alignment.cpp:97-104)
+    // and delete the chains that carry no alignment (:106-113)
+    auto finish = [&](PartJob& job, std::chrono::steady_clock::time_point& clock) {
+        job.running.get();
+        t_wait += lap(clock);
+        std::vector<char> in_use(job.pool.size(), 0);
         for (int32_t q = 0; q < queries_length; ++q)
-            for (int k = 0; k < found_lengths[q]; ++k) in_use[dbAlignmentGetTargetIdx(found[q][k])] = 1;
-        std::vector<char> keep_chain((size_t)(database_length - chunk_begin), 0);
-        for (size_t k = 0; k < pool.size(); ++k)
-            if (in_use[k]) keep_chain[cand.ids[k] - (uint32_t)chunk_begin] = 1;
-
+            for (int k = 0; k < job.found_lengths[q]; ++k) in_use[dbAlignmentGetTargetIdx(job.found[q][k])] = 1;
+        std::vector<char> keep_chain((size_t)(job.end - job.begin), 0);
+        for (size_t k = 0; k < job.pool.size(); ++k)
+            if (in_use[k]) keep_chain[job.cand.ids[k] - (uint32_t)job.begin] = 1;
         if (*alignments == nullptr) {
-            *alignments = found;
-            *alignments_lengths = found_lengths;
+            *alignments = job.found;
+            *alignments_lengths = job.found_lengths;
         } else {
-            dbAlignmentsMerge(*alignments, *alignments_lengths, found, found_lengths, queries_length, (int)max_alignments);
-            deleteShotgunDatabase(found, found_lengths, queries_length);
+            dbAlignmentsMerge(*alignments, *alignments_lengths, job.found, job.found_lengths, queries_length, (int)max_alignments);
+            deleteShotgunDatabase(job.found, job.found_lengths, queries_length);
         }
-        for (int i = chunk_begin; i < database_length; ++i)
-            if (!keep_chain[i - chunk_begin] && database[i] != nullptr) {
+        for (int i = job.begin; i < job.end; ++i)
+            if (!keep_chain[i - job.begin] && database[i] != nullptr) {
                 chainDelete(database[i]);
                 database[i] = nullptr;
             }
-
         t_rest += lap(clock);
+    };
+
+    int chunk_begin = 0;
+    PartJob* in_flight = nullptr;                 // the part the library is working on while the next one is being read
+    for (uint32_t part = 1;; ++part) {
+        auto clock = std::chrono::steady_clock::now();
+        // (readFastaChainsPart may move the ARRAY of chain pointers; the job in flight holds copies of the pointers it needs,
+        // and the chains themselves do not move)
+        const int more = readFastaChainsPart(&database, &database_length, handle, serialized, kChunkBytes);
+        t_read += lap(clock);
+        databaseLog(part, part_gb, 0);
+        if (in_flight) { finish(*in_flight, clock); delete in_flight; in_flight = nullptr; }
+
+        PartJob* job = new PartJob(indices, database, chunk_begin, database_length);
+        t_cand += lap(clock);
+        if (job->pool.empty()) {     // nothing to align in this part: empty lists, malloc domain like the library's
+            job->found = (DbAlignment***)calloc(queries_length ? queries_length : 1, sizeof(DbAlignment**));
+            job->found_lengths = (int*)calloc(queries_length ? queries_length : 1, sizeof(int));
+            job->running = std::async(std::launch::deferred, []() {});
+        } else {
+            databaseLog(part, part_gb, 50);
+            job->running = std::async(std::launch::async, [=]() {
+                ChainDatabase* chunk_db = chainDatabaseCreate(job->pool.data(), 0, (int)job->pool.size(), cards, cards_length);
+                std::vector<int*> list_ptrs(queries_length);
+                std::vector<int> list_lens(queries_length);
+                for (int32_t q = 0; q < queries_length; ++q) {
+                    list_ptrs[q] = job->cand.lists[q].empty() ? nullptr : job->cand.lists[q].data();
+                    list_lens[q] = (int)job->cand.lists[q].size();
+                }
+                shotgunDatabaseCandidates(&job->found, &job->found_lengths, algorithm, queries, queries_length, chunk_db, scorer,
+                                          (int)max_alignments, evalue_callback, evalue_params, max_evalue, list_ptrs.data(),
+                                          list_lens.data(), cards, cards_length, nullptr);
+                chainDatabaseDelete(chunk_db);
+            });
+        }
+        in_flight = job;
         databaseLog(part, part_gb, 100);
         if (!more) break;
         chunk_begin = database_length;
     }
+    {
+        auto clock = std::chrono::steady_clock::now();
+        finish(*in_flight, clock);
+        delete in_flight;
+    }
     fprintf(stderr, "\n\n");
     if (getenv("S4G_PROFILE"))
-        fprintf(stderr, "[s4g profile] aligning stage: reading FASTA into chains %.3f s, candidate union %.3f s, library (database + scores + "
-                        "traceback) %.3f s, merge + deleting unused chains %.3f s\n", t_read, t_cand, t_lib, t_rest);
+        fprintf(stderr, "[s4g profile] aligning stage: reading FASTA into chains %.3f s, candidate union %.3f s, waiting for the library "
+                        "(database + scores + traceback; it works while the next part is read) %.3f s, merge + deleting unused chains %.3f s\n",
+                t_read, t_cand, t_wait, t_rest);
     fclose(handle);
     *database_out = database;
     *database_length_out = database_length;
