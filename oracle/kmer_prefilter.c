@@ -47,8 +47,10 @@ typedef struct { uint32_t id, position; } Hit;   /* hash.hpp:19-30 */
 
 typedef struct {
     uint32_t k, nq, max_candidates;
-    uint64_t n_kmers;       /* 32^k + 1 slots: every 5-bit code is in range (the reference sizes for codes <= 25, hash.cpp:19) */
-    uint64_t* starts;       /* hash.cpp:56-68 */
+    uint64_t n_kmers;       /* 32^k slots: every 5-bit code is in range (the reference sizes for codes <= 25, hash.cpp:19) */
+    uint32_t* ends;         /* hash.cpp:56-68 starts_, kept as ENDS: bucket of k-mer v = hits[v ? ends[v - 1] : 0 .. ends[v]) -- the fill
+                               pass of hash.cpp:75-84 advances a cursor per bucket from its start to its end, so the cursors ARE the ends
+                               and no second 32^k-entry array is needed (a test creates dozens of these indexes) */
     Hit* hits;              /* hash.cpp:70-85 */
     uint32_t max_qlen;
     /* candidates per query, every one ever seen (the cut is applied at the end: the top of a union under a total order is the
@@ -60,25 +62,24 @@ API void* s4g_oracle_prefilter_create(const uint8_t* qcodes, const uint64_t* qof
     if (k < 3 || k > 5) return NULL;                                  /* main.cpp:169 */
     Prefilter* p = (Prefilter*)calloc(1, sizeof *p);
     p->k = k; p->nq = nq; p->max_candidates = max_candidates;
-    p->n_kmers = (1ull << (k * kBits)) + 1;
-    p->starts = (uint64_t*)calloc(p->n_kmers + 1, sizeof(uint64_t));
+    p->n_kmers = 1ull << (k * kBits);
+    p->ends = (uint32_t*)calloc(p->n_kmers + 1, sizeof(uint32_t));
     uint32_t max_len = 0;
     for (uint32_t q = 0; q < nq; ++q) { uint32_t l = (uint32_t)(qoff[q + 1] - qoff[q]); if (l > max_len) max_len = l; }
     p->max_qlen = max_len;
     uint32_t* kv = (uint32_t*)malloc(sizeof(uint32_t) * (max_len + 1));
-    for (uint32_t q = 0; q < nq; ++q) {                               /* hash.cpp:60-68: counts, shifted by one */
+    for (uint32_t q = 0; q < nq; ++q) {                               /* hash.cpp:60-68: counts */
         uint32_t n = kmer_vector(qcodes + qoff[q], (uint32_t)(qoff[q + 1] - qoff[q]), k, kv);
-        for (uint32_t j = 0; j < n; ++j) ++p->starts[kv[j] + 1];
+        for (uint32_t j = 0; j < n; ++j) ++p->ends[kv[j]];
     }
-    for (uint64_t i = 1; i < p->n_kmers; ++i) p->starts[i + 1] += p->starts[i];
-    p->hits = (Hit*)malloc(sizeof(Hit) * (p->starts[p->n_kmers] + 1));
-    uint64_t* cursor = (uint64_t*)malloc(sizeof(uint64_t) * (p->n_kmers + 1));
-    memcpy(cursor, p->starts, sizeof(uint64_t) * (p->n_kmers + 1));
+    uint32_t total = 0;                                               /* counts -> starts (exclusive prefix sum) */
+    for (uint64_t v = 0; v < p->n_kmers; ++v) { const uint32_t c = p->ends[v]; p->ends[v] = total; total += c; }
+    p->hits = (Hit*)malloc(sizeof(Hit) * ((size_t)total + 1));
     for (uint32_t q = 0; q < nq; ++q) {                               /* hash.cpp:75-84: queries in order, positions in order */
         uint32_t n = kmer_vector(qcodes + qoff[q], (uint32_t)(qoff[q + 1] - qoff[q]), k, kv);
-        for (uint32_t j = 0; j < n; ++j) { Hit h = {q, j}; p->hits[cursor[kv[j]]++] = h; }
+        for (uint32_t j = 0; j < n; ++j) { Hit h = {q, j}; p->hits[p->ends[kv[j]]++] = h; }       /* starts become ends */
     }
-    free(cursor); free(kv);
+    free(kv);
     p->score = (float**)calloc(nq ? nq : 1, sizeof(float*)); p->id = (uint32_t**)calloc(nq ? nq : 1, sizeof(uint32_t*));
     p->n = (uint64_t*)calloc(nq ? nq : 1, sizeof(uint64_t)); p->cap = (uint64_t*)calloc(nq ? nq : 1, sizeof(uint64_t));
     return p;
@@ -110,7 +111,7 @@ static void target_hits(Prefilter* p, const uint8_t* codes, uint32_t len, uint32
     uint32_t n = kmer_vector(codes, len, p->k, kv), n_touched = 0;
     for (uint32_t j = 0; j < n; ++j) {
         if (j != 0 && kv[j] == kv[j - 1]) continue;                                   /* :212-214 */
-        for (uint64_t h = p->starts[kv[j]]; h < p->starts[kv[j] + 1]; ++h) {          /* :216-220 */
+        for (uint32_t h = kv[j] ? p->ends[kv[j] - 1] : 0; h < p->ends[kv[j]]; ++h) {   /* :216-220 */
             HitList* L = &lists[p->hits[h].id];
             if (L->n == 0) touched[n_touched++] = p->hits[h].id;
             if (L->n == L->cap) { L->cap = L->cap ? 2 * L->cap : 16; L->v = (int32_t*)realloc(L->v, sizeof(int32_t) * L->cap); }
@@ -192,7 +193,7 @@ API void s4g_oracle_prefilter_destroy(void* handle) {
     Prefilter* p = (Prefilter*)handle;
     if (!p) return;
     for (uint32_t q = 0; q < p->nq; ++q) { free(p->score[q]); free(p->id[q]); }
-    free(p->score); free(p->id); free(p->n); free(p->cap); free(p->starts); free(p->hits); free(p);
+    free(p->score); free(p->id); free(p->n); free(p->cap); free(p->ends); free(p->hits); free(p);
 }
 
 /* Dense form for the kernel-level tests: lis[q * nt + t] = LIS of the hit list of (query q, target t), 0 where there is none. */
