@@ -143,10 +143,14 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     // dst (database_search.cpp:166-178): ascending ids per query
     std::vector<uint32_t> ids((size_t)std::max(1, queries_length) * max_candidates), counts((size_t)std::max(1, queries_length));
     if (s4g_prefilter_finish(filter, ids.data(), counts.data(), nullptr) != S4G_OK) die("prefilter");
-    s4g_prefilter_destroy(filter);
+    const double t_lists = seconds_since(t0);
+    // the handle's buffers (a few GB of device memory, a few hundred MB of pinned staging) are given back underneath what follows;
+    // the static future's destructor waits for that at exit at the latest
+    static std::future<void> cleanup;
+    cleanup = std::async(std::launch::async, [filter]() { s4g_prefilter_destroy(filter); });
     if (getenv("S4G_PROFILE"))
         fprintf(stderr, "[s4g profile] prefilter stage: reading FASTA into flat codes %.3f s, waiting for the device %.3f s, lists to the host %.3f s\n",
-                t_read, t_wait, seconds_since(t0));
+                t_read, t_wait, t_lists);
     dst.clear();
     dst.resize(queries_length);
     for (int32_t i = 0; i < queries_length; ++i)
