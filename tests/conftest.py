@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs (a kernel that never ends, a deadlocked rendezvous) must fail on its own instead of holding the GPU box
+    until the driver's limit: with pytest-timeout installed every test gets 15 minutes unless it asked for something else (the
+    longest, the full-size configs, take about one)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle
