@@ -139,6 +139,19 @@ def test_long_segments_lds_and_global_tails():
     assert 3 in d_ids[0, :d_counts[0]].tolist() and d_scores[0, d_ids[0, :d_counts[0]].tolist().index(3)] == np.float32(5996) / np.float32(6000)
 
 
+def test_global_tails_on_dense_random_hits():
+    """two queries of 6000 residues over a four-letter alphabet, k = 3: every k-mer of a target hits ~90 query positions, so a
+    (query, target) pair has hundreds of thousands of hits in no particular order and its LIS runs past the 4096 tails a wave
+    keeps in LDS -- the 64-way search of pf_lis_long over tails in global memory, against the restatement's bisection"""
+    rng = np.random.default_rng(77)
+    queries = [rng.integers(0, 4, size=6000).astype(np.uint8), rng.integers(0, 4, size=5000).astype(np.uint8)]
+    targets = [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in (6000, 3000, 4500, 5999, 64, 5000)]
+    targets[3] = np.concatenate([queries[0][2000:], queries[0][:1999]])          # a rotated copy: two long increasing blocks
+    dev, ref, stats = _both(queries, [targets], 3, 10)
+    _assert_equal(dev, ref)
+    assert stats["hits"] > 3_000_000 and stats["long_pairs"] == 12
+
+
 def test_edge_cases():
     import oracle
     enc = oracle.encode
