@@ -354,3 +354,40 @@ def test_reference_cli_other_matrices_gpu_equals_oracle_pipeline(tmp_path, args)
         assert outs["gpu"][n] == outs["oracle"][n], n
     assert outs["gpu"]["alignments.txt"].count(b"\n") >= 8
     assert outs["gpu"]["alignments.txt"] != open(os.path.join(GOLDEN, "dropin_predictions", "alignments.txt"), "rb").read()
+
+
+@pytest.mark.skipif(not (os.path.exists(DEVSEARCH) and os.path.exists(DROPIN)), reason="drop-in builds missing (need /root/reference at build time)")
+def test_device_prefilter_differs_from_the_reference_prefilter_only_in_ties_at_the_cut(tmp_path):
+    """300 queries x 200 000 targets through the reference's own prefilter (32 threads) and through the device's: 5000 candidates
+    of 200 000 make the cut bind for every query, and planted homologs of low identity sit ON the cut (one shared 5-mer: score
+    1 / length, like thousands of unrelated sequences of that length).  Which of such ties survive is the one thing the two
+    prefilters may decide differently (the reference's own answer changes with --threads); so every alignment only one of the
+    two builds reports must be a pair whose prefilter score EQUALS its query's cut, and everything else must be identical."""
+    import oracle
+    from sift4g_amd import synth
+    from sift4g_amd.seqio import write_fasta
+    nq, nt = 300, 200000
+    c = synth.make_config(2, nq, nt)
+    write_fasta(str(tmp_path / "q.fa"), [f"q{i}" for i in range(nq)], c["q_codes"], c["q_off"])
+    write_fasta(str(tmp_path / "db.fa"), [f"t{i}" for i in range(nt)], c["t_codes"], c["t_off"])
+    lines = {}
+    for name, exe in (("reference", DROPIN), ("device", DEVSEARCH)):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run([exe, "-q", str(tmp_path / "q.fa"), "-d", str(tmp_path / "db.fa"), "--cards", "0", "--out", str(out), "--sub-results", "-t", "32"],
+                           capture_output=True, text=True, timeout=600, cwd=str(out))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[name] = set(ln for ln in (out / "alignments.txt").read_bytes().split(b"\n") if ln and not ln.startswith(b"#"))
+    assert len(lines["reference"]) > 13000
+    only = (lines["reference"] - lines["device"]) | (lines["device"] - lines["reference"])
+    assert len(only) <= 20                                      # a handful of ties, not a different result
+    qo, to = c["q_off"], c["t_off"]
+    targets = [c["t_codes"][int(to[i]):int(to[i + 1])] for i in range(nt)]
+    for ln in only:
+        f = ln.split(b"\t")
+        q, t = int(f[0][1:]), int(f[1][1:])
+        pf = oracle.Prefilter([c["q_codes"][int(qo[q]):int(qo[q + 1])]], 5, 5000)
+        pf.add(targets)
+        _, _, _, cut = pf.finish()
+        lis = int(pf.lis([targets[t]])[0, 0])
+        assert cut[0] > 0 and np.float32(lis) / np.float32(len(targets[t])) == cut[0], (q, t, lis, len(targets[t]), float(cut[0]))
