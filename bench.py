@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E column model, 2 int32 loads + 2 stores per cell
 TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
-LANES_PER_CLK_PER_SIMD = 16    # a wave64 vector instruction occupies its SIMD for 4 clocks (profiles/r01_valu_rates.txt)
+LANES_PER_CLK_PER_SIMD = 16    # a wave64 vector instruction occupies its SIMD for 4 clocks (profiles/r03_valu_issue.txt)
+GUIDE_CLOCK_MHZ = 2400.0       # MI355X_MICROARCH.md: peak engine clock; the roofline's `peak` is priced at it
 # algorithmic vector ops per DP cell of each scan kernel (counted from the recurrence, not from the ISA)
 VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75, "sw_scan_pk<ArithF16,32>": 3.75,
                      "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5, "sw_scan_i32d<32>": 6.5}
@@ -189,6 +190,7 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the k-mer prefilter leg after the timed region")
     ap.add_argument("--no-tiers", action="store_true", help="skip the two extra int32-only steps after the timed region")
+    ap.add_argument("--no-scale-ref", action="store_true", help="skip the configs[2]-on-one-GPU leg (the N > 1 lines' denominator) after the timed region")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -213,6 +215,13 @@ def main():
             log(f"{world} ranks but {n_dev} GPU(s) visible (set S4G_BENCH_SHARE_GPU=1 to emulate the N-rank job on fewer devices)")
         sys.exit(2)
     dev_index = local_rank % n_dev
+    # one process per GPU: keep this rank's host threads (the library's worker pool, staging copies, the process group's helpers)
+    # on the NUMA node its GPU hangs off -- before the first HIP call, so the runtime's own threads inherit the mask.  Only for
+    # N > 1: the N = 1 line times the CPU baseline on ALL host cores.
+    affinity = None
+    if world > 1 and os.environ.get("S4G_BENCH_NO_PIN") != "1":
+        from sift4g_amd import numa
+        affinity = numa.pin_to_gpu(dev_index)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import sift4g_amd as s4g
@@ -317,17 +326,26 @@ def main():
     elif args.no_drift and "pkd" in plan["kernel"]:
         plan["kernel"] = "sw_scan_pk<ArithI16M3,32>"
     scores = None if db_shard else torch.empty((max(q_count, 1), db.n), dtype=torch.int32, device=dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # per step: scan start, scan end, top-k end, gather (+ merge) end -- on the stream every launch of the step goes to
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
+    gather_host_s = []              # gloo (emulated runs): the gather is host-synchronous, events do not see it
     gather_group = None
 
     def step(i=None, fl=flags):
         if i is not None:
             ev[i][0].record()
+        def gathered(fn):
+            t_g = time.perf_counter()
+            g = fn()
+            if i is not None:
+                ev[i][3].record()
+                gather_host_s.append(time.perf_counter() - t_g)
+            return g
         if db_shard:
             ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, **fl)             # streaming scan + tile top-k + merge
             if i is not None:
-                ev[i][1].record()
-            return (ids, sc, cnt), shard.gather_db_shards(ids, sc, cnt, rank * n_per, TOPK, gather_group)   # all-gather + K-way merge
+                ev[i][1].record(); ev[i][2].record()                                  # (the top-k is inside the streaming scan)
+            return (ids, sc, cnt), gathered(lambda: shard.gather_db_shards(ids, sc, cnt, rank * n_per, TOPK, gather_group))   # all-gather + K-way merge
         if q_count:
             s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, **fl)
         if i is not None:
@@ -338,7 +356,9 @@ def main():
             ids = torch.full((0, TOPK), -1, dtype=torch.int32, device=dev)
             sc = torch.zeros((0, TOPK), dtype=torch.int32, device=dev)
             cnt = torch.zeros((0,), dtype=torch.int32, device=dev)
-        return (ids, sc, cnt), shard.gather_query_shards(ids, sc, cnt, allq.n, gather_group)        # all-gather of the hit lists (N > 1)
+        if i is not None:
+            ev[i][2].record()
+        return (ids, sc, cnt), gathered(lambda: shard.gather_query_shards(ids, sc, cnt, allq.n, gather_group))        # all-gather of the hit lists (N > 1)
 
     def fence():
         if use_dist:
@@ -354,16 +374,27 @@ def main():
         last = step(i)
     fence()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else 0.0
+    topk_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if args.steps else 0.0
+    gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) if args.steps else 0.0
+    if backend == "gloo" and gather_host_s:
+        gather_ms = float(np.mean(gather_host_s)) * 1e3
     stats = s4gd.scan_stats(dev_index)
+    clk = s4gd.scan_clock(dev_index)                # sampled inside the scan kernel of the last timed step
 
     red_dev = dev if backend != "gloo" else torch.device("cpu")
-    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=red_dev)
+    t = torch.tensor([dt, kern_ms, topk_ms, gather_ms], dtype=torch.float64, device=red_dev)
+    tmin = t.clone()
     c = torch.tensor([float(cells_rank)], dtype=torch.float64, device=red_dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    dt, kern_ms_max = float(t[0]), float(t[1])
+    dt = float(t[0])
+    phases = {"scan_ms": {"max": round(float(t[1]), 3), "min": round(float(tmin[1]), 3)},
+              "topk_ms": {"max": round(float(t[2]), 3), "min": round(float(tmin[2]), 3)},
+              "gather_ms": {"max": round(float(t[3]), 3), "min": round(float(tmin[3]), 3)},
+              "note": "per rank, mean over the timed steps (HIP events on the step's stream; gloo gathers by host clock); max / min over ranks"}
     cells_total = float(c[0])
 
     line = None
@@ -371,11 +402,24 @@ def main():
         gcups = cells_total * args.steps / dt / 1e9
         kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         ops = VALU_OPS_PER_CELL.get(plan["kernel"], 0.0)
-        # ---- the roof that binds: vector-ALU issue, priced at the clock the chip runs at under load ----
-        probe = s4gd.clock_probe(dev_index)
-        clock_mhz = probe["shader_mhz"] or probe["nominal_mhz"]
-        valu_peak = probe["cus"] * 4 * LANES_PER_CLK_PER_SIMD * clock_mhz * 1e6 / 1e12          # T lane-ops/s
+        # ---- the roof that binds: vector-ALU issue.  `peak` = CUs x 4 SIMDs x 16 lanes per clock x the guide's 2.4 GHz;
+        #      the clock the timed kernel really ran at is sampled INSIDE it (s4g_scan_clock) and prices `peak_at_measured_clock` ----
+        import ctypes as _ct
+        cus = torch.cuda.get_device_properties(dev_index).multi_processor_count
+        clock_mhz = clk["shader_mhz"] if clk["launches"] and clk["shader_mhz"] > 500.0 else 0.0
+        valu_peak = cus * 4 * LANES_PER_CLK_PER_SIMD * GUIDE_CLOCK_MHZ * 1e6 / 1e12             # T lane-ops/s at 2.4 GHz
+        valu_peak_meas = cus * 4 * LANES_PER_CLK_PER_SIMD * clock_mhz * 1e6 / 1e12 if clock_mhz else None
         valu_achieved = kern_gcups * ops / 1e3
+        # executed (not algorithmic) lane-ops per cell: SQ_INSTS_VALU x 64 / cells of a committed rocprofv3 --pmc pass of this
+        # command (profiles/valu_executed.json, tagged with the commit it was collected on)
+        exec_ops, exec_src = None, None
+        try:
+            ve = json.load(open(os.path.join(ROOT, "profiles", "valu_executed.json"))).get(plan["kernel"])
+            if ve and ve.get("workload_cells") == cells_rank:
+                exec_ops, exec_src = ve["lane_ops_per_cell"], ve.get("source")
+        except Exception:
+            exec_ops = None
+        valu_executed = kern_gcups * exec_ops / 1e3 if exec_ops else None
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes of this command
         if os.path.exists(prof):
@@ -407,12 +451,23 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(valu_achieved, 3), "peak": round(valu_peak, 3), "unit": "T lane-ops/s",
                 "frac": round(valu_achieved / valu_peak, 4) if valu_peak else None, "traffic": traffic,
+                "traffic_measured_in_run": False,
                 "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
                 "ops_per_cell": ops,
-                "peak_basis": (f"{probe['cus']} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {clock_mhz:.0f} MHz "
-                               + ("(shader clock measured under a vector-ALU load by s4g_clock_probe in this run)" if probe["shader_mhz"]
-                                  else "(nominal clock: the part's cycle counter does not follow the shader clock)")),
-                "measured_pk_add_rate": round(probe["pk_add_T_lane_ops"], 2),
+                "peak_basis": f"{cus} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {GUIDE_CLOCK_MHZ:.0f} MHz (guide peak engine clock)",
+                # achieved = algorithmic lane-ops per cell x cells / the kernel's HIP-event time; frac_algorithmic = frac
+                "frac_algorithmic": round(valu_achieved / valu_peak, 4) if valu_peak else None,
+                "executed_ops_per_cell": exec_ops, "executed": round(valu_executed, 3) if valu_executed else None,
+                "frac_executed": round(valu_executed / valu_peak, 4) if valu_executed else None,
+                "executed_source": exec_src,
+                # the clock the timed kernel ran at, from s_memtime / s_memrealtime samples taken by its own blocks
+                "clock_in_kernel": {"shader_mhz": round(clock_mhz, 1), "min_block": round(clk["shader_mhz_min"], 1),
+                                    "max_block": round(clk["shader_mhz_max"], 1), "blocks": clk["blocks"],
+                                    "kernel_ms_by_100MHz_counter": round(clk["kernel_ms"], 3), "tier": clk["tier"],
+                                    "launches_sampled": clk["launches"]},
+                "peak_at_measured_clock": round(valu_peak_meas, 3) if valu_peak_meas else None,
+                "frac_algorithmic_at_measured_clock": round(valu_achieved / valu_peak_meas, 4) if valu_peak_meas else None,
+                "frac_executed_at_measured_clock": round(valu_executed / valu_peak_meas, 4) if valu_executed and valu_peak_meas else None,
                 "traffic_source": traffic_src,
                 "note": "a register-tiled kernel moves ~8/R bytes per cell, so it sits far above the HBM contract roofline by construction; "
                         "vector-ALU issue is the limit that binds (achieved = algorithmic ops per cell x measured cells/s)",
@@ -421,6 +476,9 @@ def main():
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": BYTES_PER_CELL,
                         "traffic": traffic,
                         "traffic_frac_of_peak": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kern_ms else None)}},
+            "phases": phases,
+            "gather_payload_bytes": (allq.n * 2 * TOPK * 4 * world if db_shard else (max(shard.shard_bounds(allq.n, world)[r + 1] - shard.shard_bounds(allq.n, world)[r] for r in range(world)) * (2 * TOPK + 1) * 4 * world)) if use_dist else 0,
+            "host_affinity": affinity,
             "speculative": {"queries": stats["speculative"], "rechecked": stats["rechecked"]},
             "routing": {k: stats[k] for k in ("tier_drift", "tier_m3", "tier_i16", "tier_i32", "pair_items")},
         }
@@ -484,9 +542,45 @@ def main():
                 ms32.append(e0.elapsed_time(e1))
             k32 = float(np.mean(ms32))
             g32 = cells_rank / (k32 * 1e-3) / 1e9
+            clk32 = s4gd.scan_clock(dev_index)
+            mhz32 = clk32["shader_mhz"] if clk32["launches"] else 0.0
+            peak32 = cus * 4 * LANES_PER_CLK_PER_SIMD * mhz32 * 1e6 / 1e12 if mhz32 else None
             out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32d<32>", "steps": 2,
-                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None},
+                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None,
+                                      "shader_mhz_in_kernel": round(mhz32, 1),
+                                      "valu_frac_at_measured_clock": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / peak32, 4) if peak32 else None},
                             tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
+        if world == 1 and not db_shard and args.workload == "auto" and not args.no_scale_ref and args.queries is None and args.targets is None:
+            # ---- like-for-like denominator of the N > 1 lines: the workload they run (configs[2], strong-scaled) on this one GPU,
+            #      two steps (scan + top-k, as a timed step) outside the timed region ----
+            try:
+                wl2 = WORKLOADS["configs2"]
+                t_g = time.perf_counter()
+                cfg2 = synth.make_config(wl2["cfg"], n_queries=wl2["queries"], n_targets=wl2["targets"], q_len=wl2["qlen"])
+                t_g = time.perf_counter() - t_g
+                del scores
+                torch.cuda.empty_cache()
+                db2 = s4g.Database(codes=cfg2["t_codes"], offsets=cfg2["t_off"], device=dev_index)
+                q2 = s4g.QuerySet(codes=cfg2["q_codes"], offsets=cfg2["q_off"], device=dev_index)
+                sc2 = torch.empty((q2.n, db2.n), dtype=torch.int32, device=dev)
+                cells2 = s4gd.scan_cells(db2, q2, 0, q2.n)
+                ms2 = []
+                for it in range(3):                         # one warm-up (workspace allocation), two measured
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    s4g.scan(db2, q2, scorer, sc2)
+                    s4g.topk_device(db2, sc2, TOPK, 1)
+                    torch.cuda.synchronize()
+                    if it:
+                        ms2.append((time.perf_counter() - t_s) * 1e3)
+                out["scale_ref"] = {"workload": f"{wl2['label']}: {q2.n} queries x {db2.n} targets on ONE GPU (what --gpus N > 1 strong-scales)",
+                                    "gcups": round(cells2 / (float(np.mean(ms2)) * 1e-3) / 1e9, 2), "ms_per_step": round(float(np.mean(ms2)), 3),
+                                    "steps": 2, "cells_per_step": float(cells2), "generate_s": round(t_g, 1),
+                                    "shader_mhz_in_kernel": round(s4gd.scan_clock(dev_index)["shader_mhz"], 1)}
+                del sc2, db2, q2, cfg2
+            except Exception as exc:               # an extra leg must never cost the line the headline number
+                out["scale_ref"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"scale_ref leg failed: {exc}")
         if world == 1 and not db_shard and not args.no_prefilter and cfg is not None:
             try:                                   # an extra leg must never cost the line the headline number
                 out["prefilter"] = prefilter_leg(cfg, dev_index)
@@ -512,6 +606,11 @@ def main():
         print(line, flush=True)
         if json.loads(line).get("selfcheck", {}).get("mismatches") or json.loads(line).get("prefilter", {}).get("check", {}).get("mismatches"):
             sys.exit(3)
+        # a roofline the kernel's own executed instruction rate exceeds is not a roofline: refuse to pass such a line off
+        rf = json.loads(line)["roofline"]
+        if rf.get("executed") and rf.get("peak_at_measured_clock") and rf["executed"] > 1.01 * rf["peak_at_measured_clock"]:
+            log(f"ROOFLINE INCONSISTENT: executed {rf['executed']} T lane-ops/s above the issue peak {rf['peak_at_measured_clock']} at the clock measured in the kernel")
+            sys.exit(4)
 
 
 if __name__ == "__main__":

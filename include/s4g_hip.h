@@ -38,7 +38,7 @@
  *       step 4 of swsharp alignDatabase: traceback of the survivors
  *   s4g_warmup
  *       the device initialisation swsharp does behind cudaCheckCards / its first alignDatabase call, main.cpp:186
- *   s4g_scan_stats / s4g_clock_probe / s4g_scan_plan / s4g_scan_cells
+ *   s4g_scan_stats / s4g_scan_clock / s4g_clock_probe / s4g_scan_plan / s4g_scan_cells
  *       measurement only (bench.py); no counterpart in the reference, which prints no throughput figures
  *   s4g_topk / s4g_topk_host / s4g_scan_topk / s4g_scan_topk_host
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
@@ -238,6 +238,16 @@ int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
  * speculative launches marked and the exact int32 pass recomputed, out[6] = (query, target) pairs given to the
  * one-wave-per-pair kernels, out[7] = pairs scored by the packed list kernel (s4g_score_pairs_host / s4g_score_lists_host).  cap >= 8. */
 int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
+
+/* Shader clock and duration of the scan launches of the last s4g_scan* / s4g_scan_topk* call on `device`, sampled INSIDE those
+ * kernels (measurement; synchronises the device): thread 0 of every persistent block reads the shader-clock counter
+ * (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts, every wave again when the work queue is
+ * drained.  out[0] = launches sampled in the call (at most 16); for the LONGEST of them: out[1] = shader clock in MHz, mean over
+ * blocks of d(s_memtime) / d(s_memrealtime) x 100, out[2] / out[3] = smallest / largest block value, out[4] = blocks that
+ * contributed, out[5] = duration in ms by the 100 MHz counter (longest block), out[6] = tier of that launch (0 drifting frame,
+ * 1 maximum3, 2 plain int16, 3 int32), out[7] = shader clocks of the longest block.  All zero if the call launched no scan
+ * kernel.  cap >= 8.  This is the clock bench.py prices the vector-issue roofline with. */
+int s4g_scan_clock(int device, double* out, uint32_t cap);
 
 /* Starts, once per device and on a thread of its own, everything a process pays before its first scan: HIP context, code
  * objects, side stream, pinned staging.  Returns at once; calls that need the device meanwhile wait for it.  The

@@ -76,6 +76,7 @@ SIGNATURES = {
                                           c_i32p, c_i32p, c_u64p, c_u8p, ctypes.c_uint32]),
     "s4g_warmup": (ctypes.c_int, [ctypes.c_int]),
     "s4g_scan_stats": (ctypes.c_int, [ctypes.c_int, c_u64p, ctypes.c_uint32]),
+    "s4g_scan_clock": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),
     "s4g_clock_probe": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),
     "s4g_scan_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_u64p]),

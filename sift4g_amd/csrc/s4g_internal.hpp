@@ -142,7 +142,14 @@ struct DeviceCtx {
     uint32_t grid_lists = 0;
     uint64_t stat_tier[4] = {0, 0, 0, 0};
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
+    // clock samples of the scan launches of the last call (s4g_scan_clock; sw_kernels.hip.h clk_enter / clk_leave): a region of
+    // 4 counters per block for each of the call's first kClkLaunches launches
+    unsigned long long* d_clk = nullptr;
+    uint64_t clk_cap = 0;                // counters allocated
+    struct ClkLaunch { uint64_t off; uint32_t blocks; int tier; };
+    std::vector<ClkLaunch> clk_launches;
 };
+constexpr unsigned kClkLaunches = 16;
 constexpr int kStatRechecked = 40;      // index into DeviceCtx::d_counter
 constexpr int kListCounter = 44;        // work queue of sw_scan_lists
 

@@ -253,6 +253,15 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     if ((uint64_t)n_groups * most >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
     HIP_TRY(hipMemsetAsync(counters, 0, 16, stream));
+    // clock samples (s4g_scan_clock): a zeroed region of 4 counters per block for each of the call's first launches
+    auto clk_region = [&](uint32_t blocks, int tier) -> unsigned long long* {
+        if (cx->clk_launches.size() >= kClkLaunches) return nullptr;
+        const uint64_t off = cx->clk_launches.empty() ? 0 : cx->clk_launches.back().off + 4ull * cx->clk_launches.back().blocks;
+        if (off + 4ull * blocks > cx->clk_cap) return nullptr;
+        if (hipMemsetAsync(cx->d_clk + off, 0, 32ull * blocks, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        cx->clk_launches.push_back({off, blocks, tier});
+        return cx->d_clk + off;
+    };
     ScanArgs16 a;
     a.db_res = t.d_res; a.grp_off = t.d_grp_off + g0; a.grp_len4 = t.d_grp_len4 + g0; a.grp_perm = perm + (size_t)g0 * 64;
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len;
@@ -266,12 +275,15 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
         a.floor_bits = p.bias | (p.bias << 16);
         a.spec_base = p.speculative ? p.spec_base : 0;
-        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift)), dim3(kBlock), 0, stream, a);
+        const uint32_t gd = grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift);
+        a.clk = clk_region(gd, 0);
+        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
         a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2; a.prio_cost = w.prio_cost[1];
         const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)n_groups * w.n_m3);
+        a.clk = clk_region(g3, 1);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
             hipLaunchKernelGGL((sw_scan_pk<ArithF16, kStripRows16>), dim3(g3), dim3(kBlock), 0, stream, a);
@@ -286,7 +298,9 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     if (w.n_pk) {
         a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
         a.floor_bits = 0;
-        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(grid_of(p.grid_i16, (uint64_t)n_groups * w.n_pk)), dim3(kBlock), 0, stream, a);
+        const uint32_t g2 = grid_of(p.grid_i16, (uint64_t)n_groups * w.n_pk);
+        a.clk = clk_region(g2, 2);
+        hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(g2), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_wide) {
@@ -300,9 +314,11 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         b.n_groups = n_groups; b.q_begin = q_begin; b.q_count = w.n_wide;
         b.q_list = cx->d_qlist + w.off_wide;
         b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
+        const uint32_t gw = grid_of(p.grid_i32, (uint64_t)n_groups * w.n_wide);
+        b.clk = clk_region(gw, 3);
         // the drifting-frame form (6.5 ops per cell instead of 7.5) wherever its shifted scores fit the int8 strip profile
-        if (p.wide_drift) hipLaunchKernelGGL(sw_scan_i32d<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
-        else hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(grid_of(p.grid_i32, (uint64_t)n_groups * w.n_wide)), dim3(kBlock), 0, stream, b);
+        if (p.wide_drift) hipLaunchKernelGGL(sw_scan_i32d<kStripRows>, dim3(gw), dim3(kBlock), 0, stream, b);
+        else hipLaunchKernelGGL(sw_scan_i32<kStripRows>, dim3(gw), dim3(kBlock), 0, stream, b);
         HIP_TRY(hipGetLastError());
     }
     return S4G_OK;
@@ -338,6 +354,14 @@ static int stats_begin(DeviceCtx* cx, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(cx->d_counter + kStatRechecked, 0, 4, stream));
     for (auto& v : cx->stat_tier) v = 0;
     cx->stat_spec_queries = cx->stat_pair_items = cx->stat_list_pairs = 0;
+    cx->clk_launches.clear();
+    if (!cx->d_clk) {
+        int rc = device_props(cx);
+        if (rc) return rc;
+        const uint64_t cap = 4ull * kClkLaunches * (uint64_t)cx->prop.multiProcessorCount * 8;      // grids are <= 8 blocks per CU
+        HIP_TRY(hipMalloc((void**)&cx->d_clk, cap * 8));
+        cx->clk_cap = cap;
+    }
     return S4G_OK;
 }
 static void stats_add(DeviceCtx* cx, const Plan& p) {
@@ -358,6 +382,40 @@ S4G_API int s4g_scan_stats(int device, uint64_t* out, uint32_t cap) {
     }
     for (int k = 0; k < 4; ++k) out[k] = cx->stat_tier[k];
     out[4] = cx->stat_spec_queries; out[5] = rechecked; out[6] = cx->stat_pair_items; out[7] = cx->stat_list_pairs;
+    return S4G_OK;
+}
+
+// s4g_scan_clock: the shader clock and the duration of the scan launches of the last call, from the samples the kernels took
+// themselves (clk_enter / clk_leave): per block d(s_memtime) / d(s_memrealtime) x 100 MHz.
+S4G_API int s4g_scan_clock(int device, double* out, uint32_t cap) {
+    if (!out || cap < 8) return fail(S4G_ERR_INVALID, "need room for 8 values");
+    if (device < 0 || device >= 64) return fail(S4G_ERR_INVALID, "bad device %d", device);
+    DeviceGuard guard(device);
+    DeviceCtx* cx = device_ctx(device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    for (uint32_t i = 0; i < 8; ++i) out[i] = 0.0;
+    if (!cx->d_clk || cx->clk_launches.empty()) return S4G_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    out[0] = (double)cx->clk_launches.size();
+    std::vector<unsigned long long> h;
+    double best_ms = -1.0;
+    for (const auto& L : cx->clk_launches) {
+        h.resize(4ull * L.blocks);
+        HIP_TRY(hipMemcpy(h.data(), cx->d_clk + L.off, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0, lo = 1e30, hi = 0, ms = 0, shader_ticks = 0;
+        uint32_t used = 0;
+        for (uint32_t b = 0; b < L.blocks; ++b) {
+            const unsigned long long t0 = h[4 * b], r0 = h[4 * b + 1], t1 = h[4 * b + 2], r1 = h[4 * b + 3];
+            if (r1 <= r0 || t1 <= t0 || r1 - r0 < 1000) continue;          // a block that found the queue empty: < 10 us
+            const double mhz = (double)(t1 - t0) / (double)(r1 - r0) * 100.0;       // s_memrealtime counts at 100 MHz
+            sum += mhz; lo = std::min(lo, mhz); hi = std::max(hi, mhz); ++used;
+            ms = std::max(ms, (double)(r1 - r0) * 1e-5);
+            shader_ticks = std::max(shader_ticks, (double)(t1 - t0));
+        }
+        if (!used || ms <= best_ms) continue;
+        best_ms = ms;                                                   // report the longest launch of the call
+        out[1] = sum / used; out[2] = lo; out[3] = hi; out[4] = used; out[5] = ms; out[6] = L.tier; out[7] = shader_ticks;
+    }
     return S4G_OK;
 }
 

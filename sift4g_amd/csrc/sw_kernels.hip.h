@@ -56,7 +56,26 @@ struct ScanArgs {
     uint32_t q_begin, q_count;               // output row = query id - q_begin
     const uint32_t* __restrict__ q_list;     // optional: the q_count query ids to score (NULL = q_begin .. q_begin+q_count)
     uint32_t open, ext;
+    unsigned long long* clk;                 // optional clock samples, 4 per block (clk_enter / clk_leave)
 };
+
+// Clock samples of a launch (s4g_scan_clock): thread 0 of every block stores the shader-clock counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime) as the block starts working; lane 0 of every wave raises the block's two exit
+// samples as it leaves the work queue.  The persistent blocks all live from the launch to the drain of the queue, so
+// (exit - entry) of the two counters is the clock the kernel ran at, measured inside the timed kernel itself, and the
+// 100 MHz delta is its duration.  Two scalar reads per block and per wave: nothing next to one work item.
+__device__ __forceinline__ void clk_enter(unsigned long long* clk) {
+    if (clk && threadIdx.x == 0) {
+        clk[4 * blockIdx.x + 0] = __builtin_readcyclecounter();
+        clk[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+__device__ __forceinline__ void clk_leave(unsigned long long* clk, int lane) {
+    if (clk && lane == 0) {
+        atomicMax(&clk[4 * blockIdx.x + 2], (unsigned long long)__builtin_readcyclecounter());
+        atomicMax(&clk[4 * blockIdx.x + 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+}
 
 __device__ __forceinline__ unsigned usub_sat(unsigned a, unsigned b) {
     return __builtin_elementwise_sub_sat(a, b);
@@ -112,11 +131,14 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     __syncthreads();
+    clk_enter(a.clk);
 
     const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
     v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
     const unsigned n_items = a.n_groups * a.q_count;
-    const unsigned open = a.open, ext = a.ext;
+    // the penalties live in VGPRs: v_sub_u32 ... clamp with two VGPR sources issues at twice the rate of the SGPR-operand form
+    unsigned open = a.open, ext = a.ext;
+    asm volatile("" : "+v"(open), "+v"(ext));
 
     for (;;) {
         unsigned item = 0;
@@ -198,6 +220,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) a.scores[(uint64_t)(q - a.q_begin) * a.score_stride + p] = best;
     }
+    clk_leave(a.clk, lane);
 }
 
 
@@ -244,12 +267,14 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     __syncthreads();
+    clk_enter(a.clk);
 
     const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
     v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
     const unsigned n_items = a.n_groups * a.q_count;
     const int e = (int)a.ext;
-    const int eo = (int)a.ext - (int)a.open;
+    int eo = (int)a.ext - (int)a.open;
+    asm volatile("" : "+v"(eo));           // in a VGPR: v_add_u32 with two VGPR sources issues a little faster than the SGPR-operand form (tools/valu_issue.hip)
     const int two_e = 2 * e;
 
     for (;;) {
@@ -332,6 +357,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) a.scores[(uint64_t)(q - a.q_begin) * a.score_stride + p] = best;
     }
+    clk_leave(a.clk, lane);
 }
 
 
@@ -374,6 +400,7 @@ struct ScanArgs16 {
     uint32_t floor_bits;                     // packed floor of the arithmetic policy (see Arith*)
     uint32_t prio_cost;                      // items with rows * len4 >= prio_cost run at raised wave priority (0 = never)
     uint32_t spec_base;                      // sw_scan_pkd, speculative launch: 0x7BFF - B - (max score + 2 ext); 0 = exact launch
+    unsigned long long* clk;                 // optional clock samples, 4 per block (clk_enter / clk_leave)
 };
 
 // Written by a speculative sw_scan_pkd launch instead of a score that may not be exact; sw_pair_recheck replaces it.
@@ -419,17 +446,27 @@ __device__ __forceinline__ int pk_maximum3(int a, int b, int c) {
 // denormals preserved: .amdhsa_float_denorm_mode_16_64 3, hipcc's default), so on such operands the instruction IS an
 // integer max3.  Every value is kept >= 0 by storing H, E, F with a bias `fl` = B >= max(open, ext, -min score):
 // diag+s >= 0, E-ext >= 0, h-open >= 0, and the floor max(., B) replaces the clamp at 0.  Exact while
-// bound + B <= 0x7BFF.  4 integer add/sub + 3.5 maximum3 = 7.5 ops per pair of cells.
+// bound + B <= 0x7BFF.
+//
+// The adds and subtracts are PLAIN 32-BIT ONES on the register pair (round 3).  gfx950 issues v_add_u32 / v_sub_u32 with two
+// VGPR sources at 32 lanes per clock and SIMD -- twice the rate of every packed, three-operand, SDWA or SGPR-operand form
+// (tools/valu_issue.hip, profiles/r03_valu_issue.txt) -- and on these values a 32-bit add IS the packed add: read the pair as
+// the integer hi * 65536 + lo; no half ever leaves 0 .. 0xFFFF (every result is >= 0 by the bias and <= 0x7BFF by the window),
+// so no carry or borrow crosses the halves.  The substitution scores are paired as the integer sB * 65536 + sA (a negative sA
+// borrows from the upper half in advance), the penalties sit in VGPRs (an SGPR operand would halve the rate).  Per pair of
+// cells: 4 adds/subs at double rate + 3.5 maximum3 = 5.5 issue slots (7.5 with packed adds).
+// Speculative launches (spec_base != 0): a LOWER half that leaves the window may carry into the upper half, so the kernel
+// marks the upper result whenever it marks the lower one; the upper half's carries leave the register.
 struct ArithI16M3 {
     static constexpr bool kMax3 = true;
-    static __device__ __forceinline__ int pen(unsigned p) { return (int)(p | (p << 16)); }
-    static __device__ __forceinline__ int add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
+    static __device__ __forceinline__ int pen(unsigned p) { int v = (int)(p | (p << 16)); asm volatile("" : "+v"(v)); return v; }   // a VGPR, opaque to the compiler
+    static __device__ __forceinline__ int add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
     static __device__ __forceinline__ int hmax(int s, int e, int f) { return pk_maximum3(s, e, f); }
-    static __device__ __forceinline__ int sub(int x, int p) { return as_i(as_s(x) - as_s(p)); }       // never wraps: x >= B >= p
+    static __device__ __forceinline__ int sub(int x, int p) { return (int)((unsigned)x - (unsigned)p); }     // no borrow: x >= B >= p in both halves
     static __device__ __forceinline__ int gmax(int a, int b, int fl) { return pk_maximum3(a, b, fl); }
     static __device__ __forceinline__ int best1(int best, int h) { return pk_maximum3(best, h, h); }
     static __device__ __forceinline__ int best2(int best, int h0, int h1) { return pk_maximum3(best, h0, h1); }
-    static __device__ __forceinline__ int pair(int sA, int sB) { return (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16)); }
+    static __device__ __forceinline__ int pair(int sA, int sB) { return (int)(((unsigned)sB << 16) + (unsigned)sA); }
     static __device__ __forceinline__ int out(int best, int half, int fl) { return (int)as_s(best)[half] - (int)as_s(fl)[0]; }
 };
 
@@ -534,6 +571,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     __syncthreads();
+    clk_enter(a.clk);
 
     const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
     v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
@@ -602,7 +640,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
             // `best` is the biased H + B, and the first value to pass 0x7BFF is a diag + s whose diag was exact and
             // already > spec_base = 0x7BFF - max score, so best <= spec_base => exact
             if (a.spec_base) {
-                if (((unsigned)best & 0xFFFFu) > a.spec_base) outA = kScoreUnsure;
+                if (((unsigned)best & 0xFFFFu) > a.spec_base) outA = outB = kScoreUnsure;      // a lower half beyond the window may have carried into the upper one
                 if (((unsigned)best >> 16) > a.spec_base) outB = kScoreUnsure;
             }
         }
@@ -612,6 +650,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
             if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = outB;
         }
     }
+    clk_leave(a.clk, lane);
 }
 
 
@@ -637,11 +676,13 @@ __device__ __forceinline__ void pkd_rows8(int (&H)[R], int (&E)[R], int row0, co
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = row0 + i;
-        const int h = pk_maximum3(as_i(as_s(diag) + as_s(sc[i / 4][i % 4])), E[r], F);
+        // (plain 32-bit adds on the pair where both sources are VGPRs: they issue a little faster than the packed forms --
+        // tools/valu_issue.hip -- and no half ever leaves 0 .. 0xFFFF, so no carry crosses; sc and eo are integer-sum pairs)
+        const int h = pk_maximum3((int)((unsigned)diag + (unsigned)sc[i / 4][i % 4]), E[r], F);
         const int t = as_i(as_s(h) - as_s(zcur));                      // true H of both cells (>= 0)
         if (i & 1) best = pk_maximum3(best, tprev, t); else tprev = t;
         zcur += e2;                                                    // scalar: z(i+1, j) = z(i, j+1)
-        const int hm = as_i(as_s(h) + as_s(eo));
+        const int hm = (int)((unsigned)h + (unsigned)eo);
         E[r] = pk_maximum3(E[r], hm, zcur);
         F = as_i(pk_max(as_s(F), as_s(hm)));
         diag = H[r];
@@ -712,12 +753,14 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     __syncthreads();
+    clk_enter(a.clk);
 
     const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
     v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
     const unsigned n_items = a.n_groups * a.n_pairs;
     const int e2 = (int)(a.ext | (a.ext << 16));
-    const int eo = (int)(((a.ext - a.open) & 0xFFFFu) * 0x10001u);     // packed (e - o), two's complement per half
+    int eo = ((int)a.ext - (int)a.open) * 65537;                         // the pair (e - o, e - o) as the integer hi * 65536 + lo, in a VGPR
+    asm volatile("" : "+v"(eo));
     const int B2 = (int)a.floor_bits;                                   // packed bias B
     const int two_e = 2 * (int)a.ext;
 
@@ -760,7 +803,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
                 for (int d = 0; d < 4; ++d) {
                     const int sA = lmat[((cA >> (8 * d)) & 31u) * 32 + t] + two_e;
                     const int sB = lmat[((cB >> (8 * d)) & 31u) * 32 + t] + two_e;
-                    out[d] = (int)(((unsigned)sA & 0xFFFFu) | ((unsigned)sB << 16));
+                    out[d] = (int)(((unsigned)sB << 16) + (unsigned)sA);        // integer-sum pair: a negative sA borrows from sB in advance
                 }
                 *reinterpret_cast<v4i*>(prof + e * 16) = out;
             }
@@ -794,7 +837,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
             // every max), but as an unsigned 16-bit value best stays > limit.  Hence: best <= limit => exact.
             const unsigned zmax = (lq + 2u * R + len4 * 4u + 8u) * a.ext;
             const unsigned limit = a.spec_base > zmax ? a.spec_base - zmax : 0u;
-            if (((unsigned)best & 0xFFFFu) > limit) outA = kScoreUnsure;
+            if (((unsigned)best & 0xFFFFu) > limit) outA = outB = kScoreUnsure;   // (a lower half outside the window may have carried into the upper one)
             if (((unsigned)best >> 16) > limit) outB = kScoreUnsure;
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
@@ -803,6 +846,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
             if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = outB;
         }
     }
+    clk_leave(a.clk, lane);
 }
 
 }  // namespace s4g

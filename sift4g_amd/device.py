@@ -193,6 +193,15 @@ def scan_stats(device=0):
                 speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]), list_pairs=int(out[7]))
 
 
+def scan_clock(device=0):
+    """shader clock and duration of the longest scan launch of the last scan call on `device`, sampled inside the kernel
+    (s4g_scan_clock)"""
+    out = (ctypes.c_double * 8)()
+    check(lib.s4g_scan_clock(device, out, 8), "s4g_scan_clock")
+    return dict(launches=int(out[0]), shader_mhz=out[1], shader_mhz_min=out[2], shader_mhz_max=out[3], blocks=int(out[4]),
+                kernel_ms=out[5], tier=("drift", "m3", "i16", "i32")[int(out[6])] if out[0] else None, shader_clocks=out[7])
+
+
 def clock_probe(device=0):
     """shader clock under vector-ALU load and the measured packed-int16 issue rate (s4g_clock_probe)"""
     out = (ctypes.c_double * 5)()

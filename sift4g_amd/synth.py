@@ -61,10 +61,22 @@ def random_set(seed, lengths):
     off[1:] = np.cumsum(lengths).astype(np.uint64)
     total = int(off[-1])
     codes = np.empty(max(total, 1), dtype=np.uint8)
-    step = 1 << 24
-    for b in range(0, total, step):
+    step = 1 << 22
+
+    def fill(b):
         m = min(step, total - b)
         codes[b:b + m] = residues(seed, m, b)
+
+    starts = range(0, total, step)
+    if total > 4 * step:        # counter-based generator: chunks are independent, numpy releases the GIL inside its loops
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(fill, starts))
+    else:
+        for b in starts:
+            fill(b)
     return codes, off
 
 

@@ -52,6 +52,16 @@ def _check_common(d, n_gpus, steps, warmup):
     # SURVEY.md 8d (16 B per cell against 8 TB/s) rides along
     assert rf["bound"] == "valu" and rf["unit"] == "T lane-ops/s" and 20.0 < rf["peak"] < 45.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 0
+    # `peak` is priced at the guide's 2.4 GHz; the clock the timed kernel ran at is sampled inside it and prices the second peak
+    assert "2400 MHz" in rf["peak_basis"] and rf["frac_algorithmic"] == rf["frac"] and rf["traffic_measured_in_run"] is False
+    ck = rf["clock_in_kernel"]
+    if ck["launches_sampled"]:           # a call that went to the pair waves as a whole launches no scan kernel
+        assert 800.0 < ck["min_block"] <= ck["shader_mhz"] <= ck["max_block"] < 2600.0 and ck["blocks"] >= 1
+        assert abs(rf["peak_at_measured_clock"] / rf["peak"] - ck["shader_mhz"] / 2400.0) < 1e-3
+        if rf["kernel_ms"] > 50.0 and ck["launches_sampled"] == 1:       # one long launch: the two clocks must tell the same time
+            assert abs(ck["kernel_ms_by_100MHz_counter"] / rf["kernel_ms"] - 1.0) < 0.05
+    for ph in ("scan_ms", "topk_ms", "gather_ms"):
+        assert d["phases"][ph]["max"] >= d["phases"][ph]["min"] >= 0.0
     hb = rf["hbm"]
     assert hb["bound"] == "hbm" and hb["unit"] == "GB/s" and hb["peak"] == 8000.0 and abs(hb["frac"] - hb["achieved"] / hb["peak"]) < 1e-3
     if "selfcheck" in d:
@@ -104,3 +114,56 @@ def test_bench_db_shard_mode_device_generated_shards():
         chk = d["selfcheck"]
         assert chk["planted_copies"] == 6 and chk["planted_not_first"] == 0 and chk["mismatches"] == 0
         assert d["config"]["extrapolated"]["wall_s_at_this_rate_per_gpu_x8"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_eight_rank_rehearsal_on_one_gpu():
+    """The job the driver launches on an 8-GPU node, rehearsed with its eight ranks sharing this box's GPU(s): a query count that
+    does not divide by 8 (ragged shards), per-phase timings and the all-gather payload in the line, self-check of rank 0's lists;
+    then the same for --mode db-shard.  Emulated (gloo) unless the box really has eight GPUs; never a scaling measurement."""
+    d = _run_bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--queries", "45", "--targets", "5000", "--no-cpu-baseline",
+                   env={"S4G_BENCH_SHARE_GPU": "1"})
+    _check_common(d, 8, 2, 1)
+    assert "query-shard x8" in d["config"]["parallelism"] and d["scaling"] == "strong"
+    # 45 queries over 8 ranks: shards of 5 or 6 queries; every rank pads its lists to the longest shard for the all-gather
+    assert d["gather_payload_bytes"] == 6 * (2 * 400 + 1) * 4 * 8
+    assert d["phases"]["scan_ms"]["max"] > 0 and d["phases"]["gather_ms"]["max"] > 0
+    assert d["selfcheck"]["mismatches"] == 0 and d["selfcheck"]["top_list_entries"] > 0
+    one = _run_bench("--gpus", "1", "--workload", "configs2", "--steps", "1", "--warmup", "0", "--queries", "45", "--targets", "5000",
+                     "--no-cpu-baseline", "--no-tiers", "--no-prefilter")
+    assert one["config"]["cells_per_step"] == d["config"]["cells_per_step"]
+    d = _run_bench("--gpus", "8", "--mode", "db-shard", "--steps", "1", "--warmup", "1", "--queries", "11", "--targets", "12000",
+                   "--no-cpu-baseline", env={"S4G_BENCH_SHARE_GPU": "1"})
+    _check_common(d, 8, 1, 1)
+    assert d["scaling"] == "weak" and "db-shard x8" in d["config"]["parallelism"]
+    assert d["gather_payload_bytes"] == 11 * 2 * 400 * 4 * 8
+    chk = d["selfcheck"]
+    assert chk["planted_copies"] == 11 and chk["planted_not_first"] == 0 and chk["mismatches"] == 0
+
+
+def test_numa_pinning_reads_a_kfd_topology(tmp_path):
+    """sift4g_amd/numa.py on a synthetic sysfs tree: two CPU nodes, four GPUs (two per socket), io_links to the socket."""
+    from sift4g_amd import numa
+    kfd, nodes = tmp_path / "kfd", tmp_path / "node"
+    for i in range(2):
+        (kfd / str(i)).mkdir(parents=True)
+        (kfd / str(i) / "properties").write_text("cpu_cores_count 4\nsimd_count 0\n")
+        (nodes / f"node{i}").mkdir(parents=True)
+        (nodes / f"node{i}" / "cpulist").write_text("0-3\n" if i == 0 else "4-7\n")
+    for g in range(4):
+        d = kfd / str(2 + g)
+        (d / "io_links" / "0").mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndomain 0\nlocation_id 256\n")
+        (d / "io_links" / "0" / "properties").write_text(f"type 2\nnode_from {2 + g}\nnode_to {g // 2}\n")
+    assert numa.gpu_numa_nodes(str(kfd)) == [0, 0, 1, 1]
+    assert numa._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    before = os.sched_getaffinity(0)
+    try:
+        info = numa.pin_to_gpu(2, str(kfd), str(nodes))
+        if before & {4, 5, 6, 7}:
+            assert info["pinned"] and info["numa_node"] == 1 and os.sched_getaffinity(0) == before & {4, 5, 6, 7}
+        else:
+            assert not info["pinned"] and "affinity" in info["reason"]
+        assert numa.pin_to_gpu(9, str(kfd), str(nodes))["pinned"] is False
+    finally:
+        os.sched_setaffinity(0, before)

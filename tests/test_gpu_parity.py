@@ -968,7 +968,8 @@ def test_speculative_launch_really_marks_results(s4g, oracle_mod, blosum62):
     got2 = s4g.scan_host(s4g.Database(ts2), s4g.QuerySet(qs2), s4g.Scorer("BLOSUM_62", 12, 5), no_pairs=True)
     st = s4gd.scan_stats(0)
     assert np.array_equal(got2, exp2) and exp2[2, 20] > 32767
-    assert st["speculative"] >= 1 and st["rechecked"] == 1 and st["tier_m3"] >= 1, st
+    # (the upper half of a register pair is marked together with a marked lower half: the partner query's result at that target too)
+    assert st["speculative"] >= 1 and 1 <= st["rechecked"] <= 2 and st["tier_m3"] >= 1, st
 
 
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):

@@ -53,4 +53,10 @@ json.dump(s, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 if label.startswith("sw_scan_pkd"):        # the default kernel: what bench.py copies into roofline.traffic
     json.dump(dict(kernel=label, workload_cells=cells, hbm_bytes_per_launch=s["hbm_bytes_per_launch"], source=f"{dst}/pmc_summary.json",
                    git_sha=sha), open("profiles/hbm_traffic.json", "w"), indent=1)
+# executed vector lane-ops per cell of every profiled scan kernel: what bench.py's roofline.frac_executed is priced with
+ve_path = "profiles/valu_executed.json"
+ve = json.load(open(ve_path)) if os.path.exists(ve_path) else {}
+ve[label] = dict(lane_ops_per_cell=s["derived"]["valu_lane_ops_per_cell"], workload_cells=cells, SQ_INSTS_VALU=sq["SQ_INSTS_VALU"]["sum"],
+                 source=f"{dst}/pmc_summary.json", git_sha=sha)
+json.dump(ve, open(ve_path, "w"), indent=1)
 print(json.dumps(s["derived"], indent=1))
