@@ -36,9 +36,13 @@ BYTES_PER_CELL = 16.0          # SURVEY.md 8d contract figure: streamed H/E colu
 TOPK = 400                     # max_alignments default (/root/reference/sift4g/src/main.cpp:75)
 LANES_PER_CLK_PER_SIMD = 16    # a wave64 vector instruction occupies its SIMD for 4 clocks (profiles/r03_valu_issue.txt)
 GUIDE_CLOCK_MHZ = 2400.0       # MI355X_MICROARCH.md: peak engine clock; the roofline's `peak` is priced at it
-# algorithmic vector ops per DP cell of each scan kernel (counted from the recurrence, not from the ISA)
-VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": 3.25, "sw_scan_pk<ArithI16M3,32>": 3.75, "sw_scan_pk<ArithF16,32>": 3.75,
-                     "sw_scan_pk<ArithI16,32>": 4.5, "sw_scan_i32<32>": 7.5, "sw_scan_i32d<32>": 6.5}
+# Algorithmic vector instructions per DP cell of each scan kernel, counted from the recurrence, as
+# (all, of which "half-slot" class).  A gfx950 SIMD issues one vector instruction per 4-clock slot (16 lanes per clock) -- except
+# that 32-bit add / sub / logic / mov / f32 add-mul-fma with two VGPR sources can share a slot two at a time when two waves present
+# them together (tools/valu_issue.hip, profiles/r03_valu_issue.txt).  The roofline counts such an instruction as HALF a slot: the
+# bound holds even if every one of them found a partner (in the kernels' mixes few do: 0.85-0.95 of a slot each, measured).
+VALU_OPS_PER_CELL = {"sw_scan_pkd<32>": (3.25, 1.0), "sw_scan_pk<ArithI16M3,32>": (3.75, 2.0), "sw_scan_pk<ArithF16,32>": (3.75, 0.0),
+                     "sw_scan_pk<ArithI16,32>": (4.5, 0.0), "sw_scan_i32<32>": (7.5, 3.0), "sw_scan_i32d<32>": (6.5, 1.0)}
 WORKLOADS = {
     "configs1": dict(cfg=2, queries=1000, targets=100_000, qlen=(300, 400), label="BASELINE configs[1]"),
     "configs2": dict(cfg=3, queries=1000, targets=570_000, qlen=(300, 400), label="BASELINE configs[2] (Swiss-Prot scale)"),
@@ -401,7 +405,8 @@ def main():
     if rank == 0:
         gcups = cells_total * args.steps / dt / 1e9
         kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        ops = VALU_OPS_PER_CELL.get(plan["kernel"], 0.0)
+        ops, half_ops = VALU_OPS_PER_CELL.get(plan["kernel"], (0.0, 0.0))
+        slots = ops - 0.5 * half_ops                 # issue slots per cell if every half-slot instruction found a partner
         # ---- the roof that binds: vector-ALU issue.  `peak` = CUs x 4 SIMDs x 16 lanes per clock x the guide's 2.4 GHz;
         #      the clock the timed kernel really ran at is sampled INSIDE it (s4g_scan_clock) and prices `peak_at_measured_clock` ----
         import ctypes as _ct
@@ -409,7 +414,8 @@ def main():
         clock_mhz = clk["shader_mhz"] if clk["launches"] and clk["shader_mhz"] > 500.0 else 0.0
         valu_peak = cus * 4 * LANES_PER_CLK_PER_SIMD * GUIDE_CLOCK_MHZ * 1e6 / 1e12             # T lane-ops/s at 2.4 GHz
         valu_peak_meas = cus * 4 * LANES_PER_CLK_PER_SIMD * clock_mhz * 1e6 / 1e12 if clock_mhz else None
-        valu_achieved = kern_gcups * ops / 1e3
+        valu_achieved = kern_gcups * slots / 1e3
+        valu_all_full = kern_gcups * ops / 1e3       # round 2's figure: every instruction a full slot
         # executed (not algorithmic) lane-ops per cell: SQ_INSTS_VALU x 64 / cells of a committed rocprofv3 --pmc pass of this
         # command (profiles/valu_executed.json, tagged with the commit it was collected on)
         exec_ops, exec_src = None, None
@@ -419,7 +425,7 @@ def main():
                 exec_ops, exec_src = ve["lane_ops_per_cell"], ve.get("source")
         except Exception:
             exec_ops = None
-        valu_executed = kern_gcups * exec_ops / 1e3 if exec_ops else None
+        valu_executed = kern_gcups * (exec_ops - 0.5 * half_ops) / 1e3 if exec_ops else None      # executed slots (the half-slot share as counted above)
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes of this command
         if os.path.exists(prof):
@@ -453,10 +459,12 @@ def main():
                 "frac": round(valu_achieved / valu_peak, 4) if valu_peak else None, "traffic": traffic,
                 "traffic_measured_in_run": False,
                 "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
-                "ops_per_cell": ops,
-                "peak_basis": f"{cus} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {GUIDE_CLOCK_MHZ:.0f} MHz (guide peak engine clock)",
-                # achieved = algorithmic lane-ops per cell x cells / the kernel's HIP-event time; frac_algorithmic = frac
+                "ops_per_cell": ops, "half_slot_ops_per_cell": half_ops, "issue_slots_per_cell": slots,
+                "peak_basis": f"{cus} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {GUIDE_CLOCK_MHZ:.0f} MHz (guide peak engine clock): one vector "
+                              "instruction per SIMD and 4-clock issue slot; two-VGPR-source add/sub/logic/mov count half a slot (they can pair up across waves)",
+                # achieved = algorithmic issue slots per cell (x 64 lanes) x cells / the kernel's HIP-event time; frac_algorithmic = frac
                 "frac_algorithmic": round(valu_achieved / valu_peak, 4) if valu_peak else None,
+                "frac_every_instruction_a_full_slot": round(valu_all_full / valu_peak, 4) if valu_peak else None,
                 "executed_ops_per_cell": exec_ops, "executed": round(valu_executed, 3) if valu_executed else None,
                 "frac_executed": round(valu_executed / valu_peak, 4) if valu_executed else None,
                 "executed_source": exec_src,
@@ -470,7 +478,7 @@ def main():
                 "frac_executed_at_measured_clock": round(valu_executed / valu_peak_meas, 4) if valu_executed and valu_peak_meas else None,
                 "traffic_source": traffic_src,
                 "note": "a register-tiled kernel moves ~8/R bytes per cell, so it sits far above the HBM contract roofline by construction; "
-                        "vector-ALU issue is the limit that binds (achieved = algorithmic ops per cell x measured cells/s)",
+                        "vector-ALU issue is the limit that binds (achieved = algorithmic issue slots per cell x 64 lanes x measured cells/s)",
                 # the contract figure of SURVEY.md 8d / BASELINE.md: 16 algorithmic bytes per cell against 8 TB/s
                 "hbm": {"bound": "hbm", "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": BYTES_PER_CELL,
@@ -545,10 +553,12 @@ def main():
             clk32 = s4gd.scan_clock(dev_index)
             mhz32 = clk32["shader_mhz"] if clk32["launches"] else 0.0
             peak32 = cus * 4 * LANES_PER_CLK_PER_SIMD * mhz32 * 1e6 / 1e12 if mhz32 else None
+            slots32 = VALU_OPS_PER_CELL["sw_scan_i32d<32>"][0] - 0.5 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"][1]
             out["tiers"] = {"int32": {"gcups": round(g32, 2), "kernel_ms": round(k32, 3), "kernel": "sw_scan_i32d<32>", "steps": 2,
-                                      "valu_frac": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / valu_peak, 4) if valu_peak else None,
+                                      "valu_frac": round(g32 * slots32 / 1e3 / valu_peak, 4) if valu_peak else None,
                                       "shader_mhz_in_kernel": round(mhz32, 1),
-                                      "valu_frac_at_measured_clock": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"] / 1e3 / peak32, 4) if peak32 else None},
+                                      "valu_frac_at_measured_clock": round(g32 * slots32 / 1e3 / peak32, 4) if peak32 else None,
+                                      "valu_frac_every_instruction_a_full_slot": round(g32 * VALU_OPS_PER_CELL["sw_scan_i32d<32>"][0] / 1e3 / valu_peak, 4) if valu_peak else None},
                             tier: {"gcups": round(kern_gcups, 2), "kernel_ms": round(kern_ms, 3), "kernel": plan["kernel"]}}
         if world == 1 and not db_shard and args.workload == "auto" and not args.no_scale_ref and args.queries is None and args.targets is None:
             # ---- like-for-like denominator of the N > 1 lines: the workload they run (configs[2], strong-scaled) on this one GPU,

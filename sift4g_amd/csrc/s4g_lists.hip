@@ -23,6 +23,7 @@ constexpr double kListChipRate = 9.0e12, kListWaveChipRate = 2.8e12;
 constexpr double kListCyclesPerRowCol = 20.0, kListCyclesPerQueuedItem = 5.5, kClockHz = 2.4e9;
 constexpr double kListItemsToFill = 700.0;
 constexpr double kListFixedCost = 250e-6;            // sort + item tables + gather + one host round trip
+constexpr uint32_t kListPairSlack = 64;              // two queries share an item (one per register half) when their lengths differ by no more than this
 constexpr uint32_t kListMaxTarget = 4096;            // longer targets always go to the pair waves: the block workspace is 2 KB per residue
                                                      // of the longest member and block (6.4 GB at 4096 residues on 768 blocks)
 
@@ -117,7 +118,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     for (uint32_t i = 0; i < q->n; ++i) {
         const uint64_t fixed = q->score_bound[i] + bias;
         if (fixed > cap) continue;
-        const uint64_t rows = (uint64_t)q->len[i] + 2 * kListRows;
+        const uint64_t rows = (uint64_t)q->len[i] + 2 * kListRows + kListPairSlack;        // (an item runs to the longer of its two queries)
         uint64_t cols = scorer->ext ? (cap - fixed) / (uint64_t)scorer->ext : 0xFFFFFFFFull;
         if (scorer->ext && cols < rows + 16) continue;
         if (scorer->ext) cols -= rows + 12;              // 8 + rounding of the length to 4
@@ -253,10 +254,31 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     const auto t1 = now();
 
     // ---- host: entries (key = query, length rank; value = target, local index) and the item table ----
-    // items of block k of every query come before block k + 1 of any: the longest members of every list start first
+    // Units: two queries of nearly the same length walk their lists in step, 64 candidates each per item; a query without such a
+    // partner is a unit of its own (items of 128).  Items of block k of every unit come before block k + 1 of any: the longest
+    // members of every list start first.
+    struct Unit { uint32_t a, b; };             // b == a: single
+    std::vector<Unit> units;
+    {
+        std::vector<uint32_t> order;
+        for (uint32_t i = 0; i < q->n; ++i) if (count[i + 1]) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return q->len[x] > q->len[y]; });
+        for (size_t i = 0; i < order.size();) {
+            if (i + 1 < order.size() && q->len[order[i]] - q->len[order[i + 1]] <= kListPairSlack) { units.push_back({order[i], order[i + 1]}); i += 2; }
+            else { units.push_back({order[i], order[i]}); i += 1; }
+        }
+    }
+    // items of a unit: while both lists last, 64 + 64; then (or for a single) 128 of the one that is left
+    auto unit_items = [&](const Unit& u) -> uint32_t {
+        const uint32_t ca = count[u.a + 1], cb = u.b != u.a ? count[u.b + 1] : 0;
+        const uint32_t paired = std::min((ca + 63) / 64, (cb + 63) / 64);           // items with both halves filled (the last may be short)
+        const uint32_t done = paired * 64;
+        const uint32_t rest = (ca > done ? ca - done : 0) + (cb > done ? cb - done : 0);          // only one of the two is non-zero
+        return paired + (rest + 127) / 128;
+    };
     uint32_t n_items = 0, max_blocks = 0;
-    for (uint32_t i = 0; i < q->n; ++i) {
-        const uint32_t blocks = (count[i + 1] + 127) / 128;
+    for (const Unit& u : units) {
+        const uint32_t blocks = unit_items(u);
         n_items += blocks;
         max_blocks = std::max(max_blocks, blocks);
     }
@@ -296,10 +318,26 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     {
         uint32_t at = 0;
         for (uint32_t blk = 0; blk < max_blocks; ++blk)
-            for (uint32_t i = 0; i < q->n; ++i) {
-                const uint32_t seg = count[i + 1] - count[i];
-                if (seg <= blk * 128) continue;
-                h_items[at++] = ListItem{i, count[i] + blk * 128, std::min(128u, seg - blk * 128), 0u, 0ull};
+            for (const Unit& u : units) {
+                const uint32_t ca = count[u.a + 1] - count[u.a], cb = u.b != u.a ? count[u.b + 1] - count[u.b] : 0;
+                const uint32_t paired = std::min((ca + 63) / 64, (cb + 63) / 64);
+                ListItem it;
+                it.len4 = 0; it.res_off = 0;
+                if (blk < paired) {
+                    it.qa = u.a; it.qb = u.b;
+                    it.first_a = count[u.a] + blk * 64; it.first_b = count[u.b] + blk * 64;
+                    it.na = (uint16_t)std::min(64u, ca - blk * 64); it.nb = (uint16_t)std::min(64u, cb - blk * 64);
+                } else {
+                    const uint32_t done = paired * 64;
+                    const bool from_a = ca > done;
+                    const uint32_t qx = from_a ? u.a : u.b, cx_ = from_a ? ca : cb;
+                    const uint32_t off = done + (blk - paired) * 128;
+                    if (cx_ <= off) continue;
+                    it.qa = it.qb = qx;
+                    it.first_a = count[qx] + off; it.first_b = it.first_a + 64;
+                    it.na = (uint16_t)std::min(64u, cx_ - off); it.nb = (uint16_t)(cx_ - off > 64 ? std::min(64u, cx_ - off - 64) : 0);
+                }
+                h_items[at++] = it;
             }
     }
     int q_bits = 1;

@@ -7,16 +7,23 @@
 // needs targets both queries want; the one-wave-per-pair kernels (sw_pair.hip.h) take any pair but spend 11 vector
 // lane-ops per cell (int32, 64 lanes on one DP) and run at the vector-issue limit doing so (profiles/r02_pair).
 //
-// Here the halves of a register carry two different TARGETS of the SAME query:
-//   * a query's candidates are sorted by length on the device and cut into items of 128: candidate 2l of an item sits in
-//     the low half of lane l, candidate 2l+1 in the high half, so both halves see nearly the same lengths;
+// Here the halves of a register carry two different TARGETS, each with a query of its own:
+//   * a query's candidates are sorted by length on the device; an item is 64 consecutive candidates of query A in the lower
+//     halves of the 64 lanes and 64 consecutive candidates of query B in the upper halves, A and B being two queries of
+//     (nearly) the same length whose lists the host walks in step -- an item then spans 64 ranks of a length-sorted list
+//     instead of 128, which halves the padding to its longest member (round 2: 128 candidates of ONE query, +11 % columns).
+//     What is left of the longer list when the shorter one ends, and a query without a partner, run as items of 128 of one
+//     query (A = B, the second 64 in the upper halves);
 //   * list_gather copies the 128 targets of every item out of the resident database into a lane-transposed block of
 //     their own (dword (c*2 + half)*64 + lane = columns 4c .. 4c+3), padded to the item's longest member -- the scan then
 //     reads 2 x 256 contiguous bytes per wave and 4 columns, exactly like a database group;
 //   * sw_scan_lists is sw_scan_pkd (drifting frame, v_pk_maximum3_f16 on integer bit patterns, same exactness window)
-//     with ONE difference: the strip profile holds single 16-bit scores, a lane looks its two residues up separately
-//     (two ds_read_b128 per 8 rows, as before) and one v_perm_b32 per row pairs them up: 7.5 vector ops per pair of
-//     cells instead of 6.5.
+//     with ONE difference: a lane looks its two residues up separately.  The strip profile is two tables of 32-bit words --
+//     PA[4-row block][residue][4 rows] = s + 2e (sign-extended) for the lower half, PB = (s + 2e) << 16 for the upper --
+//     and ONE v_add3_u32 per row adds both to the diagonal: on the register pair read as the integer hi * 65536 + lo that
+//     IS the packed add (no half leaves 0 .. 0xFFFF, a negative lower score borrows from the upper half exactly as the
+//     integer sum says).  6.5 vector ops per pair of cells, as the scan kernel (round 2 paired 16-bit scores with a
+//     v_perm_b32 per row: 7.5); the price is twice the LDS reads (two ds_read_b128 per 4 rows) and 8 KB of tables per wave.
 // Targets too long for a launch this short to wait for, and queries beyond the frame window, stay on the pair kernels
 // (the host splits, s4g_lists.hip).
 #pragma once
@@ -25,12 +32,13 @@
 namespace s4g {
 
 struct ListItem {
-    uint32_t q;          // query id
-    uint32_t first;      // index of the item's first entry in the sorted entry list (entry first + 2*lane + half)
-    uint32_t n;          // entries of the item, 1 .. 128
-    uint32_t len4;       // 4-column chunks = ceil(longest member / 4)       (filled on the device: list_item_len)
-    uint64_t res_off;    // dword offset of the item's block in the gathered residues (filled on the device: exclusive scan)
+    uint32_t qa, qb;         // query of the lower / upper halves (qb == qa: one query, 128 of its candidates)
+    uint32_t first_a, first_b;   // index of the halves' first entry in the sorted entry list (lane l: entry first + l)
+    uint16_t na, nb;         // entries of each half, 0 .. 64 (na >= 1)
+    uint32_t len4;           // 4-column chunks = ceil(longest member / 4)       (filled on the device: list_item_len)
+    uint64_t res_off;        // dword offset of the item's block in the gathered residues (filled on the device: exclusive scan)
 };
+static_assert(sizeof(ListItem) == 32, "ListItem layout");
 
 struct ListArgs {
     const ListItem* __restrict__ items;
@@ -54,8 +62,10 @@ __global__ void list_item_len(ListItem* __restrict__ items, uint32_t n_items, co
                               const uint32_t* __restrict__ seq_len, uint64_t* __restrict__ dwords) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
-    const uint32_t t = (uint32_t)(entries[items[i].first] >> 32);        // entries are sorted longest first within a query
-    const uint32_t len4 = (seq_len[t] + 3) / 4;
+    const ListItem it = items[i];
+    uint32_t l = seq_len[(uint32_t)(entries[it.first_a] >> 32)];            // entries are sorted longest first within a query
+    if (it.nb) l = max(l, seq_len[(uint32_t)(entries[it.first_b] >> 32)]);
+    const uint32_t len4 = (l + 3) / 4;
     items[i].len4 = len4;
     dwords[i] = (uint64_t)len4 * 128;
 }
@@ -65,7 +75,7 @@ __global__ void list_item_off(ListItem* __restrict__ items, uint32_t n_items, co
     if (i < n_items) items[i].res_off = offs[i];
 }
 
-// One block per item: out[(c*2 + half)*64 + lane] = dword c of entry first + 2*lane + half, pad (code 31) beyond a
+// One block per item: out[(c*2 + half)*64 + lane] = dword c of entry first_a + lane (half 0) / first_b + lane (half 1), pad (code 31) beyond a
 // member's own length and in empty slots.  Sources are lane-transposed database sequences (dword c of a sequence lives
 // 64*c dwords after its first): 128 scattered 4-byte reads per output row, served by L2 -- the pool of a chunk is a few
 // tens of MB and every sector is wanted by the 16 neighbours of its group sooner or later.
@@ -75,11 +85,10 @@ __global__ __launch_bounds__(256) void list_gather(const ListItem* __restrict__ 
     const ListItem it = items[blockIdx.x];
     const int slot = threadIdx.x & 127;               // half*64 + lane
     const int half = slot >> 6, lane = slot & 63;
-    const uint32_t e = 2u * lane + half;
     const uint32_t* src = nullptr;
     uint32_t l4 = 0, lt = 0;
-    if (e < it.n) {
-        const uint32_t t = (uint32_t)(entries[it.first + e] >> 32);
+    if ((uint32_t)lane < (half ? it.nb : it.na)) {
+        const uint32_t t = (uint32_t)(entries[(half ? it.first_b : it.first_a) + lane] >> 32);
         src = reinterpret_cast<const uint32_t*>(seq_addr[t]);
         lt = seq_len[t];
         l4 = (lt + 3) / 4;
@@ -92,21 +101,20 @@ __global__ __launch_bounds__(256) void list_gather(const ListItem* __restrict__ 
     }
 }
 
-// rows row0 .. row0+7 of one column for both halves: xa / xb = the 8 scores (int16 each, s + 2e) of the low / high half's residue
+// rows row0 .. row0+3 of one column for both halves: xa = the 4 scores s + 2e of the lower half's residue, xb = those of the upper
+// half's residue << 16
 template <int R>
-__device__ __forceinline__ void lst_rows8(int (&H)[R], int (&E)[R], int row0, const v4i& xa, const v4i& xb, int& diag, int& F, int& best,
+__device__ __forceinline__ void lst_rows4(int (&H)[R], int (&E)[R], int row0, const v4i& xa, const v4i& xb, int& diag, int& F, int& best,
                                           int eo, int& zcur, int e2) {
     int tprev = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int r = row0 + i;
-        // (high half's score << 16) | low half's score: bytes 0-3 select from the second operand, 4-7 from the first
-        const int sc = (int)__builtin_amdgcn_perm((unsigned)xb[i / 2], (unsigned)xa[i / 2], (i & 1) ? 0x07060302u : 0x05040100u);
-        const int h = pk_maximum3(as_i(as_s(diag) + as_s(sc)), E[r], F);
+        const int h = pk_maximum3((int)((unsigned)diag + (unsigned)xa[i] + (unsigned)xb[i]), E[r], F);       // v_add3_u32
         const int t = as_i(as_s(h) - as_s(zcur));
         if (i & 1) best = pk_maximum3(best, tprev, t); else tprev = t;
         zcur += e2;
-        const int hm = as_i(as_s(h) + as_s(eo));
+        const int hm = (int)((unsigned)h + (unsigned)eo);               // eo: the pair (e - o, e - o) as an integer, in a VGPR
         E[r] = pk_maximum3(E[r], hm, zcur);
         F = as_i(pk_max(as_s(F), as_s(hm)));
         diag = H[r];
@@ -159,7 +167,8 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
                                           const unsigned long long* prod, unsigned long long need_tag,
                                           unsigned long long* mine, unsigned long long my_tag) {
     constexpr bool first = FIRST;
-    constexpr int NB = RR / 8;
+    constexpr int NB = RR / 4;
+    const char* const profb = prof + R * 128;       // PB behind PA
     int H[R];
     int E[R];
 #pragma unroll
@@ -180,7 +189,7 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
     uint32_t ra_n = res[0], rb_n = res[64];
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
     if (!first && len4) { wait_for(1); hb_n = wsH[lane]; fb_n = wsF[lane]; }
-    v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(prof, pk_taddr(rb_n, 0), 0);
+    v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(profb, pk_taddr(rb_n, 0), 0);
     for (unsigned c = 0; c < len4; ++c) {
         const uint32_t ra = ra_n, rb = rb_n;
         const v4i hb = hb_n, fb = fb_n;
@@ -201,9 +210,9 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const v4i xa = xa_n, xb = xb_n;
-                if (b + 1 < NB) { xa_n = lst_load(prof, ta, b + 1); xb_n = lst_load(prof, tb, b + 1); }
-                else { xa_n = lst_load(prof, ta_next, 0); xb_n = lst_load(prof, tb_next, 0); }
-                lst_rows8<R>(H, E, 8 * b, xa, xb, diag, F, best, eo, zcur, e2c);
+                if (b + 1 < NB) { xa_n = lst_load(prof, ta, b + 1); xb_n = lst_load(profb, tb, b + 1); }
+                else { xa_n = lst_load(prof, ta_next, 0); xb_n = lst_load(profb, tb_next, 0); }
+                lst_rows4<R>(H, E, 4 * b, xa, xb, diag, F, best, eo, zcur, e2c);
             }
             hdiag = first ? zcol - e2 : hb[cc];
             zcol += e2;
@@ -226,12 +235,12 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 template <int R>
 __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
-    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 64];
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 256];
     __shared__ ListSync sy;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     signed char* lmat = reinterpret_cast<signed char*>(lds);
-    char* prof = lds + 1024 + wave * (R * 64);         // [R/8 blocks][32 residues][8 rows x int16]
+    char* prof = lds + 1024 + wave * (R * 256);        // PA then PB, each [R/4 blocks][32 residues][4 rows x int32]
     for (int i = threadIdx.x; i < 256; i += kBlock)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
     for (int i = threadIdx.x; i < kListBufs * 128; i += kBlock) (&sy.best[0][0])[i] = 0;
@@ -241,7 +250,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
 
     v4i* const ws_block = reinterpret_cast<v4i*>(a.ws + (uint64_t)blockIdx.x * kListBufs * a.ws_slot);
     const int e2 = (int)(a.ext | (a.ext << 16));
-    const int eo = (int)(((a.ext - a.open) & 0xFFFFu) * 0x10001u);
+    int eo = ((int)a.ext - (int)a.open) * 65537;       // the pair (e - o, e - o) as the integer hi * 65536 + lo ...
+    asm volatile("" : "+v"(eo));                       // ... in a VGPR: the two-VGPR v_add_u32 issues a little faster (tools/valu_issue.hip)
     const int B2 = (int)a.floor_bits;
     const int two_e = 2 * (int)a.ext;
     const int prev_wave = (wave + kWavesPerBlock - 1) % kWavesPerBlock;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
                     if (lane == 0) {
                         const unsigned idx = atomicAdd(a.counter, 1u);
                         ListItem it;
-                        if (idx < a.n_items) it = a.items[idx]; else { it.q = 0; it.first = 0; it.n = 0; it.len4 = 0; it.res_off = 0; }
+                        if (idx < a.n_items) it = a.items[idx]; else { it.qa = it.qb = 0; it.first_a = it.first_b = 0; it.na = it.nb = 0; it.len4 = 0; it.res_off = 0; }
                         sy.ring[f % kListRing] = it;
                         __hip_atomic_store(&sy.fetched, f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -268,9 +278,12 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
             } else __builtin_amdgcn_s_sleep(1);
         }
         ListItem it = sy.ring[k % kListRing];
-        it.q = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.q);
-        it.first = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.first);
-        it.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.n);
+        it.qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.qa);
+        it.qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.qb);
+        it.first_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.first_a);
+        it.first_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.first_b);
+        it.na = (uint16_t)__builtin_amdgcn_readfirstlane((int)it.na);
+        it.nb = (uint16_t)__builtin_amdgcn_readfirstlane((int)it.nb);
         it.len4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.len4);
         it.res_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(it.res_off >> 32)) << 32) |
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)it.res_off);
@@ -278,18 +291,24 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     };
 
     unsigned k = 0, base = 0;                      // the item strip g falls into, and that item's first strip number
+    // rows of an item: the longer of its two queries (the shorter one's rows beyond its end score kPadScore and raise nothing)
+    auto item_rows = [&](const ListItem& x) -> unsigned {
+        if (!x.na) return 0u;
+        const unsigned la = a.q_len[x.qa], lb = a.q_len[x.qb];
+        return la > lb ? la : lb;
+    };
     ListItem it = get_item(0);
-    unsigned lq = it.n ? a.q_len[it.q] : 0u;
+    unsigned lq = item_rows(it);
     unsigned nstrips = (lq + R - 1) / R;
     for (unsigned g = (unsigned)wave;; g += kWavesPerBlock) {
-        while (it.n && g >= base + nstrips) {
+        while (it.na && g >= base + nstrips) {
             base += nstrips;
             ++k;
             it = get_item(k);
-            lq = it.n ? a.q_len[it.q] : 0u;
+            lq = item_rows(it);
             nstrips = (lq + R - 1) / R;
         }
-        if (!it.n) break;
+        if (!it.na) break;
         const unsigned s = g - base;
         // workspace buffer and best row k % 4 were last used by item k - 4: wait until no wave of the block is still there
         if (lane == 0) __hip_atomic_store(&sy.cur[wave], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -302,32 +321,33 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
         v4i* wsH = ws_block + (uint64_t)buf * (a.ws_slot / 4);
         v4i* wsF = wsH + (uint64_t)len4 * 64;
         const uint32_t* res = a.res + it.res_off + lane;
-        const uint8_t* qc = a.q_codes + a.q_off[it.q];
-        const unsigned cap = (lq + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;      // readable bytes of the query
+        const uint8_t* qca = a.q_codes + a.q_off[it.qa];
+        const uint8_t* qcb = a.q_codes + a.q_off[it.qb];
+        const unsigned cap_a = (a.q_len[it.qa] + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;      // readable bytes of the queries
+        const unsigned cap_b = (a.q_len[it.qb] + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;
         if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
         const unsigned long long my_tag = (unsigned long long)g + 1;          // tags start at 1: the initial word 0 matches no strip
         if (lane == 0) __hip_atomic_store(&sy.prog[wave], my_tag << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 
         const unsigned rows_left = lq - s * R;
         const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
-        // ---- strip profile: prof[blk][t] = 8 rows of (score + 2e) as int16 ----
+        // ---- strip profile: PA[blk][t] = 4 rows of query A's (score + 2e), PB[blk][t] = query B's << 16 ----
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int e0 = 0; e0 < 4 * R; e0 += 64) {
+        for (int e0 = 0; e0 < 8 * R; e0 += 64) {
             const int e = e0 + lane;
             const int blk = e >> 5, t = e & 31;
-            const unsigned row0 = s * R + 8 * blk;
-            unsigned c0 = 0x1F1F1F1Fu, c1 = 0x1F1F1F1Fu;
-            if (row0 < cap) { c0 = *reinterpret_cast<const unsigned*>(qc + row0); c1 = *reinterpret_cast<const unsigned*>(qc + row0 + 4); }
-            v4i out;
+            const unsigned row0 = s * R + 4 * blk;
+            const unsigned ca = row0 < cap_a ? *reinterpret_cast<const unsigned*>(qca + row0) : 0x1F1F1F1Fu;
+            const unsigned cb = row0 < cap_b ? *reinterpret_cast<const unsigned*>(qcb + row0) : 0x1F1F1F1Fu;
+            v4i lo, hi;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const unsigned w = d < 2 ? c0 : c1;
-                const int s0 = lmat[((w >> (16 * (d & 1))) & 31u) * 32 + t] + two_e;
-                const int s1 = lmat[((w >> (16 * (d & 1) + 8)) & 31u) * 32 + t] + two_e;
-                out[d] = (int)(((unsigned)s0 & 0xFFFFu) | ((unsigned)s1 << 16));
+                lo[d] = lmat[((ca >> (8 * d)) & 31u) * 32 + t] + two_e;
+                hi[d] = (int)((unsigned)(lmat[((cb >> (8 * d)) & 31u) * 32 + t] + two_e) << 16);
             }
-            *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            *reinterpret_cast<v4i*>(prof + e * 16) = lo;
+            *reinterpret_cast<v4i*>(prof + R * 128 + e * 16) = hi;
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -370,9 +390,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
                 sy.best[buf][2 * lane] = 0;
                 sy.best[buf][2 * lane + 1] = 0;
             }
-            const unsigned e_lo = 2u * lane, e_hi = 2u * lane + 1u;
-            if (e_lo < it.n) a.scores[(uint32_t)a.entries[it.first + e_lo]] = lo;
-            if (e_hi < it.n) a.scores[(uint32_t)a.entries[it.first + e_hi]] = hi;
+            if ((unsigned)lane < it.na) a.scores[(uint32_t)a.entries[it.first_a + lane]] = lo;
+            if ((unsigned)lane < it.nb) a.scores[(uint32_t)a.entries[it.first_b + lane]] = hi;
         }
     }
     if (lane == 0) __hip_atomic_store(&sy.cur[wave], 0xFFFFFFF0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
