@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_scattered / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_scattered / s4g_db_create_cached / s4g_chain_cache_info / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -103,6 +103,21 @@ int s4g_db_create_tiled(s4g_db** out, int device, const uint8_t* codes, const ui
  * query out of chains it already holds, /root/reference/sift4g/src/database_alignment.cpp:136-162 then :80): seqs[i]
  * points at the lens[i] residue codes of target i.  Saves the caller the concatenation. */
 int s4g_db_create_scattered(s4g_db** out, int device, const uint8_t* const* seqs, const uint32_t* lens, uint32_t n_seqs);
+
+/* A candidate database out of sequences the device may already hold: what the reference's wrapper builds per (query, chunk) --
+ * createFilteredDatabase + chainDatabaseCreate + one alignDatabase + chainDatabaseDelete,
+ * /root/reference/sift4g/src/database_alignment.cpp:70-92 -- out of chains that are candidates of many queries.  Every sequence
+ * goes to the device ONCE, into a per-device arena; where it went is recorded in two words the CALLER keeps with the sequence:
+ * tags[i] / addrs[i] are in/out, zero when the sequence is created, handed back unchanged on every later call (never copied
+ * from one sequence to a different one).  The database is two small device tables and serves the one-wave-per-pair routes only:
+ * s4g_score_pairs_host / s4g_score_lists_host (always one wave per pair), s4g_traceback_host; every s4g_scan* entry point and
+ * s4g_db_save return S4G_ERR_INVALID for it.  The arena starts over beyond 16 GB (once no such database is alive); sequences
+ * sent before then are simply sent again. */
+int s4g_db_create_cached(s4g_db** out, int device, const uint8_t* const* seqs, const uint32_t* lens, uint64_t* tags,
+                         uint64_t* addrs, uint32_t n_seqs);
+/* out[0] = sequences the arena of `device` holds, out[1] = its bytes, out[2] / out[3] = sequences of s4g_db_create_cached calls
+ * found there / sent, out[4] = arena generation, out[5] = databases created, out[6] = alive.  cap >= 7. */
+int s4g_chain_cache_info(int device, uint64_t* out, uint32_t cap);
 
 /* The same for residue codes and offsets that already live on `device` (a database generated, decompressed or
  * received there): only the n_seqs+1 offsets come back to the host (length sort, tile cuts); the codes are

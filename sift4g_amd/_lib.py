@@ -41,6 +41,8 @@ SIGNATURES = {
     "s4g_db_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32]),
     "s4g_db_create_tiled": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32, ctypes.c_uint32]),
     "s4g_db_create_scattered": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_u32p, ctypes.c_uint32]),
+    "s4g_db_create_cached": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_u32p, c_u64p, c_u64p, ctypes.c_uint32]),
+    "s4g_chain_cache_info": (ctypes.c_int, [ctypes.c_int, c_u64p, ctypes.c_uint32]),
     "s4g_db_create_from_device": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
     "s4g_db_tiles": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.c_uint32]),
     "s4g_db_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),

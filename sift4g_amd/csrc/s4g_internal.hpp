@@ -83,8 +83,14 @@ struct s4g_db {
     mutable uint64_t* d_seq_addr = nullptr;     // [n_seqs] device address of the sequence's first residue dword
     mutable uint32_t* d_seq_len = nullptr;      // [n_seqs]
     mutable std::vector<uint32_t> id_of_pos;    // position in the length-sorted order -> original index
-    bool seq_tables_in_block = false;           // d_seq_addr / d_seq_len are part of tiles[0].d_block
+    bool seq_tables_in_block = false;           // d_seq_addr / d_seq_len are part of tiles[0].d_block (or of d_cached_block)
+    // s4g_db_create_cached (s4g_chains.hip): no tiles -- the sequences live in the device's chain arena, the database is its two
+    // tables; it serves the one-wave-per-pair routes only
+    bool cached = false;
+    char* d_cached_block = nullptr;
+    uint64_t cached_block_bytes = 0;
 };
+void chain_cache_release(s4g_db* db);           // s4g_chains.hip
 
 // Per-device scratch shared by every database on that device: strip-boundary workspace, work-queue counters, query
 // lists, the streaming score buffer, a grow-only arena for the traceback.  sift4g's wrapper creates and destroys one

@@ -423,6 +423,7 @@ int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
     if ((uint64_t)q_begin + q_count > q->n) return fail(S4G_ERR_INVALID, "query range out of bounds");
+    if (db->cached) return fail(S4G_ERR_INVALID, "a database of cached chains (s4g_db_create_cached) serves s4g_score_pairs_host / s4g_score_lists_host / s4g_traceback_host only");
     return S4G_OK;
 }
 
@@ -430,6 +431,7 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
                           size_t kernel_name_cap, uint32_t* grid_blocks, uint32_t* block_threads,
                           uint32_t* strip_rows, uint64_t* workspace_bytes) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->cached) return fail(S4G_ERR_INVALID, "a database of cached chains has no scan plan");
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);

@@ -127,40 +127,87 @@ static void flatten(Chain** chains, int n, std::vector<uint8_t>& codes, std::vec
 
 SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, int databaseLen, int* cards, int cardsLen) {
     SW_ASSERT(database != NULL && databaseStart >= 0 && databaseLen >= 0, "chainDatabaseCreate: invalid arguments");
-    Phase ph(0);
-    ChainDatabase* db = new ChainDatabase();
+    ChainDatabase* db = new ChainDatabase();       // (S4G_PROFILE counts the device forms, below, under this function's name)
     db->chains = database + databaseStart;
     db->length = databaseLen;
     db->device = pick_device(cards, cardsLen);
-    db->dev = NULL;
+    db->cached = NULL;
     if (cards && cardsLen > 0) db->cards.assign(cards, cards + cardsLen); else db->cards.assign(1, 0);
-    // the chains stay where they are: the device library packs straight out of their code arrays
-    std::vector<const uint8_t*> seqs((size_t)databaseLen);
-    std::vector<uint32_t> lens((size_t)databaseLen);
+    db->replicas.assign(db->cards.size(), (s4g_db*)NULL);
     db->residues = 0;
     for (int i = 0; i < databaseLen; ++i) {
         SW_ASSERT(db->chains[i] != NULL, "NULL chain at index %d", i);
-        seqs[i] = reinterpret_cast<const uint8_t*>(chainGetCodes(db->chains[i]));
-        lens[i] = (uint32_t)chainGetLength(db->chains[i]);
-        db->residues += lens[i];
+        db->residues += chainGetLength(db->chains[i]);
     }
-    // one resident replica per card: queries are split across the cards (the reference hands its `cards` list through
-    // chainDatabaseCreate and alignDatabase for the same purpose, database_alignment.cpp:80-86)
-    for (int card : db->cards) {
-        s4g_db* rep = NULL;
-        int rc = s4g_db_create_scattered(&rep, card, seqs.data(), lens.data(), (uint32_t)databaseLen);
-        if (rc != S4G_OK)
-            SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", card, s4g_last_error());
-        db->replicas.push_back(rep);
+    // The chains stay where they are; which device form the database takes is decided by the first call that uses it
+    // (swimpl::packed_replica / cached_replica).  A database too large for the cached form is packed right away: the caller
+    // expects the upload to happen here (and a missing GPU to be reported here).
+    if (!swimpl::cached_form_fits(db)) {
+        // one resident replica per card: queries are split across the cards (the reference hands its `cards` list through
+        // chainDatabaseCreate and alignDatabase for the same purpose, database_alignment.cpp:80-86)
+        for (size_t slot = 0; slot < db->cards.size(); ++slot) (void)swimpl::packed_replica(db, (int)slot);
+    } else {
+        int n = 0;
+        if (s4g_device_count(&n) != S4G_OK || n <= db->device)
+            SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->device, s4g_last_error());
     }
-    db->dev = db->replicas[0];
     return db;
 }
+
+namespace swimpl {
+
+// the cached form: up to this many chains (a per-query candidate list is <= 5000, main.cpp:69) and only where it is wanted
+static const bool g_chain_cache_on = getenv("S4G_NO_CHAIN_CACHE") == NULL;
+bool cached_form_fits(const ChainDatabase* db) { return g_chain_cache_on && db->length > 0 && db->length <= 32768; }
+
+s4g_db* packed_replica(ChainDatabase* db, int slot) {
+    if (db->replicas[slot]) return db->replicas[slot];
+    Phase ph(0);
+    std::vector<const uint8_t*> seqs((size_t)db->length);
+    std::vector<uint32_t> lens((size_t)db->length);
+    for (int i = 0; i < db->length; ++i) {
+        seqs[i] = reinterpret_cast<const uint8_t*>(chainGetCodes(db->chains[i]));
+        lens[i] = (uint32_t)chainGetLength(db->chains[i]);
+    }
+    s4g_db* rep = NULL;
+    int rc = s4g_db_create_scattered(&rep, db->cards[slot], seqs.data(), lens.data(), (uint32_t)db->length);
+    if (rc != S4G_OK)
+        SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->cards[slot], s4g_last_error());
+    db->replicas[slot] = rep;
+    return rep;
+}
+
+// Two tables into the first card's chain arena: chains the device holds already are not sent again (their Chain objects say
+// where they are), the others are appended to the arena.  Serves s4g_score_pairs_host / s4g_traceback_host only.
+s4g_db* cached_replica(ChainDatabase* db) {
+    if (db->cached) return db->cached;
+    Phase ph(0);
+    const size_t n = (size_t)db->length;
+    std::vector<const uint8_t*> seqs(n);
+    std::vector<uint32_t> lens(n);
+    std::vector<uint64_t> tags(n), addrs(n);
+    for (size_t i = 0; i < n; ++i) {
+        Chain* c = db->chains[i];
+        seqs[i] = reinterpret_cast<const uint8_t*>(chainGetCodes(c));
+        lens[i] = (uint32_t)chainGetLength(c);
+        tags[i] = c->dev_tag; addrs[i] = c->dev_addr;
+    }
+    s4g_db* rep = NULL;
+    int rc = s4g_db_create_cached(&rep, db->cards[0], seqs.data(), lens.data(), tags.data(), addrs.data(), (uint32_t)n);
+    if (rc != S4G_OK)
+        SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->cards[0], s4g_last_error());
+    for (size_t i = 0; i < n; ++i) { db->chains[i]->dev_tag = tags[i]; db->chains[i]->dev_addr = addrs[i]; }
+    db->cached = rep;
+    return rep;
+}
+
+}  // namespace swimpl
 
 SW_API void chainDatabaseDelete(ChainDatabase* db) {
     if (!db) return;
     Phase ph(6);
-    for (s4g_db* rep : db->replicas) s4g_db_destroy(rep);
+    for (s4g_db* rep : db->replicas) if (rep) s4g_db_destroy(rep);
+    if (db->cached) s4g_db_destroy(db->cached);
     delete db;
 }
 
@@ -363,8 +410,12 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
     DbAlignment**** dbAlignments = &dbAlignments_base;
     int** dbAlignmentsLens = &dbAlignmentsLens_base;
     const int device = cdb->cards[card_slot];
-    s4g_db* ddb = cdb->replicas[card_slot];
     if (queriesLen == 0) return;
+    // One or a few queries against a few thousand chains -- the reference wrapper's per-query call,
+    // database_alignment.cpp:70-92 -- run one wave per pair on chains the device mostly holds already (cached_replica: nothing
+    // is packed or sent twice); anything larger takes the packed database and the scan kernels.
+    const bool use_cached = card_slot == 0 && queriesLen <= 4 && swimpl::cached_form_fits(cdb);
+    s4g_db* ddb = use_cached ? swimpl::cached_replica(cdb) : swimpl::packed_replica(cdb, card_slot);
 
     std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
     flatten(queries, queriesLen, qcodes, qoff);
@@ -400,7 +451,12 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
     // with a subset the library scores just those (query, target) pairs (one wave per pair, or a scan + column pick when
     // the subset approaches the whole database: s4g_score_pairs_host decides); rows are then `subset`-indexed
     std::vector<uint32_t> sub_q, sub_t;
-    if (!subset.empty()) {
+    if (use_cached && subset.empty()) {          // the cached form scores explicit pairs: every chain of the database
+        subset.resize((size_t)cdb->length);
+        for (int i = 0; i < cdb->length; ++i) subset[i] = i;
+    }
+    const bool explicit_pairs = !subset.empty();
+    if (explicit_pairs) {
         sub_t.resize((size_t)batch * subset.size());
         sub_q.resize(sub_t.size());
         for (uint32_t i = 0; i < batch; ++i)
@@ -427,7 +483,8 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
         for (uint32_t i = 0; i < cnt; ++i) {
             sel[i] = {queries[b + i], targets, n_targets, scores.data() + (size_t)i * row_len, &subset, maxAlignments,
                       valueFunction, valueFunctionParam, valueThreshold, {}};
-            tasks[i] = threadPoolSubmit(select_task, &sel[i]);
+            // (a single query selects on this thread: its value function -- eValues -- may then fan out over the pool itself)
+            if (cnt == 1) { tasks[i] = NULL; select_task(&sel[i]); } else tasks[i] = threadPoolSubmit(select_task, &sel[i]);
         }
         std::vector<std::vector<Survivor>> keep(cnt);
         for (uint32_t i = 0; i < cnt; ++i) {
@@ -486,7 +543,7 @@ static void candidates_on_card(DbAlignment*** out_all, int* out_lens, Chain** al
     const int queriesLen = q1 - q0;
     if (queriesLen <= 0) return;
     const int device = cdb->cards[card_slot];
-    s4g_db* ddb = cdb->replicas[card_slot];
+    s4g_db* ddb = swimpl::packed_replica(cdb, card_slot);
     std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
     flatten(queries, queriesLen, qcodes, qoff);
     s4g_queries* dq = NULL;
@@ -627,7 +684,7 @@ static void shotgun_evalues_on_card(DbAlignment*** out_all, int* out_lens, Chain
     const int nq = q1 - q0;
     if (nq == 0) return;
     const int device = cdb->cards[card_slot];
-    s4g_db* ddb = cdb->replicas[card_slot];
+    s4g_db* ddb = swimpl::packed_replica(cdb, card_slot);
     std::vector<uint8_t> qcodes; std::vector<uint64_t> qoff;
     flatten(queries, nq, qcodes, qoff);
     s4g_queries* dq = NULL;

@@ -591,7 +591,10 @@ void run_task(ThreadPoolTask* t) {
     pthread_mutex_unlock(&t->mu);
 }
 
+thread_local bool t_pool_worker = false;
+
 void* pool_worker(void*) {
+    t_pool_worker = true;
     for (;;) {
         pthread_mutex_lock(&g_pool_mu);
         while (g_queue.empty() && !g_pool_stop) pthread_cond_wait(&g_pool_cv, &g_pool_mu);
@@ -603,6 +606,11 @@ void* pool_worker(void*) {
     }
 }
 }  // namespace
+
+// true on a thread of the pool: a task must not wait there for sub-tasks it submits (a pool whose workers all did would
+// stand still), so library code that fans work out checks this first
+bool swimpl::on_pool_thread() { return t_pool_worker; }
+int swimpl::pool_threads() { pthread_mutex_lock(&g_pool_mu); const int n = g_pool_stop ? 0 : (int)g_workers.size(); pthread_mutex_unlock(&g_pool_mu); return n; }
 
 SW_API int threadPoolInitialize(int n) {
     pthread_mutex_lock(&g_pool_mu);

@@ -22,6 +22,7 @@
 //   * "blast": existence = open - extend, the statistically consistent reading of the same table: 10/1 gets (9, 1),
 //     lambda 0.206, K 0.010 -- e-values about 40 times larger at a score of 100.  Round 1 did this.
 //   S4G_EVALUE_CONVENTION=blast|swsharp selects (read when the parameters are created).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -238,17 +239,34 @@ static double spouge_evalue(const ScoreTerms& t, int n, const EValueParams* p) {
 
 static double spouge_evalue(int score, int m, int n, const EValueParams* p) { return spouge_evalue(score_terms(score, m, p), n, p); }
 
-SW_API void eValues(double* values, int* scores, Chain* query, Chain** database, int databaseLen,
-                    int* cards, int cardsLen, EValueParams* p) {
-    (void)cards; (void)cardsLen;   // double-precision host math on <= a few thousand scores: not worth a launch, and
-                                   // device erfc/exp would differ from glibc by ULPs (SURVEY.md section 7 hard parts)
-    const int m = chainGetLength(query);
+static void evalues_range(double* values, const int* scores, int m, Chain** database, int begin, int end, const EValueParams* p) {
     std::vector<ScoreTerms> memo;           // by score; most of a candidate list shares a few dozen small scores
-    for (int i = 0; i < databaseLen; ++i) {
+    for (int i = begin; i < end; ++i) {
         const int sc = scores[i];
         if (sc < 0 || sc > (1 << 20)) { values[i] = spouge_evalue(sc, m, chainGetLength(database[i]), p); continue; }
         if ((size_t)sc >= memo.size()) memo.resize((size_t)sc + 1);
         if (!memo[sc].set) memo[sc] = score_terms(sc, m, p);
         values[i] = spouge_evalue(memo[sc], chainGetLength(database[i]), p);
     }
+}
+
+SW_API void eValues(double* values, int* scores, Chain* query, Chain** database, int databaseLen,
+                    int* cards, int cardsLen, EValueParams* p) {
+    (void)cards; (void)cardsLen;   // double-precision host math on <= a few thousand scores: not worth a launch, and
+                                   // device erfc/exp would differ from glibc by ULPs (SURVEY.md section 7 hard parts)
+    const int m = chainGetLength(query);
+    // A few thousand values are a quarter of a millisecond of erfc / exp -- as much as the device takes to score them -- and
+    // every value depends on its own (score, length) only: slices go to the thread pool, unless this IS a pool thread.
+    const int workers = swimpl::on_pool_thread() ? 0 : std::min(swimpl::pool_threads(), 8);
+    if (workers < 2 || databaseLen < 1024) { evalues_range(values, scores, m, database, 0, databaseLen, p); return; }
+    struct Slice { double* values; const int* scores; int m; Chain** database; int begin, end; const EValueParams* p; };
+    const int parts = std::min(workers, databaseLen / 384);
+    std::vector<Slice> slices((size_t)parts);
+    std::vector<ThreadPoolTask*> tasks((size_t)parts, (ThreadPoolTask*)NULL);
+    for (int k = 0; k < parts; ++k) {
+        slices[k] = {values, scores, m, database, (int)((long long)databaseLen * k / parts), (int)((long long)databaseLen * (k + 1) / parts), p};
+        if (k) tasks[k] = threadPoolSubmit([](void* x) -> void* { Slice* s = (Slice*)x; evalues_range(s->values, s->scores, s->m, s->database, s->begin, s->end, s->p); return NULL; }, &slices[k]);
+    }
+    evalues_range(values, scores, m, database, slices[0].begin, slices[0].end, p);
+    for (int k = 1; k < parts; ++k) { threadPoolTaskWait(tasks[k]); threadPoolTaskDelete(tasks[k]); }
 }

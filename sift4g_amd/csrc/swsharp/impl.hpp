@@ -43,6 +43,9 @@ struct Chain {
     bool embedded;           // this Chain object lives inside its ChainData's block (the chain the block was made for)
     char* rev_chars;         // materialised only for reverse views
     char* rev_codes;
+    // where this chain's residues live on a device, if it has been sent there (s4g_db_create_cached keeps these up to date;
+    // zero = never sent).  A chain is a candidate of many queries: the wrapper's per-query chainDatabaseCreate finds it here.
+    uint64_t dev_tag, dev_addr;
 };
 
 struct Scorer {
@@ -59,10 +62,14 @@ struct ChainDatabase {
     Chain** chains;          // borrowed: database + databaseStart
     int length;
     int device;              // first card
-    s4g_db* dev;             // replica on the first card
     long long residues;
     std::vector<int> cards;          // every card the database was created for (--cards 0123...; main.cpp:254-262)
-    std::vector<s4g_db*> replicas;   // one resident copy per card; replicas[0] == dev
+    // Device forms, made when a call first needs them (swimpl::packed_replica / cached_replica, align.cpp):
+    //   replicas[slot]  the packed, length-sorted tiles the scan / list kernels read -- one resident copy per card;
+    //   cached          two tables into the device's chain arena (s4g_db_create_cached), first card only: what a call with one
+    //                   or a few queries runs on (one wave per pair), without sending the chains again.
+    std::vector<s4g_db*> replicas;
+    s4g_db* cached;
 };
 
 struct DbAlignment {
@@ -95,6 +102,14 @@ struct PairResult {
 };
 // Host Smith-Waterman with traceback (the "traceback of the <= maxAlignments survivors" stage).
 void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc, PairResult* out);
+
+bool on_pool_thread();             // core.cpp: the calling thread is a worker of the thread pool
+int pool_threads();                // workers of the pool (0: none, tasks run inline)
+
+// device forms of a ChainDatabase, made on first use (align.cpp)
+bool cached_form_fits(const ChainDatabase* db);
+s4g_db* packed_replica(ChainDatabase* db, int slot);
+s4g_db* cached_replica(ChainDatabase* db);
 
 inline Scorer* scorer_retain(Scorer* s) { if (s) s->refs.fetch_add(1, std::memory_order_relaxed); return s; }
 void scorer_release(Scorer* s);    // core.cpp: destroys the scorer with its last reference

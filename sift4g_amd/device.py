@@ -124,6 +124,26 @@ class Database(_SeqSet):
         return self
 
     @classmethod
+    def from_cached(cls, seqs, tags, addrs, device=0):
+        """seqs: list of uint8 code arrays; tags / addrs: uint64 arrays the caller keeps WITH the sequences (zero for a sequence
+        the device has not seen; updated in place).  s4g_db_create_cached: every sequence goes to the device once; the database
+        serves score_pairs / score_lists / traceback (one wave per pair) only."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in seqs]
+        ptrs = (ctypes.c_void_p * max(len(arrs), 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = np.array([a.size for a in arrs], dtype=np.uint32)
+        assert tags.dtype == np.uint64 and addrs.dtype == np.uint64 and len(tags) == len(arrs) == len(addrs)
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.device = device
+        check(lib.s4g_db_create_cached(ctypes.byref(self._h), device, ptrs, _ptr(lens, c_u32p), _ptr(tags, c_u64p), _ptr(addrs, c_u64p),
+                                       len(arrs)), "s4g_db_create_cached")
+        self.n = len(arrs)
+        self.codes = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8)
+        self.offsets = np.concatenate([[0], np.cumsum(lens, dtype=np.uint64)]).astype(np.uint64)
+        self.lengths = lens.astype(np.int64)
+        return self
+
+    @classmethod
     def from_device(cls, codes, offsets, tile_seqs=0):
         """codes: torch uint8 tensor on the GPU (one byte per residue, sequences back to back); offsets: torch int64 tensor
         [n+1] on the same GPU.  Only the offsets travel to the host; the codes are packed where they are."""
@@ -191,6 +211,13 @@ def scan_stats(device=0):
     check(lib.s4g_scan_stats(device, _ptr(out, c_u64p), 8), "s4g_scan_stats")
     return dict(tier_drift=int(out[0]), tier_m3=int(out[1]), tier_i16=int(out[2]), tier_i32=int(out[3]),
                 speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]), list_pairs=int(out[7]))
+
+
+def chain_cache_info(device=0):
+    out = np.zeros(7, dtype=np.uint64)
+    check(lib.s4g_chain_cache_info(device, _ptr(out, c_u64p), 7), "s4g_chain_cache_info")
+    return dict(chains=int(out[0]), bytes=int(out[1]), hits=int(out[2]), misses=int(out[3]), generation=int(out[4]),
+                databases=int(out[5]), alive=int(out[6]))
 
 
 def scan_clock(device=0):

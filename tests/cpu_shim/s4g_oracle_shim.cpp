@@ -73,6 +73,10 @@ API int s4g_db_create_scattered(s4g_db** out, int, const uint8_t* const* seqs, c
     for (uint32_t i = 0; i < n; ++i) { codes.insert(codes.end(), seqs[i], seqs[i] + lens[i]); off.push_back(codes.size()); }
     return make(out, codes.data(), off.data(), n);
 }
+API int s4g_db_create_cached(s4g_db** out, int dev, const uint8_t* const* seqs, const uint32_t* lens, uint64_t* tags, uint64_t* addrs, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) { tags[i] = 64; addrs[i] = 1; }       // (nothing is cached here: every call copies the chains)
+    return s4g_db_create_scattered(out, dev, seqs, lens, n);
+}
 API int s4g_db_destroy(s4g_db* db) { delete db; return S4G_OK; }
 API int s4g_queries_create(s4g_queries** out, int, const uint8_t* codes, const uint64_t* offsets, uint32_t n) { return make(out, codes, offsets, n); }
 API int s4g_queries_destroy(s4g_queries* q) { delete q; return S4G_OK; }

@@ -895,6 +895,58 @@ def test_database_from_separate_arrays(s4g, oracle_mod, blosum62, scorer):
         s4g.Database.from_arrays(bad)
 
 
+def test_candidate_databases_out_of_cached_chains(s4g, oracle_mod, blosum62, scorer):
+    """s4g_db_create_cached (what libswsharp's per-query chainDatabaseCreate turns into): overlapping candidate lists out of
+    one pool of chains -- every chain is sent once (the cache words the caller keeps with a chain say where it lives), scores
+    and alignments equal the oracle's, long / empty / single-residue chains included; the scan entry points refuse such a
+    database, a bad residue code is refused and leaves the words untouched."""
+    from sift4g_amd import device as s4gd
+    MOVE = {0: 1, 1: 2, 2: 3}
+    rng = np.random.default_rng(77)
+    pool = rand_seqs(rng, 600, 1, 700, 26) + [rand_seqs(rng, 1, 5000, 5000, 26)[0], np.zeros(0, np.uint8), rand_seqs(rng, 1, 1, 1, 26)[0]]
+    qs = rand_seqs(rng, 3, 60, 400, 26) + [rand_seqs(rng, 1, 1300, 1300, 26)[0]]
+    pool[7] = np.concatenate([qs[1][:150], qs[1][160:]])
+    pool[600] = np.concatenate([pool[600][:2000], qs[3], pool[600][2000:3700]])        # a banded query inside the long chain
+    q = s4g.QuerySet(qs)
+    tags, addrs = np.zeros(len(pool), np.uint64), np.zeros(len(pool), np.uint64)
+    before = s4gd.chain_cache_info(0)
+    seen = set()
+    for it in range(6):
+        ids = np.sort(rng.choice(len(pool), size=250, replace=False))
+        if it == 0:
+            ids = np.union1d(ids, [7, 600, 601, 602])
+        t, a = tags[ids].copy(), addrs[ids].copy()
+        db = s4g.Database.from_cached([pool[i] for i in ids], t, a)
+        assert np.all(t != 0) and np.all(a[[len(pool[i]) > 0 for i in ids]] != 0)
+        assert np.array_equal(t[tags[ids] != 0], tags[ids][tags[ids] != 0]) and np.array_equal(a[tags[ids] != 0], addrs[ids][tags[ids] != 0])
+        tags[ids], addrs[ids] = t, a
+        info = s4gd.chain_cache_info(0)
+        new = len(set(ids.tolist()) - seen)
+        seen |= set(ids.tolist())
+        assert info["misses"] - before["misses"] == len(seen) and info["alive"] == before["alive"] + 1, (info, before, new)
+        pq = np.repeat(np.arange(len(qs), dtype=np.uint32), len(ids))
+        pt = np.tile(np.arange(len(ids), dtype=np.uint32), len(qs))
+        got = s4g.score_pairs(db, q, scorer, pq, pt).reshape(len(qs), len(ids))
+        exp = oracle_mod.scan(qs, [pool[i] for i in ids], blosum62, 10, 1, threads=8)
+        assert np.array_equal(got, exp), it
+        assert np.array_equal(s4g.score_pairs(db, q, scorer, pq, pt, route="lists").reshape(len(qs), len(ids)), exp)     # (forced back to waves)
+        top = np.argsort(-exp, axis=1)[:, :6]
+        tq = np.repeat(np.arange(len(qs)), 6); tt = top.ravel()
+        for r, a_, b_ in zip(s4g.traceback(db, q, scorer, tq, tt, exp[tq, tt], route="scan"), tq, tt):
+            o = oracle_mod.sw_align(qs[a_], pool[ids[b_]], blosum62, 10, 1)
+            assert r["score"] == o["score"] and r["path"].tolist() == [MOVE[m] for m in o["path"]], (it, a_, b_)
+        with pytest.raises(RuntimeError):
+            s4g.scan_host(db, q, scorer)
+        db.close()
+    assert s4gd.chain_cache_info(0)["alive"] == before["alive"]
+    bad = [pool[3].copy(), pool[4].copy()]
+    bad[1][0] = 26
+    t, a = np.zeros(2, np.uint64), np.zeros(2, np.uint64)
+    with pytest.raises(RuntimeError):
+        s4g.Database.from_cached(bad, t, a)
+    assert not t.any() and not a.any()
+
+
 def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
     """Queries whose score BOUND is beyond the drifting-frame window (here 2048 .. 5000 residues) still run in sw_scan_pkd,
     speculatively: results that come near the window's end are marked by the kernel and recomputed in int32 by
