@@ -295,7 +295,15 @@ int s4g_clock_probe(int device, double* out, uint32_t cap);
  * A handle is used by one thread at a time; an error other than S4G_ERR_INVALID on an argument leaves its lists undefined
  * (destroy it).  Residue codes may be any 5-bit value (0..31); the 134 MB index at k = 5 is sized for that.
  *   s4g_prefilter_stats    out[0] = k-mer hits looked up so far, out[1] = (query, target) pairs with at least one hit,
- *                          out[2] = of those, pairs whose LIS ran on a whole wave (more than 32 hits), out[3] = chunks. cap >= 4. */
+ *                          out[2] = of those, pairs whose LIS ran on a whole wave (more than 32 hits), out[3] = chunks. cap >= 4.
+ *                          With cap >= 7 also: out[4] = 1 if the handle runs the fused path (one wave per target keeps its hits in
+ *                          LDS: sort by query, LIS and candidate there; lists merged per query in LDS), 0 for the general path
+ *                          (every pass through HBM: max_candidates beyond what a block sorts in LDS, more than 2^22 queries, or
+ *                          S4G_PREFILTER_GLOBAL_SORT=1), out[5] = targets the fused path handed to the general passes (more than
+ *                          1024 hits), out[6] = chunks it ran twice (the first run found more candidates than it had room for).
+ * Limits: n_queries x max_candidates <= 2^30; one chunk may produce at most 2^31 - 64 hits per pass (the general path cuts a chunk
+ * into passes) and 2^31 - 64 candidates; s4g_prefilter_add_device reads d_codes / d_offsets on the handle's own stream: they
+ * must be complete when it is called (it checks the offsets on the device: ascending, targets of at most 0x7FFFFFF0 residues). */
 typedef struct s4g_prefilter s4g_prefilter;
 int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t* codes, const uint64_t* offsets, uint32_t n_queries,
                          uint32_t kmer_length, uint32_t max_candidates);

@@ -15,6 +15,18 @@
 //                      -> candidate (query, ~score bits | target id), score = LIS / (float) target length (:228-229)
 //   (radix sort by (query, score descending), stable over ascending target id) + pf_keep -> best max_candidates per query
 //
+// Round 3 -- the fused path (the default; the passes above remain as the general path for targets with more hits than a wave
+// keeps in LDS, for max_candidates beyond what a block sorts in LDS, and behind S4G_PREFILTER_GLOBAL_SORT=1):
+//
+//   pf_target_lis      one wave per target does ALL of the above for it: bucket sizes, the hits into LDS in the reference's order,
+//                      a wave-wide bitonic sort of (query, order) keys -- the hits of a target are a few dozen to a few hundred --
+//                      segment starts by ballot, the LIS of every segment (a lane per short one, the whole wave per long one, tails
+//                      in LDS) and one (query, ~score | id) candidate per segment appended to a global array.  Hits never touch HBM.
+//   (radix sort of the candidates by query: 10 bits of key)
+//   pf_merge_lists     one block per query: its running list and its new candidates in LDS, the cut found by a radix select, the
+//                      best max_candidates kept (unordered)
+//   pf_finish_rows     one block per query: its list by ascending id -> the rows the caller gets
+//
 // HBM-bound integer work: no MFMA anywhere; what matters is coalesced target reads (a wave walks one target), the random
 // 8-byte bucket lookups (32^5 slots = 134 MB: MALL-resident, not L2) and the radix sorts (rocPRIM).
 #pragma once
@@ -63,11 +75,13 @@ __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t
 
 // hits of the CSR index from the sorted (k-mer, g) pairs: hit_q / hit_p[i] = query / position of the i-th smallest
 __global__ void pf_hash_hits(const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ pos_q,
-                             const uint32_t* __restrict__ pos_j, uint64_t n_hits, uint32_t* __restrict__ hit_q, uint32_t* __restrict__ hit_p) {
+                             const uint32_t* __restrict__ pos_j, uint64_t n_hits, uint32_t* __restrict__ hit_q, uint32_t* __restrict__ hit_p,
+                             uint64_t* __restrict__ hit_qp) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint32_t g = sorted_val[i];
     hit_q[i] = pos_q[g]; hit_p[i] = pos_j[g];
+    hit_qp[i] = ((uint64_t)pos_j[g] << 32) | pos_q[g];
 }
 
 struct PfChunk {
@@ -78,8 +92,11 @@ struct PfChunk {
                                 // instead of a random 64-byte fetch from the 134 MB of `starts`)
     const uint32_t* hit_q;      // bucket contents
     const uint32_t* hit_p;
+    const uint64_t* hit_qp;     // the same, interleaved: position << 32 | query (one load per hit in the fused path)
     uint32_t k, nt;
+    const uint32_t* tlist;      // optional: the targets to work on are tlist[0 .. nt) (the fused path's overflow); NULL: 0 .. nt
 };
+__device__ __forceinline__ uint32_t pf_target(const PfChunk& a, uint32_t i) { return a.tlist ? a.tlist[i] : i; }
 
 // number of hits the k-mer at position j of a target contributes, and where its bucket starts
 __device__ __forceinline__ uint32_t pf_bucket(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t j, uint32_t n_kmers, uint32_t* first) {
@@ -105,8 +122,9 @@ __global__ __launch_bounds__(256) void pf_target_count(PfChunk a, uint64_t* __re
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < a.nt; t += waves) {
-        const uint64_t o = a.off[t];
-        const uint32_t len = (uint32_t)(a.off[t + 1] - o);
+        const uint32_t tt = pf_target(a, t);
+        const uint64_t o = a.off[tt];
+        const uint32_t len = (uint32_t)(a.off[tt + 1] - o);
         const uint8_t* c = a.codes + o;
         const uint32_t n_kmers = len >= a.k ? len - a.k + 1 : 0;
         uint64_t sum = 0;
@@ -129,8 +147,9 @@ __global__ __launch_bounds__(256) void pf_target_emit(PfChunk a, uint32_t t0, ui
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t t = t0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); t < t1; t += waves) {
-        const uint64_t o = a.off[t];
-        const uint32_t len = (uint32_t)(a.off[t + 1] - o);
+        const uint32_t tt = pf_target(a, t);
+        const uint64_t o = a.off[tt];
+        const uint32_t len = (uint32_t)(a.off[tt + 1] - o);
         const uint8_t* c = a.codes + o;
         const uint32_t n_kmers = len >= a.k ? len - a.k + 1 : 0;
         uint64_t out = hit_off[t] - base_off;
@@ -164,11 +183,13 @@ struct PfLisArgs {
     unsigned* long_count;
     int32_t* tails;             // global fallback of pf_lis_long: n_hits + n_seg entries
     const uint32_t* q_kmers;    // [nq] k-mers of each query: bounds the LIS
+    const uint32_t* tlist;      // as PfChunk::tlist
 };
 
 __device__ __forceinline__ void pf_candidate(const PfLisArgs& a, uint32_t s, uint32_t lis) {
     const uint64_t k = a.seg_key[s];
-    const uint32_t t = a.t0 + (uint32_t)(k >> a.q_bits);
+    const uint32_t ti = a.t0 + (uint32_t)(k >> a.q_bits);
+    const uint32_t t = a.tlist ? a.tlist[ti] : ti;
     const uint32_t q = (uint32_t)(k & ((1ull << a.q_bits) - 1));
     const float score = __fdiv_rn((float)(int32_t)lis, (float)(uint32_t)(a.off[t + 1] - a.off[t]));   // database_search.cpp:228-229
     a.cand_key[s] = ((uint64_t)q << 32) | (uint32_t)~__float_as_uint(score);
@@ -251,6 +272,453 @@ __global__ __launch_bounds__(64) void pf_lis_long(PfLisArgs a) {
         }
         pf_candidate(a, s, len);                                         // every lane writes the same words
     }
+}
+
+// =====================================================================================================================
+// The fused path.
+constexpr uint32_t kPfCap = 512;                // hits a wave groups in LDS at a time (6 KB per wave: 6 waves per SIMD)
+constexpr uint32_t kPfOrderBits = 9;            // log2(kPfCap): a sort key is query << kPfOrderBits | position in the reference's order
+constexpr uint32_t kPfMaxLong = 16;             // long segments (more than kPfSmallMax hits) kPfCap hits can hold
+constexpr uint32_t kPfRanges = 64;              // a target with more hits is walked once per RANGE OF QUERIES: histogram of its hits over
+                                                // kPfRanges equal slices of the query indices, slices grouped into passes of <= kPfCap hits
+
+constexpr uint32_t kPfRegions = 64;            // the candidate array is cut into this many regions, each with a fill counter of its own
+                                                // (a line apart): 100 000 waves reserving slots through ONE counter spent a quarter of the
+                                                // kernel waiting for that atomic
+
+struct PfFused {
+    PfChunk c;
+    uint32_t first_id, nq;
+    uint32_t* cand_q;                   // [kPfRegions * region_cap] out: query (pre-filled with 0xFFFFFFFF: unused slots sort behind every query)
+    uint64_t* cand_sv;                  // [kPfRegions * region_cap] out: ~bits(score) << 32 | database index  (ascending = best first)
+    uint64_t region_cap;
+    unsigned long long* counters;       // [8 * r] candidates of region r (counted even beyond region_cap: the host then repeats the chunk
+                                        // with room); [8 * kPfRegions + 0] hits, [+1] segments of more than kPfSmallMax hits,
+                                        // [+2] targets left to the general path
+    uint32_t* overflow;                 // [nt] those targets: one slice of queries alone has more than kPfCap hits there
+    unsigned* bad;                      // residue code beyond 5 bits seen
+};
+
+// LDS traffic of ONE wave is executed in program order, so what a lane wrote is there for any lane's later read; all this has to do is
+// keep the compiler from moving LDS accesses across it (and wait for the LDS queue: cheap).  A seq_cst fence would also wait for every
+// global store in flight -- the candidates just written -- which is microseconds per target.
+__device__ __forceinline__ void pf_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Buckets of four chunks of 64 positions from `base`: lane l gets those of positions base + 64 u + l (u = 0..3).  One byte per
+// lane and chunk comes from memory, the k-mers are put together from the neighbours' bytes (shuffles), and the dependent rounds of
+// loads -- residues, presence bitmap, bucket bounds, the bucket's first hit -- are each issued for all four chunks before any is
+// waited for.  hq / hp: query and position of the bucket's first hit (most buckets hold exactly one).
+struct PfBlock { uint32_t first[4], n[4], hq[4], hp[4]; };
+__device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t base,
+                                            uint32_t lane, PfBlock& blk, unsigned& wrong) {
+    uint32_t (&first)[4] = blk.first; uint32_t (&n)[4] = blk.n; uint32_t (&hq)[4] = blk.hq; uint32_t (&hp)[4] = blk.hp;
+    uint32_t carry = base ? pf_kmer(c + base - 1, a.k) : 0xFFFFFFFFu;   // the k-mer before this block's first (the "equal to its predecessor" rule)
+    uint32_t b[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const uint32_t j = base + 64 * u + lane; b[u] = (j < len && (u < 4 || lane < 8)) ? c[j] : 0u; }
+    uint32_t v[4];
+    bool look[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (b[u] >= 32) wrong = 1;
+        uint32_t x = 0;
+        for (uint32_t i = 0; i < a.k; ++i) {            // byte of position j + i: lane + i of this chunk, or of the next one
+            const uint32_t src = lane + i;
+            const uint32_t own = (uint32_t)__shfl((int)b[u], (int)(src & 63), 64), nxt = (uint32_t)__shfl((int)b[u + 1], (int)(src & 63), 64);
+            x = (x << kKmerBits) | ((src < 64 ? own : nxt) & 31u);
+        }
+        v[u] = x;
+        uint32_t prev = (uint32_t)__shfl_up((int)x, 1, 64);
+        if (lane == 0) prev = carry;
+        carry = (uint32_t)__shfl((int)x, 63, 64);
+        const uint32_t j = base + 64 * u + lane;
+        look[u] = j < n_kmers && !(j != 0 && prev == x);            // database_search.cpp:212: equal to the k-mer before it
+    }
+    uint32_t bits[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bits[u] = look[u] ? a.present[v[u] >> 5] : 0u;
+    uint32_t s0[4], s1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        look[u] = look[u] && ((bits[u] >> (v[u] & 31)) & 1u);
+        uint64_t se = 0;                                             // starts[v], starts[v + 1]: one 8-byte load (4-byte aligned)
+        if (look[u]) __builtin_memcpy(&se, a.starts + v[u], 8);
+        s0[u] = (uint32_t)se; s1[u] = (uint32_t)(se >> 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { first[u] = s0[u]; n[u] = s1[u] - s0[u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const uint64_t qp = n[u] ? a.hit_qp[first[u]] : 0ull; hq[u] = (uint32_t)qp; hp[u] = (uint32_t)(qp >> 32); }
+}
+
+// One sweep over a target: its hits with a query in [qa, qb) (FILTER) or all of them go into key / pos in the order the reference
+// appends them (by target position, then bucket order) -- as long as they fit: once kPfCap would be passed nothing more is written
+// and only the count goes on.  -> the number of such hits (the same in every lane); *fits = all of them are in LDS.
+template <bool FILTER>
+__device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t lane,
+                                               uint32_t qa, uint32_t qb, uint32_t* key, uint32_t* pos, bool* fits, unsigned& wrong,
+                                               const PfBlock* block0) {      // block0: the buckets of positions 0 .. 255, if the caller has them
+    uint64_t out = 0;
+    bool ok = true;
+    for (uint32_t base = 0; base < n_kmers; base += 256) {
+        PfBlock blk;
+        if (base == 0 && block0) blk = *block0; else pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong);
+        uint32_t (&first)[4] = blk.first; uint32_t (&n)[4] = blk.n; uint32_t (&hq)[4] = blk.hq; uint32_t (&hp)[4] = blk.hp;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t mine_n = n[u];                 // this position's hits inside the query range (a bucket is ordered by query)
+            if (FILTER) { mine_n = 0; for (uint32_t h = 0; h < n[u]; ++h) { const uint32_t q = h ? (uint32_t)c0.hit_qp[first[u] + h] : hq[u]; mine_n += (q >= qa && q < qb); } }
+            uint32_t incl = mine_n;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += up; }
+            const uint32_t chunk = __shfl(incl, 63, 64);
+            ok = ok && out + chunk <= kPfCap;
+            if (ok) {
+                uint32_t w = (uint32_t)out + incl - mine_n;
+                for (uint32_t h = 0; h < n[u]; ++h) {
+                    const uint64_t qp = h ? c0.hit_qp[first[u] + h] : (((uint64_t)hp[u] << 32) | hq[u]);
+                    const uint32_t q = (uint32_t)qp;
+                    if (FILTER && (q < qa || q >= qb)) continue;
+                    key[w] = (q << kPfOrderBits) | w;
+                    pos[w] = (uint32_t)(qp >> 32);
+                    ++w;
+                }
+            }
+            out += chunk;
+        }
+    }
+    *fits = ok;
+    return out;
+}
+
+// The `total` hits in key / pos: sorted by (query, order), cut into segments, the LIS of every segment, one candidate each.
+__device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uint32_t lane, uint32_t region, uint32_t* key, const uint32_t* pos,
+                                           int32_t* tail, uint32_t* lng, float flen, uint32_t id, unsigned long long& sum_long) {
+    uint32_t m = 64;                                         // sort size: a power of two >= total
+    while (m < total) m <<= 1;
+    for (uint32_t i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
+    pf_lds_fence();
+    // ---- bitonic sort of the keys: grouped by query, the reference's order inside a query ----
+    for (uint32_t size = 2; size <= m; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = lane; i < m / 2; i += 64) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t x = key[lo], y = key[hi];
+                if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+            }
+            pf_lds_fence();
+        }
+    // ---- segments = runs of one query; count them, reserve their candidates with one atomic on the wave's region ----
+    uint32_t n_seg = 0;
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + lane;
+        const bool start = i < total && (i == 0 || (key[i] >> kPfOrderBits) != (key[i - 1] >> kPfOrderBits));
+        n_seg += (uint32_t)__popcll(__ballot(start));
+    }
+    unsigned long long slot0 = 0;
+    if (lane == 0) { slot0 = atomicAdd(&a.counters[8 * region], (unsigned long long)n_seg); lng[0] = 0; }
+    slot0 = ((unsigned long long)(uint32_t)__shfl((int)(slot0 >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)slot0, 0, 64);
+    pf_lds_fence();
+    const uint64_t region_base = (uint64_t)region * a.region_cap;
+    auto emit = [&](uint32_t q, uint32_t lis, unsigned long long slot) {
+        if (slot >= a.region_cap) return;
+        const float score = __fdiv_rn((float)(int32_t)lis, flen);                          // database_search.cpp:228-229
+        a.cand_q[region_base + slot] = q;
+        a.cand_sv[region_base + slot] = ((uint64_t)(uint32_t)~__float_as_uint(score) << 32) | id;
+    };
+    // ---- the LIS of every segment: a lane per segment of up to kPfSmallMax hits ----
+    uint32_t rank0 = 0;
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t q = i < total ? key[i] >> kPfOrderBits : 0xFFFFFFFFu;
+        const bool start = i < total && (i == 0 || q != (key[i - 1] >> kPfOrderBits));
+        const unsigned long long bal = __ballot(start);
+        const uint32_t rank = rank0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        rank0 += (uint32_t)__popcll(bal);
+        if (start) {
+            // length: up to the next segment start -- in this chunk of 64 by the ballot, beyond it by looking
+            const unsigned long long later = lane < 63 ? bal >> (lane + 1) : 0ull;
+            uint32_t n;
+            if (later) n = (uint32_t)__ffsll((long long)later);
+            else { n = min(64u - lane, total - i); while (i + n < total && (key[i + n] >> kPfOrderBits) == q) ++n; }
+            if (n == 1) emit(q, 1, slot0 + rank);
+            else if (n <= 8) {
+                // the hits in registers (independent LDS reads), then the quadratic recurrence without touching LDS again:
+                // L[i] = 1 + max{L[j]: j < i, x[j] < x[i]} -- the same longest strictly increasing run as the tails method finds
+                int32_t x[8];
+                uint32_t L[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = (uint32_t)k < n ? (int32_t)pos[key[i + k] & (kPfCap - 1)] : 0x7FFFFFFF;
+                uint32_t best = 1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t l = 1;
+#pragma unroll
+                    for (int j = 0; j < k; ++j) if (x[j] < x[k] && L[j] + 1 > l) l = L[j] + 1;
+                    L[k] = l;
+                    if ((uint32_t)k < n && l > best) best = l;
+                }
+                emit(q, best, slot0 + rank);
+            } else if (n > kPfSmallMax) {
+                const uint32_t w = atomicAdd(&lng[0], 1u);          // (at most kPfCap / (kPfSmallMax + 1) < kPfMaxLong of them)
+                lng[1 + 3 * w] = i; lng[2 + 3 * w] = n; lng[3 + 3 * w] = rank;
+            } else {
+                int32_t* T = tail + i;                               // T[l] = smallest last element of an increasing run of length l + 1
+                uint32_t best = 0;
+                for (uint32_t k = 0; k < n; ++k) {
+                    const int32_t x = (int32_t)pos[key[i + k] & (kPfCap - 1)];
+                    uint32_t l = 0, u = best;                        // first l in [0, best] with T[l] >= x  (T[best] = +inf)
+                    while (u > l) { const uint32_t mid = (l + u) / 2; if (T[mid] < x) l = mid + 1; else u = mid; }
+                    T[l] = x;
+                    best = l + 1 > best ? l + 1 : best;
+                }
+                emit(q, best, slot0 + rank);
+            }
+        }
+    }
+    pf_lds_fence();
+    // ---- long segments, the whole wave on each.  The tails live in REGISTERS, tail l in lane l % 64 of register l / 64 (eight
+    //      registers: kPfCap tails), unused ones at +infinity: the number of tails below x is eight ballots and their popcounts, the
+    //      update one predicated move -- no LDS round trip inside the dependent chain (with tails in LDS a hit cost ~300 clocks) ----
+    const uint32_t n_long = lng[0];
+    sum_long += n_long;
+    for (uint32_t w = 0; w < n_long; ++w) {
+        const uint32_t i0 = lng[1 + 3 * w], n = lng[2 + 3 * w], rank = lng[3 + 3 * w];
+        int32_t T[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) T[r] = 0x7FFFFFFF;
+        uint32_t llen = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const int32_t xs = base + lane < n ? (int32_t)pos[key[i0 + base + lane] & (kPfCap - 1)] : 0;     // 64 hits of the segment at a time
+            const uint32_t cnt = min(64u, n - base);
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int32_t x = __builtin_amdgcn_readlane(xs, (int)k);
+                uint32_t lo = 0;                                                    // tails below x (positions are distinct, tails ascending)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if ((uint32_t)r * 64 <= llen) lo += (uint32_t)__popcll(__ballot(T[r] < x));
+                const uint32_t reg = lo >> 6;
+                if (lane == (lo & 63)) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (reg == (uint32_t)r) T[r] = x;
+                }
+                llen = max(llen, lo + 1);
+            }
+        }
+        if (lane == 0) emit(key[i0] >> kPfOrderBits, llen, slot0 + rank);
+    }
+    pf_lds_fence();
+}
+
+// One wave per target (grid-stride).  See the header of this file.
+__global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
+    __shared__ uint32_t s_key[4][kPfCap];       // query << 9 | order, sorted in place
+    __shared__ uint32_t s_pos[4][kPfCap];       // query position of the hit with order index i
+    __shared__ int32_t s_tail[4][kPfCap];       // LIS tails: a segment that starts at sorted position i uses [i, i + its length)
+    __shared__ uint32_t s_misc[4][kPfMaxLong * 3 + 1 + kPfRanges];     // [0] count, then (start, length, rank) of long segments; the range histogram
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* key = s_key[wv];
+    uint32_t* pos = s_pos[wv];
+    int32_t* tail = s_tail[wv];
+    uint32_t* lng = s_misc[wv];
+    uint32_t* hist = s_misc[wv] + kPfMaxLong * 3 + 1;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t region = wave_id % kPfRegions;
+    const PfChunk& c0 = a.c;
+    const uint32_t q_per_range = (a.nq + kPfRanges - 1) / kPfRanges;
+    unsigned long long sum_hits = 0, sum_long = 0;
+    unsigned wrong = 0;
+    // The four dependent rounds of loads of a target's first 256 positions are issued BEFORE the previous target's hits are sorted and
+    // walked, so they are there when its turn comes (three targets in four are no longer than that).
+    PfBlock ahead;
+    uint64_t o_next = 0;
+    uint32_t len_next = 0;
+    if (wave_id < c0.nt) {
+        o_next = c0.off[wave_id]; len_next = (uint32_t)(c0.off[wave_id + 1] - o_next);
+        pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong);
+    }
+    for (uint32_t t = wave_id; t < c0.nt; t += waves) {
+        const uint64_t o = o_next;
+        const uint32_t len = len_next;
+        const uint8_t* c = c0.codes + o;
+        const uint32_t n_kmers = len >= c0.k ? len - c0.k + 1 : 0;
+        for (uint32_t j = (n_kmers + 255) / 256 * 256 + lane; j < len; j += 64) if (c[j] >= 32) wrong = 1;      // (the tail the k-mer sweep does not load)
+        const float flen = (float)len;
+        const uint32_t id = a.first_id + t;
+        bool fits = false;
+        const PfBlock mine_block = ahead;
+        const uint64_t total64 = pf_collect<false>(c0, c, len, n_kmers, lane, 0u, 0xFFFFFFFFu, key, pos, &fits, wrong, n_kmers ? &mine_block : nullptr);
+        if (t + waves < c0.nt) {
+            o_next = c0.off[t + waves]; len_next = (uint32_t)(c0.off[t + waves + 1] - o_next);
+            pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong);
+        }
+        if (total64 == 0) continue;
+        sum_hits += total64;
+        if (fits) { pf_process(a, (uint32_t)total64, lane, region, key, pos, tail, lng, flen, id, sum_long); continue; }
+        // ---- more hits than a wave keeps: once per range of queries.  Histogram of the hits over kPfRanges slices of the query
+        //      indices, consecutive slices grouped into passes of at most kPfCap hits ----
+        pf_lds_fence();
+        hist[lane] = 0;
+        pf_lds_fence();
+        for (uint32_t base = 0; base < n_kmers; base += 256) {
+            PfBlock blk;
+            pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (uint32_t h = 0; h < blk.n[u]; ++h) atomicAdd(&hist[(h ? (uint32_t)c0.hit_qp[blk.first[u] + h] : blk.hq[u]) / q_per_range], 1u);
+        }
+        pf_lds_fence();
+        if (__ballot(hist[lane] > kPfCap)) {                            // one slice of queries alone does not fit: the general passes take the target
+            if (lane == 0) a.overflow[atomicAdd(&a.counters[8 * kPfRegions + 2], 1ull)] = t;
+            continue;
+        }
+        for (uint32_t r0 = 0; r0 < kPfRanges;) {
+            uint32_t acc = 0, r1 = r0;                                  // as many slices as fit (uniform: every lane reads the same words)
+            while (r1 < kPfRanges && acc + hist[r1] <= kPfCap) acc += hist[r1++];
+            const uint32_t qa = r0 * q_per_range, qb = r1 * q_per_range;
+            r0 = r1;
+            if (acc == 0) continue;
+            const uint64_t tot = pf_collect<true>(c0, c, len, n_kmers, lane, qa, qb, key, pos, &fits, wrong, nullptr);
+            if (tot) pf_process(a, (uint32_t)tot, lane, region, key, pos, tail, lng, flen, id, sum_long);
+        }
+    }
+    if (lane == 0) {
+        if (sum_hits) atomicAdd(&a.counters[8 * kPfRegions + 0], sum_hits);
+        if (sum_long) atomicAdd(&a.counters[8 * kPfRegions + 1], sum_long);
+    }
+    if (wrong) atomicOr(a.bad, 1u);
+}
+
+// candidates of the general path (key = query << 32 | ~score, value = id) appended to the fused path's arrays
+__global__ void pf_append(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t n, uint32_t* __restrict__ cand_q,
+                          uint64_t* __restrict__ cand_sv, uint64_t at, uint64_t cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || at + i >= cap) return;
+    cand_q[at + i] = (uint32_t)(key[i] >> 32);
+    cand_sv[at + i] = (key[i] << 32) | val[i];
+}
+
+// bitonic sort of n (a power of two) 64-bit keys in LDS by the whole block, ascending
+__device__ __forceinline__ void pf_block_sort(uint64_t* keys, uint32_t n) {
+    for (uint32_t size = 2; size <= n; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+// The want-th smallest of the n distinct 64-bit keys in LDS (1 <= want <= n): a radix select, most significant byte first -- per
+// round a 256-bin histogram of the keys that still match the bytes decided so far picks the bin the want-th smallest lies in.
+// Whole block; hist: 256 words, ctl: 2 words of LDS.
+__device__ __forceinline__ uint64_t pf_block_kth(const uint64_t* keys, uint32_t n, uint32_t want, uint32_t* hist, uint32_t* ctl) {
+    uint64_t prefix = 0;                         // the bytes of the answer decided so far
+    uint32_t remaining = want;                   // its rank among the keys that match them (1-based)
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t k = keys[i];
+            if (shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0, bin = 0;
+            for (; bin < 255; ++bin) { if (acc + hist[bin] >= remaining) break; acc += hist[bin]; }
+            ctl[0] = bin; ctl[1] = remaining - acc;
+        }
+        __syncthreads();
+        prefix |= (uint64_t)ctl[0] << shift;
+        remaining = ctl[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// One block per query: list[q] (list_cnt[q] entries, any order) and its new candidates sv[first[q] .. first[q + 1]) -> the best
+// max_c of them (smallest keys: score descending, ties to the lower database index -- database_search.cpp:129-150,
+// include/s4g_hip.h), in no particular order: s4g_prefilter_finish orders a list when it is asked for.  cap = 64-bit keys the
+// block's LDS holds; the new candidates go through it in slices of cap - max_c.  A selection, not a sort: the cut is found by a
+// radix select in LDS and the survivors go straight back to the list.
+__global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ list, uint32_t* __restrict__ list_cnt, uint32_t max_c,
+                                                      const uint64_t* __restrict__ sv, const uint32_t* __restrict__ first, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t pf_keys[];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    const uint32_t q = blockIdx.x;
+    const uint32_t b = first[q], e = first[q + 1];
+    if (b == e) return;
+    uint64_t* mine = list + (uint64_t)q * max_c;
+    uint32_t cur = list_cnt[q];
+    for (uint32_t at = b; at < e;) {
+        const uint32_t take = min(e - at, cap - cur);
+        const uint32_t n = cur + take;
+        if (n <= max_c) {                        // everything is kept: append
+            for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) mine[cur + i] = sv[at + i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < cur; i += blockDim.x) pf_keys[i] = mine[i];
+            for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) pf_keys[cur + i] = sv[at + i];
+            __syncthreads();
+            const uint64_t kth = pf_block_kth(pf_keys, n, max_c, s_hist, s_ctl);
+            if (threadIdx.x == 0) s_ctl[2] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint64_t k = pf_keys[i];
+                if (k <= kth) mine[atomicAdd(&s_ctl[2], 1u)] = k;          // the keys are distinct: exactly max_c of them pass
+            }
+        }
+        __syncthreads();                          // (the list just written is read back by the next slice)
+        cur = min(n, max_c);
+        at += take;
+    }
+    if (threadIdx.x == 0) list_cnt[q] = cur;
+}
+
+// first[q] = index of the first candidate of query q in the query-sorted array (first[nq] = n): one thread per candidate boundary
+__global__ void pf_bucket_first(const uint32_t* __restrict__ sorted_q, uint32_t n, uint32_t nq, uint32_t* __restrict__ first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    // queries prev .. cur start at i (those between the query at i - 1 and the one at i have no candidate); entries of a query >= nq
+    // are the unused slots of the candidate regions, sorted behind everything
+    const uint32_t prev = i == 0 ? 0u : min(sorted_q[i - 1], nq) + 1;
+    const uint32_t cur = i == n ? nq : min(sorted_q[i], nq);
+    for (uint32_t q = prev; q <= cur; ++q) first[q] = i;
+}
+
+// One block per query: its list by ascending database index -> a row of ids and scores, and the count (database_search.cpp:166-178)
+__global__ __launch_bounds__(512) void pf_finish_rows(const uint64_t* __restrict__ list, const uint32_t* __restrict__ list_cnt, uint32_t max_c,
+                                                      uint32_t* __restrict__ ids, float* __restrict__ scores, uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t pf_keys[];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = list_cnt[q];
+    const uint64_t* mine = list + (uint64_t)q * max_c;
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        uint64_t k = ~0ull;
+        if (i < n) { const uint64_t v = mine[i]; k = (v << 32) | (uint32_t)~(uint32_t)(v >> 32); }       // id << 32 | bits(score)
+        pf_keys[i] = k;
+    }
+    __syncthreads();
+    pf_block_sort(pf_keys, m);
+    for (uint32_t i = threadIdx.x; i < max_c; i += blockDim.x) {
+        const bool ok = i < n;
+        ids[(uint64_t)q * max_c + i] = ok ? (uint32_t)(pf_keys[i] >> 32) : 0u;
+        scores[(uint64_t)q * max_c + i] = ok ? __uint_as_float((uint32_t)pf_keys[i]) : 0.0f;
+    }
+    if (threadIdx.x == 0) counts[q] = n;
+}
+
+// offsets handed over in device memory are checked where they are: ascending, no target beyond 0x7FFFFFF0 residues
+__global__ void pf_check_offsets(const uint64_t* __restrict__ off, uint32_t nt, unsigned* __restrict__ bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nt && (off[t + 1] < off[t] || off[t + 1] - off[t] > 0x7FFFFFF0ull)) atomicOr(bad, 2u);
 }
 
 // Running lists: slots [q * max .. (q + 1) * max) of list_key / list_val, empty = kPfNoEntry.

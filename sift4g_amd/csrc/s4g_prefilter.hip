@@ -34,6 +34,7 @@ struct s4g_prefilter {
     uint32_t* d_present = nullptr;  // [n_slots / 32 + 1] bitmap of the k-mers any query holds
     uint32_t* d_hit_q = nullptr;
     uint32_t* d_hit_p = nullptr;
+    uint64_t* d_hit_qp = nullptr;   // interleaved (position << 32 | query): what the fused path reads
     uint32_t* d_q_kmers = nullptr;
     uint64_t n_hash_hits = 0;
     uint64_t* d_list_key = nullptr; // [nq * max_c] running lists: query << 32 | ~bits(score); kPfNoEntry = empty
@@ -49,6 +50,12 @@ struct s4g_prefilter {
     uint32_t last_first_id = 0, last_n = 0;
     bool any_chunk = false;
     uint64_t stat_hits = 0, stat_pairs = 0, stat_long = 0, stat_chunks = 0;
+    // the fused path (kmer_prefilter.hip.h): lists = nq rows of max_c keys ~score << 32 | id, ascending, d_list_cnt entries used
+    bool fused = false;
+    uint32_t lds_keys = 0;          // 64-bit keys a block of pf_merge_lists sorts in LDS
+    uint32_t* d_list_cnt = nullptr;
+    uint64_t cand_guess = 0;        // candidates the last chunk produced (sizes the next chunk's arrays)
+    uint64_t stat_overflow = 0, stat_repeats = 0;
 };
 
 namespace {
@@ -99,6 +106,7 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     HIP_TRY(hipMemcpyAsync(p->d_q_kmers, q_kmers.data(), q_kmers.size() * 4, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc((void**)&p->d_hit_q, std::max<uint64_t>(1, p->n_hash_hits) * 4));
     HIP_TRY(hipMalloc((void**)&p->d_hit_p, std::max<uint64_t>(1, p->n_hash_hits) * 4));
+    HIP_TRY(hipMalloc((void**)&p->d_hit_qp, std::max<uint64_t>(1, p->n_hash_hits) * 8));
     DevBuf<uint32_t> count;                              // [n_slots + 1]: bucket sizes, then scanned into d_starts
     HIP_TRY(count.alloc(p->n_slots + 1));
     HIP_TRY(hipMemsetAsync(count.p, 0, (p->n_slots + 1) * 4, p->stream));
@@ -121,7 +129,7 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
         if (p->n_hash_hits)
             hipLaunchKernelGGL(s4g::pf_hash_hits, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, val2.p, pos_q.p, pos_j.p,
-                               p->n_hash_hits, p->d_hit_q, p->d_hit_p);
+                               p->n_hash_hits, p->d_hit_q, p->d_hit_p, p->d_hit_qp);
     }
     size_t t = std::max(cub_scan, cub_sort);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, count.p, p->d_starts, (int)(p->n_slots + 1), p->stream));
@@ -145,15 +153,16 @@ int merge_candidates(s4g_prefilter* p, uint64_t* cand_key, uint32_t* cand_val, u
     return S4G_OK;
 }
 
-int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id) {
-    if (p->any_chunk && first_id < p->last_first_id + p->last_n)
-        return fail(S4G_ERR_INVALID, "prefilter: chunks must arrive in ascending id order (ties at the cut go to the lower index)");
-    p->any_chunk = true; p->last_first_id = first_id; p->last_n = nt;
-    ++p->stat_chunks;
-    if (!nt || !p->nq) return S4G_OK;
+int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint64_t n);
+int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes);
+
+// The general path: every pass through HBM.  tlist == NULL: targets 0 .. nt of the chunk, the whole prefilter in this form
+// (handles with fused == false).  tlist != NULL (device array of nt target indices): the targets the fused path left over; their
+// candidates are merged into the fused path's lists.
+int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, const uint32_t* tlist) {
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->k, nt};
+    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, tlist};
 
     // ---- pass 0: hits per target, their offsets, down to the host (which cuts the chunk into passes) ----
     size_t cub_scan = 0;
@@ -176,7 +185,7 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
     if (p->h_flags[0]) return fail(S4G_ERR_INVALID, "prefilter: database residue code out of range (5-bit codes, hash.cpp:16-17)");
     std::vector<uint64_t> hit_off((const uint64_t*)p->h_stage, (const uint64_t*)p->h_stage + nt + 1);
     const uint64_t chunk_hits = hit_off[nt];
-    p->stat_hits += chunk_hits;
+    if (!tlist) p->stat_hits += chunk_hits;           // (the fused path has counted the hits of the targets it hands over)
     const auto t_counted = Clock::now();
     if (!chunk_hits) return S4G_OK;
 
@@ -203,7 +212,8 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
         if (cand_cap > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidate slots exceed what one sort takes", (unsigned long long)cand_cap);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_cand, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
                                                    (uint32_t*)nullptr, (int)cand_cap, 0, (int)(32 + p->list_q_bits), p->stream));
-        const uint64_t b_cub = align256(std::max(std::max(cub_sort, cub_rle), std::max(cub_scan32, cub_cand)));
+        uint64_t b_cub = align256(std::max(std::max(cub_sort, cub_rle), std::max(cub_scan32, cub_cand)));
+        if (p->fused) { uint64_t fb = 0; S4G_TRY(merge_fused_bytes(p, H, &fb)); b_cub = std::max(b_cub, fb); }
         const uint64_t need = 2 * b_cnt + 2 * align256(H * 8) + 2 * align256(H * 4)            // hit keys / values, in and out
                             + align256(H * 8) + 3 * align256(H * 4)                              // segments: key, length, offset, long list
                             + align256((2 * H + 1) * 4)                                          // tails of the long segments
@@ -239,15 +249,24 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
         t = b_cub;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, t, seg_len, seg_off, (int)n_seg, p->stream));
         HIP_TRY(hipMemsetAsync(p->d_flags + 1, 0, 8, p->stream));
-        HIP_TRY(hipMemcpyAsync(cand_key, p->d_list_key, slots * 8, hipMemcpyDeviceToDevice, p->stream));
-        HIP_TRY(hipMemcpyAsync(cand_val, p->d_list_val, slots * 4, hipMemcpyDeviceToDevice, p->stream));
+        if (!p->fused) {
+            HIP_TRY(hipMemcpyAsync(cand_key, p->d_list_key, slots * 8, hipMemcpyDeviceToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(cand_val, p->d_list_val, slots * 4, hipMemcpyDeviceToDevice, p->stream));
+        }
         s4g::PfLisArgs la{seg_key, seg_len, seg_off, p->d_flags + 3, val_out, d_off, t0, first_id, p->q_bits,
-                          cand_key + slots, cand_val + slots, long_list, p->d_flags + 1, tails, p->d_q_kmers};
+                          cand_key + slots, cand_val + slots, long_list, p->d_flags + 1, tails, p->d_q_kmers, tlist};
         hipLaunchKernelGGL(s4g::pf_lis_small, dim3((unsigned)std::min<uint64_t>(((uint64_t)n_seg + 255) / 256, 8192)), dim3(256), 0, p->stream, la);
         hipLaunchKernelGGL(s4g::pf_lis_long, dim3(p->grid_waves), dim3(64), 0, p->stream, la);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(p->h_flags + 1, p->d_flags + 1, 4, hipMemcpyDeviceToHost, p->stream));
-        S4G_TRY(merge_candidates(p, cand_key, cand_val, cand_key2, cand_val2, first, cub, b_cub, slots + n_seg));
+        if (!p->fused) S4G_TRY(merge_candidates(p, cand_key, cand_val, cand_key2, cand_val2, first, cub, b_cub, slots + n_seg));
+        else if (n_seg) {
+            // the new candidates in the fused path's form (into the second candidate array, free in this mode), then its merge
+            uint32_t* fq = cand_val2;
+            uint64_t* fsv = cand_key2;
+            hipLaunchKernelGGL(s4g::pf_append, dim3((n_seg + 255) / 256), dim3(256), 0, p->stream, cand_key + slots, cand_val + slots, n_seg, fq, fsv, (uint64_t)0, (uint64_t)n_seg);
+            S4G_TRY(merge_fused(p, (char*)cub, b_cub, fq, fsv, n_seg));
+        }
         HIP_TRY(hipStreamSynchronize(p->stream));
         chunk_pairs += n_seg; chunk_long += p->h_flags[1];
         t0 = t1;
@@ -258,6 +277,123 @@ int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, u
                 nt, first_id, (unsigned long long)chunk_hits, (unsigned long long)chunk_pairs, (unsigned long long)chunk_long, passes,
                 passes == 1 ? "" : "es", us(t_begin, t_counted), us(t_counted, Clock::now()));
     return S4G_OK;
+}
+
+
+// ---- the fused path ----
+// scratch of one merge: the candidates sorted by query (q2, sv2), first[nq + 1], the sort's own temporary storage
+int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes) {
+    size_t cub = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr,
+                                               (uint64_t*)nullptr, (int)std::max<uint64_t>(n, 1), 0, (int)p->q_bits + 1, p->stream));
+    *bytes = align256(n * 4) + align256(n * 8) + align256(((uint64_t)p->nq + 1) * 4) + align256(cub) + 1024;
+    return S4G_OK;
+}
+
+// n candidates (query, ~score << 32 | id), any order -> into the running lists: one radix sort by query (q_bits bits of key),
+// then one block per query sorts its list and its new candidates in LDS and keeps the best max_c.  Asynchronous on p->stream.
+int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint64_t n) {
+    if (!n) return S4G_OK;
+    if (n > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidates in one merge", (unsigned long long)n);
+    uint64_t need = 0;
+    S4G_TRY(merge_fused_bytes(p, n, &need));
+    if (arena_bytes < need) return fail(S4G_ERR_INVALID, "prefilter: internal error: merge scratch of %llu bytes, %llu needed", (unsigned long long)arena_bytes, (unsigned long long)need);
+    Arena A{arena};
+    uint32_t* q2 = A.take<uint32_t>(n);
+    uint64_t* sv2 = A.take<uint64_t>(n);
+    uint32_t* first = A.take<uint32_t>((uint64_t)p->nq + 1);
+    size_t cub = arena_bytes - A.at;
+    // (q_bits + 1 bits of key: the unused slots of the candidate regions hold 0xFFFFFFFF and sort behind every query)
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(arena + A.at, cub, cand_q, q2, cand_sv, sv2, (int)n, 0, (int)p->q_bits + 1, p->stream));
+    hipLaunchKernelGGL(s4g::pf_bucket_first, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, p->stream, q2, (uint32_t)n, p->nq, first);
+    // LDS of a block: the smallest power of two that leaves a quarter of it to a slice of new candidates (5000 -> 8192 keys = 64 KB:
+    // two blocks per CU)
+    uint32_t keys = 1024;
+    while (keys < p->lds_keys && (uint64_t)p->max_c * 4 > (uint64_t)keys * 3) keys *= 2;
+    hipLaunchKernelGGL(s4g::pf_merge_lists, dim3(p->nq), dim3(512), (size_t)keys * 8, p->stream, p->d_list_key, p->d_list_cnt, p->max_c, sv2, first, keys);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, uint64_t residues) {
+    const bool profile = getenv("S4G_PROFILE") != nullptr;
+    const auto t_begin = Clock::now();
+    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, nullptr};
+    constexpr uint32_t R = s4g::kPfRegions;
+    constexpr uint64_t kCounterWords = 8 * R + 8;
+    unsigned long long counters[kCounterWords];
+    unsigned long long n_cand = 0, n_hits = 0, n_long = 0, n_over = 0;
+    uint32_t* overflow = nullptr;
+    S4G_TRY(ensure_stage(p, 16384));
+    for (int attempt = 0;; ++attempt) {
+        // Candidates: one per (target, query) pair with a hit -- about one per five residues at k = 5 against a thousand queries.  The
+        // array is cut into regions with a fill counter each (kmer_prefilter.hip.h); the kernel counts every candidate even when its
+        // region is full, and the chunk is then repeated with room for the fullest region.
+        const uint64_t region_cap = std::max<uint64_t>(std::max<uint64_t>(p->cand_guess + p->cand_guess / 4 + 256, residues / (3 * R)), 1024);
+        const uint64_t cand_cap = region_cap * R;
+        if (cand_cap > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidates in one chunk: hand the database over in smaller chunks", (unsigned long long)cand_cap);
+        uint64_t merge_bytes = 0;
+        S4G_TRY(merge_fused_bytes(p, cand_cap, &merge_bytes));
+        const uint64_t need = align256(kCounterWords * 8) + align256((uint64_t)nt * 4) + align256(cand_cap * 4) + align256(cand_cap * 8) + merge_bytes;
+        S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+        Arena A{p->d_work};
+        unsigned long long* d_counters = A.take<unsigned long long>(kCounterWords);
+        overflow = A.take<uint32_t>(nt);
+        uint32_t* cand_q = A.take<uint32_t>(cand_cap);
+        uint64_t* cand_sv = A.take<uint64_t>(cand_cap);
+        char* scratch = p->d_work + A.at;
+        HIP_TRY(hipMemsetAsync(d_counters, 0, kCounterWords * 8, p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_flags, 0, 16, p->stream));
+        HIP_TRY(hipMemsetAsync(cand_q, 0xFF, cand_cap * 4, p->stream));         // unused slots: a query index behind every real one
+        s4g::PfFused f{c, first_id, p->nq, cand_q, cand_sv, region_cap, d_counters, overflow, p->d_flags};
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nt + 3) / 4, p->grid_waves / 4);
+        hipLaunchKernelGGL(s4g::pf_target_lis, dim3(grid), dim3(256), 0, p->stream, f);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(p->h_stage, d_counters, kCounterWords * 8, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (p->h_flags[0]) return fail(S4G_ERR_INVALID, "prefilter: database residue code out of range (5-bit codes, hash.cpp:16-17)");
+        memcpy(counters, p->h_stage, kCounterWords * 8);
+        unsigned long long fullest = 0;
+        n_cand = 0;
+        for (uint32_t r = 0; r < R; ++r) { fullest = std::max(fullest, counters[8 * r]); n_cand += counters[8 * r]; }
+        n_hits = counters[8 * R]; n_long = counters[8 * R + 1]; n_over = counters[8 * R + 2];
+        p->cand_guess = fullest;
+        if (fullest > region_cap) {
+            if (attempt) return fail(S4G_ERR_HIP, "prefilter: internal error: candidate count changed between two runs of a chunk");
+            ++p->stat_repeats;
+            continue;
+        }
+        S4G_TRY(merge_fused(p, scratch, p->work_cap - A.at, cand_q, cand_sv, cand_cap));
+        break;
+    }
+    p->stat_hits += n_hits; p->stat_pairs += n_cand; p->stat_long += n_long; p->stat_overflow += n_over;
+    const auto t_fused = Clock::now();
+    if (n_over) {
+        // targets where a single slice of the query range has more hits than a wave keeps in LDS: through the general passes, as a
+        // list (the indices move out of the arena first; ascending, so that the general path's per-target keys follow the database order)
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        std::vector<uint32_t> h(n_over);
+        HIP_TRY(hipMemcpy(h.data(), overflow, h.size() * 4, hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        DevBuf<uint32_t> tlist;
+        HIP_TRY(tlist.upload(h));
+        S4G_TRY(add_chunk_general(p, d_codes, d_off, (uint32_t)n_over, first_id, tlist.p));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    if (profile)
+        fprintf(stderr, "[s4g profile] prefilter chunk (fused): %u targets from %u, %llu hits, %llu pairs (%llu on a wave), %llu targets through the general passes: "
+                        "target kernel + sync %.0f us, rest %.0f us\n", nt, first_id, n_hits, n_cand, n_long, n_over, us(t_begin, t_fused), us(t_fused, Clock::now()));
+    return S4G_OK;
+}
+
+int add_chunk(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, uint64_t residues) {
+    if (p->any_chunk && first_id < p->last_first_id + p->last_n)
+        return fail(S4G_ERR_INVALID, "prefilter: chunks must arrive in ascending id order (ties at the cut go to the lower index)");
+    p->any_chunk = true; p->last_first_id = first_id; p->last_n = nt;
+    ++p->stat_chunks;
+    if (!nt || !p->nq) return S4G_OK;
+    return p->fused ? add_chunk_fused(p, d_codes, d_off, nt, first_id, residues) : add_chunk_general(p, d_codes, d_off, nt, first_id, nullptr);
 }
 
 }  // namespace
@@ -304,10 +440,24 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
         HIP_TRY(hipHostMalloc((void**)&p->h_flags, 64, hipHostMallocDefault));
         HIP_TRY(hipMemsetAsync(p->d_flags, 0, 64, p->stream));
         const uint64_t slots = std::max<uint64_t>(1, (uint64_t)n_queries * max_candidates);
+        // The fused path (kmer_prefilter.hip.h) wherever it applies: a query index must fit a 32-bit sort key beside 10 bits of order,
+        // and a query's list plus a slice of new candidates must fit the LDS a block may have (64-bit keys: half of them the list).
+        int lds_bytes = 0;
+        HIP_TRY(hipDeviceGetAttribute(&lds_bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        p->lds_keys = 1024;
+        while (p->lds_keys < 16384 && (uint64_t)p->lds_keys * 2 * 8 <= (uint64_t)lds_bytes) p->lds_keys *= 2;
+        p->fused = getenv("S4G_PREFILTER_GLOBAL_SORT") == nullptr && p->q_bits + s4g::kPfOrderBits <= 32 && max_candidates <= p->lds_keys / 2;
         HIP_TRY(hipMalloc((void**)&p->d_list_key, slots * 8));
-        HIP_TRY(hipMalloc((void**)&p->d_list_val, slots * 4));
-        hipLaunchKernelGGL(s4g::pf_fill, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, p->stream, p->d_list_key, slots);
-        HIP_TRY(hipGetLastError());
+        if (p->fused) {
+            HIP_TRY(hipMalloc((void**)&p->d_list_cnt, (uint64_t)std::max(1u, n_queries) * 4));
+            HIP_TRY(hipMemsetAsync(p->d_list_cnt, 0, (uint64_t)std::max(1u, n_queries) * 4, p->stream));
+            HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_merge_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->lds_keys * 8)));
+            HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_finish_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->lds_keys * 8)));
+        } else {
+            HIP_TRY(hipMalloc((void**)&p->d_list_val, slots * 4));
+            hipLaunchKernelGGL(s4g::pf_fill, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, p->stream, p->d_list_key, slots);
+            HIP_TRY(hipGetLastError());
+        }
         return build_index(p, codes, offsets);
     };
     const int rc = body();
@@ -320,14 +470,26 @@ S4G_API int s4g_prefilter_add_device(s4g_prefilter* p, const uint8_t* d_codes, c
     if (!p || (n_targets && (!d_codes || !d_offsets))) return fail(S4G_ERR_INVALID, "NULL argument");
     if ((uint64_t)first_id + n_targets > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "prefilter: database index beyond 32 bits");
     DeviceGuard guard(p->device);
-    return add_chunk(p, d_codes, d_offsets, n_targets, first_id);
+    if (!n_targets) return add_chunk(p, nullptr, nullptr, 0, first_id, 0);
+    // the offsets are checked where they are (ascending, no target beyond 0x7FFFFFF0 residues); their two ends come to the host
+    S4G_TRY(ensure_stage(p, 4096));
+    HIP_TRY(hipMemsetAsync(p->d_flags, 0, 16, p->stream));
+    hipLaunchKernelGGL(s4g::pf_check_offsets, dim3((n_targets + 255) / 256), dim3(256), 0, p->stream, d_offsets, n_targets, p->d_flags);
+    HIP_TRY(hipGetLastError());
+    uint64_t* ends = (uint64_t*)p->h_stage;
+    HIP_TRY(hipMemcpyAsync(ends, d_offsets, 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(ends + 1, d_offsets + n_targets, 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->h_flags[0] & 2u) return fail(S4G_ERR_INVALID, "prefilter: device offsets are not ascending (or a target is longer than 0x7FFFFFF0 residues)");
+    return add_chunk(p, d_codes, d_offsets, n_targets, first_id, ends[1] - ends[0]);
 }
 
 S4G_API int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint64_t* offsets, uint32_t n_targets, uint32_t first_id) {
     if (!p || (n_targets && (!codes || !offsets))) return fail(S4G_ERR_INVALID, "NULL argument");
     if ((uint64_t)first_id + n_targets > 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "prefilter: database index beyond 32 bits");
     DeviceGuard guard(p->device);
-    if (!n_targets) return add_chunk(p, nullptr, nullptr, 0, first_id);
+    if (!n_targets) return add_chunk(p, nullptr, nullptr, 0, first_id, 0);
     for (uint32_t t = 0; t < n_targets; ++t)
         if (offsets[t + 1] < offsets[t] || offsets[t + 1] - offsets[t] > 0x7FFFFFF0ull) return fail(S4G_ERR_INVALID, "bad offsets at %u", t);
     const uint64_t residues = offsets[n_targets] - offsets[0];
@@ -343,7 +505,54 @@ S4G_API int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint
     HIP_TRY(hipMemcpyAsync(p->d_off, h_off, b_off, hipMemcpyHostToDevice, p->stream));
     if (residues) HIP_TRY(hipMemcpyAsync(p->d_codes, h_codes, residues, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));            // the staging buffer is reused for the offsets coming back down
-    return add_chunk(p, p->d_codes, p->d_off, n_targets, first_id);
+    return add_chunk(p, p->d_codes, p->d_off, n_targets, first_id, residues);
+}
+
+// Rows to the host through the pinned staging buffer, piece by piece: the copy of a piece into the caller's (pageable) memory runs
+// on the worker pool underneath the transfer of the next one.  (Straight into pageable memory the runtime stages the 60 MB of a
+// thousand queries itself, single-threaded: 5.5 ms.)
+static int rows_to_host(s4g_prefilter* p, const void* d_src, void* h_dst, uint64_t bytes) {
+    const uint64_t piece = 8ull << 20;
+    S4G_TRY(ensure_stage(p, 2 * piece));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const uint64_t n = (bytes + piece - 1) / piece;
+    int rc = S4G_OK;
+    for (uint64_t k = 0; k <= n && rc == S4G_OK; ++k) {
+        if (k < n) {
+            const uint64_t b = std::min(piece, bytes - k * piece);
+            if (hipMemcpyAsync(p->h_stage + (k & 1) * piece, (const char*)d_src + k * piece, b, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+                hipEventRecord(ev[k & 1], p->stream) != hipSuccess) rc = fail(S4G_ERR_HIP, "prefilter: download failed");
+        }
+        if (k > 0 && rc == S4G_OK) {
+            const uint64_t j = k - 1, b = std::min(piece, bytes - j * piece);
+            if (hipEventSynchronize(ev[j & 1]) != hipSuccess) { rc = fail(S4G_ERR_HIP, "prefilter: download failed"); break; }
+            const char* src = p->h_stage + (j & 1) * piece;
+            char* dst = (char*)h_dst + j * piece;
+            parallel_for(b, parallel_parts(b, 1u << 20), [&](unsigned, unsigned, uint64_t x, uint64_t y) { memcpy(dst + x, src + x, y - x); });
+        }
+    }
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    return rc;
+}
+
+static int finish_fused(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores) {
+    const uint64_t slots = (uint64_t)p->nq * p->max_c;
+    const uint64_t need = 2 * align256(slots * 4) + align256((uint64_t)p->nq * 4);
+    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+    Arena A{p->d_work};
+    uint32_t* ids = A.take<uint32_t>(slots); float* scores = A.take<float>(slots);
+    uint32_t* counts = A.take<uint32_t>(p->nq);
+    uint32_t m = 2;
+    while (m < p->max_c) m <<= 1;
+    hipLaunchKernelGGL(s4g::pf_finish_rows, dim3(p->nq), dim3(512), (size_t)m * 8, p->stream, p->d_list_key, p->d_list_cnt, p->max_c, ids, scores, counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_counts, counts, (uint64_t)p->nq * 4, hipMemcpyDeviceToHost, p->stream));
+    S4G_TRY(rows_to_host(p, ids, h_ids, slots * 4));
+    if (h_scores) S4G_TRY(rows_to_host(p, scores, h_scores, slots * 4));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return S4G_OK;
 }
 
 S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores) {
@@ -351,6 +560,7 @@ S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_
     if (!p->nq) return S4G_OK;
     DeviceGuard guard(p->device);
     const uint64_t slots = (uint64_t)p->nq * p->max_c;
+    if (p->fused) return finish_fused(p, h_ids, h_counts, h_scores);
     size_t cub_sort = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
                                                (uint32_t*)nullptr, (int)slots, 0, (int)(32 + p->list_q_bits), p->stream));
@@ -372,9 +582,9 @@ S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_
     hipLaunchKernelGGL(s4g::pf_query_first, g, b, 0, p->stream, key2, slots, p->nq, first);
     hipLaunchKernelGGL(s4g::pf_rows, g, b, 0, p->stream, key2, val2, slots, p->nq, p->max_c, first, ids, scores, counts);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_ids, ids, slots * 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(h_counts, counts, (uint64_t)p->nq * 4, hipMemcpyDeviceToHost, p->stream));
-    if (h_scores) HIP_TRY(hipMemcpyAsync(h_scores, scores, slots * 4, hipMemcpyDeviceToHost, p->stream));
+    S4G_TRY(rows_to_host(p, ids, h_ids, slots * 4));
+    if (h_scores) S4G_TRY(rows_to_host(p, scores, h_scores, slots * 4));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return S4G_OK;
 }
@@ -382,6 +592,7 @@ S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_
 S4G_API int s4g_prefilter_stats(const s4g_prefilter* p, uint64_t* out, uint32_t cap) {
     if (!p || !out || cap < 4) return fail(S4G_ERR_INVALID, "s4g_prefilter_stats: out[4] needed");
     out[0] = p->stat_hits; out[1] = p->stat_pairs; out[2] = p->stat_long; out[3] = p->stat_chunks;
+    if (cap >= 7) { out[4] = p->fused ? 1 : 0; out[5] = p->stat_overflow; out[6] = p->stat_repeats; }
     return S4G_OK;
 }
 
@@ -389,8 +600,8 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     if (!p) return S4G_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_starts); (void)hipFree(p->d_present); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_q_kmers);
-    (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
+    (void)hipFree(p->d_starts); (void)hipFree(p->d_present); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->h_flags) (void)hipHostFree(p->h_flags);

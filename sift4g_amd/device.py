@@ -401,9 +401,10 @@ class Prefilter:
         return ids[: self.nq], counts[: self.nq], scores[: self.nq]
 
     def stats(self):
-        out = np.zeros(4, dtype=np.uint64)
-        check(lib.s4g_prefilter_stats(self._h, _ptr(out, c_u64p), 4), "s4g_prefilter_stats")
-        return dict(hits=int(out[0]), pairs=int(out[1]), long_pairs=int(out[2]), chunks=int(out[3]))
+        out = np.zeros(7, dtype=np.uint64)
+        check(lib.s4g_prefilter_stats(self._h, _ptr(out, c_u64p), 7), "s4g_prefilter_stats")
+        return dict(hits=int(out[0]), pairs=int(out[1]), long_pairs=int(out[2]), chunks=int(out[3]), fused=bool(out[4]),
+                    general_path_targets=int(out[5]), repeated_chunks=int(out[6]))
 
     def close(self):
         if getattr(self, "_h", None) and lib is not None:
