@@ -131,7 +131,9 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
     for _ in range(reps + 1):                          # the first round grows the buffers
         torch.cuda.synchronize()
         t0 = time.perf_counter(); p = s4gd.Prefilter(queries, 5, 5000, device=dev_index); t1 = time.perf_counter()
-        p.add_device(d_codes, d_off, first_id=0); t2 = time.perf_counter()
+        p.add_device(d_codes, d_off, first_id=0)
+        torch.cuda.synchronize()                       # (the merge of a chunk's candidates into the lists runs on behind the call: count it)
+        t2 = time.perf_counter()
         p.finish(); t3 = time.perf_counter()
         stats = p.stats()
         p.close()
@@ -151,8 +153,26 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
     for q in range(nq):
         n = int(min(counts[q], r_counts[q]))
         bad += int((ids[q, :n] != r_ids[q, :n]).sum()) + int((scores[q, :n].view(np.uint32) != r_scores[q, :n].view(np.uint32)).sum())
+    # against the HBM roof: what the stage has to move at the least -- every residue in once, one 12-byte candidate (query, score, id)
+    # out per (query, target) pair with a hit -- over the time of the call; the counter traffic of the same call (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE passes of tools/prefilter_bench.py, profiles/r03_prefilter) rides along
+    alg_bytes = residues + 12.0 * stats["pairs"]
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "prefilter_traffic.json")))
+        if pj.get("residues") == residues and pj.get("queries") == nq:
+            traffic = pj
+    except Exception:
+        traffic = None
+    roof = {"bound": "hbm", "achieved": round(alg_bytes / best["add"] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_bytes / best["add"] / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes,
+            "traffic": traffic["hbm_bytes_per_add"] if traffic else None, "traffic_measured_in_run": False,
+            "traffic_source": traffic["source"] if traffic else None,
+            "note": "integer gather work: the target kernel is bound by vector issue and scattered 4/8-byte lookups (bitmap, bucket bounds, hits), "
+                    "not by streaming; traffic = FETCH_SIZE + WRITE_SIZE of every kernel of one add call"}
     return {"stage": "k-mer prefilter (database_search.cpp:66-253) on the device, database resident in HBM",
-            "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues,
+            "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues, "roofline": roof,
+            "path": "fused" if stats.get("fused") else "general", "general_path_targets": stats.get("general_path_targets"),
             "index_ms": round(best["index"] * 1e3, 3), "add_ms": round(best["add"] * 1e3, 3), "finish_ms": round(best["finish"] * 1e3, 3),
             "residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],
             "check": {"targets": m, "mismatches": bad, "against": "oracle/kmer_prefilter.c (CPU restatement, 1 thread)",

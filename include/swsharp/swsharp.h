@@ -84,6 +84,9 @@ char scorerDecode(char c);
 /* ---- cards (main.cpp:184,186): HIP device ids ---- */
 void cudaGetCards(int** cards, int* cardsLen);                              /* all usable devices; malloc'd */
 int cudaCheckCards(int* cards, int cardsLen);                               /* 1 = ok; passes for 0 cards */
+/* Extension (not in upstream swsharp): the first card of the first successful cudaCheckCards call, 0 before any.  For stages
+ * whose reference signature carries no card list (searchDatabase, database_search.hpp) yet have work for the device. */
+int swsharpPreferredCard(void);
 
 /* ---- ChainDatabase (database_alignment.cpp:80,92): targets packed and resident in HBM ---- */
 ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, int databaseLen, int* cards, int cardsLen);

@@ -60,9 +60,11 @@ double seconds_since(std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
 }
 
+// the card this stage works on: the first one of the user's --cards list (main.cpp validates the list with cudaCheckCards before
+// it calls us; the reference's searchDatabase signature has no card argument), S4G_PREFILTER_DEVICE overrides
 int device_of_choice() {
     const char* v = getenv("S4G_PREFILTER_DEVICE");
-    return v ? atoi(v) : 0;
+    return v ? atoi(v) : swsharpPreferredCard();
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 // Call sites that fix each signature are cited in include/swsharp/swsharp.h.
 #include "impl.hpp"
 
+#include <atomic>
 #include <pthread.h>
 
 #include <cctype>
@@ -558,13 +559,25 @@ SW_API void cudaGetCards(int** cards, int* cardsLen) {
 
 // sift4g calls this once at start-up (main.cpp:186), a few hundred milliseconds of FASTA reading and prefiltering before it
 // aligns anything: the cards it names (card 0 when it names none) start warming up underneath that work (s4g_warmup).
+static std::atomic<int> g_first_card{-1};      // the first card a successful cudaCheckCards was given (-1: none yet)
+
 SW_API int cudaCheckCards(int* cards, int cardsLen) {
     const int ok = s4g_device_check(cards, cardsLen);
     if (ok) {
         if (cardsLen <= 0) (void)s4g_warmup(0);
         for (int i = 0; i < cardsLen; ++i) (void)s4g_warmup(cards[i]);
+        int none = -1;
+        g_first_card.compare_exchange_strong(none, cardsLen > 0 ? cards[0] : 0);
     }
     return ok;
+}
+
+// Extension: the first card the caller validated with cudaCheckCards (main.cpp:183-186 does so with its --cards list before any
+// stage runs), 0 if it never did.  Stages that are not handed a card list -- searchDatabase, database_search.hpp: no `cards`
+// argument -- place their device work there instead of on card 0 whatever the user asked for.
+SW_API int swsharpPreferredCard(void) {
+    const int c = g_first_card.load();
+    return c < 0 ? 0 : c;
 }
 
 // ------------------------------------------------------------------------------------------------ thread pool

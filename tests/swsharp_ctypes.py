@@ -38,6 +38,7 @@ SIG = {
     "scorerGetMaxScore": (ci, [vp]),
     "cudaGetCards": (None, [ctypes.POINTER(pi), pi]),
     "cudaCheckCards": (ci, [pi, ci]),
+    "swsharpPreferredCard": (ci, []),
     "chainDatabaseCreate": (vp, [pvp, ci, ci, pi, ci]),
     "chainDatabaseDelete": (None, [vp]),
     "alignDatabase": (None, [ctypes.POINTER(pvp), pi, ci, vp, vp, vp, ci, ValueFunction, vp, cd, pi, ci, pi, ci, vp]),

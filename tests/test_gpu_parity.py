@@ -184,7 +184,9 @@ def test_drift_frame_window_routing(s4g, oracle_mod, blosum62):
     qs = rand_seqs(rng, 6, 50, 400) + [np.full(1500, W, dtype=np.uint8)]
     ts = rand_seqs(rng, 150, 10, 500) + [rand_seqs(rng, 1, 13000, 13000)[0], np.full(2000, W, dtype=np.uint8),
                                           np.concatenate([qs[0], qs[0], qs[0]])]
-    for go, ge in ((10, 1), (12, 4), (30, 30), (11, 0), (200, 9)):
+    # (the last two: frames of (rows + columns) * ext = 10^7 .. 6 * 10^7 in the int32 drifting kernel, whose guard against leaving
+    # int32 -- half a million residues at ext 4096 -- lets them through)
+    for go, ge in ((10, 1), (12, 4), (30, 30), (11, 0), (200, 9), (3000, 2000), (4096, 4096)):
         sc = s4g.Scorer("BLOSUM_62", go, ge)
         got = _check(s4g, oracle_mod, blosum62, qs, ts, sc, go, ge)
         assert got[6, 151] == 1500 * 11

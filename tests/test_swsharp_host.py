@@ -531,3 +531,15 @@ def test_serialized_database_cache(tmp_path, monkeypatch):
         rec, res = ctypes.c_longlong(-1), ctypes.c_longlong(-1)
         L.fastaResidueCount(str(fa).encode(), ctypes.byref(rec), ctypes.byref(res))
         assert (rec.value, res.value) == (len(parts[0]), want_res), env
+
+
+def test_preferred_card_is_the_first_validated_one():
+    """swsharpPreferredCard (extension): what stages without a card argument -- the device prefilter behind the reference's
+    searchDatabase signature -- place their work on: the first card of the first successful cudaCheckCards, card 0 before any.
+    Without a GPU no check succeeds, so the answer stays 0 here; tests/test_gpu_swsharp.py covers the other side."""
+    from swsharp_ctypes import L
+    assert L.swsharpPreferredCard() == 0
+    import ctypes
+    cards = (ctypes.c_int * 1)(3)
+    if not L.cudaCheckCards(cards, 1):           # card 3 does not exist here: a failed check must not be remembered
+        assert L.swsharpPreferredCard() == 0
