@@ -30,9 +30,12 @@ build/obj/%.o: $(CSRC)/%.hip $(HIPHDR)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(LIBDIR)/libs4g_hip.so: $(HIPOBJ)
+$(LIBDIR)/libs4g_hip.so: $(HIPOBJ) tools/check_denorm.py
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIPOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@.tmp $(HIPOBJ)
+	@# the packed kernels' integer max3 needs f16 denormals preserved: refuse a build whose kernel descriptors say otherwise
+	python3 tools/check_denorm.py $@.tmp || { rm -f $@.tmp; exit 1; }
+	mv $@.tmp $@
 
 $(LIBDIR)/libswsharp.so: $(SWSRC) $(CSRC)/swsharp/impl.hpp $(CSRC)/matrices.h $(CSRC)/swsharp/libswsharp.map include/swsharp/swsharp.h include/swsharp/evalue.h $(LIBDIR)/libs4g_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(SWSRC) -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,--version-script=$(CSRC)/swsharp/libswsharp.map

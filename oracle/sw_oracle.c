@@ -188,12 +188,15 @@ S4G_ORACLE_API int s4g_oracle_sw_align(const uint8_t* q, int lq, const uint8_t* 
     int i = bi, j = bj, n = 0;
     int state = 0; /* 0 = in H, 1 = in E (LEFT run), 2 = in F (UP run) */
     uint8_t* rev = path_out;
+    /* the one tie rule that is a switch (S4G_TRACEBACK_TIES): "left" = LEFT (E) before UP (F) */
+    const char* ties = getenv("S4G_TRACEBACK_TIES");
+    const int left_first = ties && strcmp(ties, "left") == 0;
     while (i > 0 && j > 0) {
         size_t c = i * W + j;
         if (state == 0) {
             if (H[c] == 0) break;
             if (H[c] == H[c - W - 1] + M[26 * q[i - 1] + t[j - 1]]) { rev[n++] = 0; --i; --j; }
-            else if (H[c] == F[c]) state = 2;
+            else if (left_first ? H[c] != E[c] : H[c] == F[c]) state = 2;
             else state = 1;
         } else if (state == 1) {
             rev[n++] = 1;

@@ -150,6 +150,7 @@ struct DeviceCtx {
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
     // clock samples of the scan launches of the last call (s4g_scan_clock; sw_kernels.hip.h clk_enter / clk_leave): a region of
     // 4 counters per block for each of the call's first kClkLaunches launches
+    int max3_state = 0;                  // ensure_max3: 0 not yet checked, 1 the integer-max3-on-f16-patterns argument holds here, -1 it does not
     unsigned long long* d_clk = nullptr;
     uint64_t clk_cap = 0;                // counters allocated
     struct ClkLaunch { uint64_t off; uint32_t blocks; int tier; };
@@ -160,6 +161,14 @@ constexpr int kStatRechecked = 40;      // index into DeviceCtx::d_counter
 constexpr int kListCounter = 44;        // work queue of sw_scan_lists
 
 DeviceCtx* device_ctx(int device);
+
+// S4G_TRACEBACK_TIES (read per call): which gap a cell's H is traced into when the vertical (UP, gap in the target) and the
+// horizontal (LEFT, gap in the query) one give the same value and the diagonal does not.  "up" (default) or "left".  swsharp's own
+// choice is not known here; INTEGRATION.md lists the switch with the other unpinned assumptions.
+inline uint32_t traceback_left_first() {
+    const char* v = getenv("S4G_TRACEBACK_TIES");
+    return v && strcmp(v, "left") == 0 ? 1u : 0u;
+}
 
 struct s4g_queries {
     int device = 0;
@@ -266,6 +275,10 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
 // what made a pairs submission on the side stream serialise the caller behind the side stream's earlier kernels.  Callers have
 // passed scratch_acquire (no launch of another scorer is still reading d_mat).  Caller holds cx->mu.
 int ensure_mat(DeviceCtx* cx, const s4g_scorer* scorer, hipStream_t stream);
+// Before a device's first launch of a kernel that uses v_pk_maximum3_f16 as an integer max3 (sw_scan_pkd, sw_scan_pk<ArithI16M3>,
+// sw_scan_lists): a self-test on denormal-range patterns (denorm_selftest, sw_kernels.hip.h).  Fails the call -- loudly, with the
+// reason -- on a device or build that does not preserve f16 denormals.  Caller holds cx->mu.
+int ensure_max3(DeviceCtx* cx);
 int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count,
                    int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream);
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,

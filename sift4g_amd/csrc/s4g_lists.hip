@@ -234,6 +234,8 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     if (rc) return rc;
     rc = ensure_mat(cx, scorer, stream);
     if (rc) return rc;
+    rc = ensure_max3(cx);
+    if (rc) return rc;
 
     // ---- the long / ineligible pairs start first, on the side stream, as pair waves ----
     static thread_local std::vector<uint32_t> wave_where;

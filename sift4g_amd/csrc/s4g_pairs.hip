@@ -624,6 +624,7 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
         a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
         a.counter = cx->d_counter + 32; a.n_pairs = ni; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        a.left_first = traceback_left_first();
         if (c == kPairClasses) {
             if (cx->grid_pair_trace_band == 0) {
                 int per_cu = 0;

@@ -261,6 +261,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
     if ((uint64_t)n_groups * most >= 0xFFFFFFFFull)
         return fail(S4G_ERR_INVALID, "too many work items in one tile launch; split the query range");
+    if ((w.n_drift || (w.n_m3 && !p.f16_arith))) { const int rc3 = ensure_max3(cx); if (rc3) return rc3; }
     HIP_TRY(hipMemsetAsync(counters, 0, 16, stream));
     // clock samples (s4g_scan_clock): a zeroed region of 4 counters per block for each of the call's first launches
     auto clk_region = [&](uint32_t blocks, int tier) -> unsigned long long* {
@@ -342,6 +343,45 @@ int ensure_mat(DeviceCtx* cx, const s4g_scorer* scorer, hipStream_t stream) {
     HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->mat_ready, stream));
     cx->mat_serial = scorer->serial;
+    return S4G_OK;
+}
+
+// Load-time guard of that argument (ensure_max3 below, before a device's first packed launch): maximum3 on bit patterns of
+// the whole window -- f16 denormals (1 .. 0x3FF: with a bias of 64 most stored values are), normals, the window's top 0x7BFF --
+// must return the integer maximum bit for bit.  A device or build that flushes f16 denormals fails here, loudly, not in the scores.
+__global__ void denorm_selftest(unsigned* __restrict__ bad) {
+    const unsigned lane = threadIdx.x;
+    unsigned mism = 0;
+    for (unsigned round = 0; round < 16; ++round) {
+        const unsigned a = (lane * 37u + round * 61u + 1u) & 0x3FFu;                  // denormal patterns
+        const unsigned b = 0x0400u + ((lane * 257u + round * 1031u) % 0x77FFu);       // 0x0400 .. 0x7BFE
+        const unsigned c = (lane + round) & 1u ? 0x7BFFu - lane : lane;               // the top of the window / next to zero
+        const unsigned x = a | (b << 16), y = b | (c << 16), z = c | (a << 16);
+        const unsigned r = (unsigned)pk_maximum3((int)x, (int)y, (int)z);
+        const unsigned lo = max(max(a, b), c), hi = max(max(b, c), a);
+        if (r != (lo | (hi << 16))) mism = 1;
+        const unsigned r2 = (unsigned)pk_maximum3((int)a, (int)a, (int)(1u | (1u << 16)));   // two denormals against the smallest one
+        if (r2 != (max(a, 1u) | (1u << 16))) mism = 1;
+    }
+    if (mism) atomicOr(bad, 1u);
+}
+
+int ensure_max3(DeviceCtx* cx) {
+    if (cx->max3_state > 0) return S4G_OK;
+    if (cx->max3_state == 0) {
+        if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
+        unsigned* flag = cx->d_counter + 48;
+        unsigned h = 0;
+        HIP_TRY(hipMemcpy(flag, &h, 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(denorm_selftest, dim3(1), dim3(64), 0, nullptr, flag);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(&h, flag, 4, hipMemcpyDeviceToHost));
+        cx->max3_state = h ? -1 : 1;
+    }
+    if (cx->max3_state < 0)
+        return fail(S4G_ERR_HIP, "v_pk_maximum3_f16 does not order integer bit patterns on device %d: f16 denormals are flushed (the library must be built "
+                                 "with FLOAT_DENORM_MODE_16_64 = 3, hipcc's default; tools/check_denorm.py checks a build).  S4G_SCAN_NO_F16 selects the "
+                                 "plain packed int16 kernels, which do not depend on it.", cx->device);
     return S4G_OK;
 }
 

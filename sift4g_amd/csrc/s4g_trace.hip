@@ -150,6 +150,7 @@ int traceback_groups(const s4g_db* db, const s4g_queries* q, const s4g_scorer* s
         a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = d_mat.p;
         a.dirs = d_dirs; a.ws = reinterpret_cast<int32_t*>(A + o_ws); a.ws_slot = ws_slot; a.counter = d_counter.p; a.n_items = ni;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        a.left_first = traceback_left_first();
         a.end_key = reinterpret_cast<uint32_t*>(A + o_end); a.best = reinterpret_cast<int32_t*>(A + o_best);
         hipLaunchKernelGGL(sw_trace_fill, dim3(grid), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());

@@ -432,6 +432,7 @@ struct PairTraceArgs {
     unsigned* counter;
     uint32_t n_pairs;
     uint32_t open, ext;
+    uint32_t left_first;            // ties between the two gap sources of H: 0 = UP (F) before LEFT (E), 1 = LEFT before UP (S4G_TRACEBACK_TIES)
 };
 
 template <int RPL>
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(64) void sw_pair_trace(const PairTraceArgs a) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (h == (int)F ? 2u : 3u));
+                const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (a.left_first ? (h == (int)E[r] ? 3u : 2u) : (h == (int)F ? 2u : 3u)));
                 D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
                 if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
                 best = imax(best, h);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(64) void sw_pair_trace_band(const PairTraceBandArgs
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
                     const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                    const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (h == (int)F ? 2u : 3u));
+                    const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (a.left_first ? (h == (int)E[r] ? 3u : 2u) : (h == (int)F ? 2u : 3u)));
                     D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
                     if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
                     best = imax(best, h);

@@ -39,6 +39,7 @@ struct TraceArgs {
     uint32_t open, ext;
     uint32_t* __restrict__ end_key;             // [items*64] (i << 16 | j) of the end cell, ~0u if none
     int32_t* __restrict__ best;                 // [items*64] recomputed best score (cross-check)
+    uint32_t left_first;                        // ties between the gap sources of H: 0 = UP before LEFT, 1 = LEFT before UP (S4G_TRACEBACK_TIES)
 };
 
 __global__ __launch_bounds__(kBlock, 2) void sw_trace_fill(const TraceArgs a) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kBlock, 2) void sw_trace_fill(const TraceArgs a) {
                         const int sv = (int)(signed char)(w >> (8 * (r % 4)));
                         const int d = diag + sv;
                         const int h = imax(imax(d, (int)E[r]), (int)F);
-                        const unsigned src = h == 0 ? TB_STOP : (h == d ? TB_DIAG : (h == (int)F ? TB_UP : TB_LEFT));
+                        const unsigned src = h == 0 ? TB_STOP : (h == d ? TB_DIAG : (a.left_first ? (h == (int)E[r] ? TB_LEFT : TB_UP) : (h == (int)F ? TB_UP : TB_LEFT)));
                         D[r] |= (src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * cc);
                         if (h == want && h > 0) {
                             const unsigned kcell = ((s * R + r) << 16) | jcol;

@@ -66,6 +66,8 @@ void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc
     out->score = best;
     if (best == 0) return;
     // pass 2: direction bytes on the prefix box [1..bi] x [1..bj] (cell values there equal the full DP's)
+    const char* ties = getenv("S4G_TRACEBACK_TIES");                 // "up" (default) | "left": as the device kernels (s4g_internal.hpp)
+    const bool left_first = ties && strcmp(ties, "left") == 0;
     const size_t W = (size_t)bj + 1;
     std::vector<unsigned char> dir(((size_t)bi + 1) * W, 0);
     std::fill(Hrow.begin(), Hrow.end(), 0);
@@ -80,7 +82,7 @@ void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc
             const int f = imax(Frow[j] - ext, f_open);
             const int d = diag + Mq[(int)t[j - 1]];
             const int h = imax(imax(d, 0), imax(e, f));
-            unsigned char b = h == 0 ? H_STOP : (h == d ? H_DIAG : (h == f ? H_UP : H_LEFT));
+            unsigned char b = h == 0 ? H_STOP : (h == d ? H_DIAG : (left_first ? (h == e ? H_LEFT : H_UP) : (h == f ? H_UP : H_LEFT)));
             if (e == e_open) b |= E_OPENS;
             if (f == f_open) b |= F_OPENS;
             drow[j] = b;
@@ -302,6 +304,23 @@ void* trace_task(void* p) {
 
 }  // namespace
 
+// Order of the survivors: value ascending, then score descending, then -- S4G_SELECTION_TIES -- "index" (default): position in
+// the database ascending; "reverse": descending; "name": chain name ascending (then position).  swsharp's own order among equal
+// values is not known here; with maxAlignments binding it decides which of the tied hits are reported.
+// database[idx] = the chain a survivor's idx names.
+static void sort_survivors(std::vector<Survivor>& keep, Chain** database) {
+    const char* ties = getenv("S4G_SELECTION_TIES");
+    const int mode = !ties || !*ties || strcmp(ties, "index") == 0 ? 0 : strcmp(ties, "reverse") == 0 ? 1 : strcmp(ties, "name") == 0 ? 2 : -1;
+    if (mode < 0) SW_FATAL("S4G_SELECTION_TIES='%s' is not one of index, reverse, name", ties);
+    std::sort(keep.begin(), keep.end(), [&](const Survivor& a, const Survivor& b) {
+        if (a.value != b.value) return a.value < b.value;
+        if (a.score != b.score) return a.score > b.score;
+        if (mode == 1) return a.idx > b.idx;
+        if (mode == 2) { const int c = strcmp(chainGetName(database[a.idx]), chainGetName(database[b.idx])); if (c) return c < 0; }
+        return a.idx < b.idx;
+    });
+}
+
 // steps 2-3: values, threshold, order, cut
 static void select_survivors(std::vector<Survivor>& keep, Chain* query, Chain** database, int databaseLen, const int* scores,
                              int maxAlignments, ValueFunction valueFunction, void* valueFunctionParam, double valueThreshold) {
@@ -316,11 +335,7 @@ static void select_survivors(std::vector<Survivor>& keep, Chain* query, Chain** 
     }
     for (int i = 0; i < databaseLen; ++i)
         if (scores[i] > 0 && (!valueFunction || values[i] <= valueThreshold)) keep.push_back({i, scores[i], values[i]});
-    std::sort(keep.begin(), keep.end(), [](const Survivor& a, const Survivor& b) {
-        if (a.value != b.value) return a.value < b.value;
-        if (a.score != b.score) return a.score > b.score;
-        return a.idx < b.idx;
-    });
+    sort_survivors(keep, database);
     if (maxAlignments >= 0 && (int)keep.size() > maxAlignments) keep.resize(maxAlignments);
 }
 
@@ -736,11 +751,7 @@ static void shotgun_evalues_on_card(DbAlignment*** out_all, int* out_lens, Chain
             std::vector<Survivor>& kp = keep[i];
             for (uint32_t x = 0; x < c; ++x)
                 if (val[x] <= maxEvalue) kp.push_back({(int)ids[(size_t)i * k + x], csc[x], val[x]});
-            std::sort(kp.begin(), kp.end(), [](const Survivor& a, const Survivor& b) {
-                if (a.value != b.value) return a.value < b.value;
-                if (a.score != b.score) return a.score > b.score;
-                return a.idx < b.idx;
-            });
+            sort_survivors(kp, cdb->chains);
             if (maxAlignments >= 0 && (int)kp.size() > maxAlignments) kp.resize(maxAlignments);
             if ((int)c == k) {        // the device list was cut: prove that nothing left out could have made it
                 const double bar = (maxAlignments >= 0 && (int)kp.size() == maxAlignments && !kp.empty()) ? kp.back().value : maxEvalue;

@@ -897,6 +897,48 @@ def test_database_from_separate_arrays(s4g, oracle_mod, blosum62, scorer):
         s4g.Database.from_arrays(bad)
 
 
+def test_traceback_tie_switch_on_the_device(s4g, oracle_mod, blosum62, monkeypatch):
+    """S4G_TRACEBACK_TIES (divergence manifest): pairs whose optimal alignment differs between "UP before LEFT"
+    (default) and "LEFT before UP" -- both device traceback implementations follow the switch exactly as the oracle does."""
+    MOVE = {0: 1, 1: 2, 2: 3}
+    rng = np.random.default_rng(101)
+    pairs = []
+    for _ in range(20000):
+        q = rand_seqs(rng, 1, 6, 40)[0]
+        cut = int(rng.integers(2, len(q) - 2))
+        t = np.concatenate([q[:cut], rand_seqs(rng, 1, 0, 3)[0], q[cut + int(rng.integers(0, 3)):]])
+        if len(t) == 0:
+            continue
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", "up")
+        a = oracle_mod.sw_align(q, t, blosum62, 3, 3)
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", "left")
+        b = oracle_mod.sw_align(q, t, blosum62, 3, 3)
+        if a["score"] > 0 and a["path"].tolist() != b["path"].tolist():
+            pairs.append((q, t))
+            if len(pairs) == 12:
+                break
+    assert len(pairs) >= 6
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    sc = s4g.Scorer("BLOSUM_62", 3, 3)
+    idx = np.arange(len(pairs), dtype=np.uint32)
+    scores = s4g.score_pairs(db, q, sc, idx, idx)
+    differ = 0
+    paths = {}
+    for mode in ("up", "left"):
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", mode)
+        for route in ("wave", "scan"):
+            res = s4g.traceback(db, q, sc, idx, idx, scores, route=route)
+            for k, r in enumerate(res):
+                o = oracle_mod.sw_align(qs[k], ts[k], blosum62, 3, 3)
+                assert r["score"] == o["score"] and r["path"].tolist() == [MOVE[m] for m in o["path"]], (mode, route, k)
+                paths[(mode, route, k)] = r["path"].tolist()
+    for k in range(len(pairs)):
+        differ += paths[("up", "wave", k)] != paths[("left", "wave", k)]
+    assert differ == len(pairs)
+    monkeypatch.delenv("S4G_TRACEBACK_TIES")
+
+
 def test_candidate_databases_out_of_cached_chains(s4g, oracle_mod, blosum62, scorer):
     """s4g_db_create_cached (what libswsharp's per-query chainDatabaseCreate turns into): overlapping candidate lists out of
     one pool of chains -- every chain is sent once (the cache words the caller keeps with a chain say where it lives), scores

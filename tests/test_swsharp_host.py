@@ -543,3 +543,94 @@ def test_preferred_card_is_the_first_validated_one():
     cards = (ctypes.c_int * 1)(3)
     if not L.cudaCheckCards(cards, 1):           # card 3 does not exist here: a failed check must not be remembered
         assert L.swsharpPreferredCard() == 0
+
+
+def _tie_pairs(oracle_mod, blosum62, monkeypatch, want=6):
+    """random small pairs whose optimal alignment differs between the two tie rules (gap source of H: UP first / LEFT first)"""
+    rng = np.random.default_rng(101)
+    found = []
+    for _ in range(20000):
+        q = rand_seqs(rng, 1, 6, 40)[0]
+        cut = int(rng.integers(2, len(q) - 2))
+        t = np.concatenate([q[:cut], rand_seqs(rng, 1, 0, 3)[0], q[cut + int(rng.integers(0, 3)):]])
+        if len(t) == 0:
+            continue
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", "up")
+        a = oracle_mod.sw_align(q, t, blosum62, 3, 3)
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", "left")
+        b = oracle_mod.sw_align(q, t, blosum62, 3, 3)
+        if a["score"] > 0 and a["path"].tolist() != b["path"].tolist():
+            found.append((q, t))
+            if len(found) == want:
+                break
+    monkeypatch.delenv("S4G_TRACEBACK_TIES")
+    return found
+
+
+def test_switches_for_the_unpinned_assumptions(oracle_mod, blosum62, monkeypatch):
+    """INTEGRATION.md's divergence manifest, both ways: S4G_JOU_POLICY (what J, O, U score as), S4G_TRACEBACK_TIES (UP or LEFT first
+    when both gaps explain a cell), S4G_SELECTION_TIES (order of hits with equal value and score)."""
+    from sift4g_amd import device as s4g
+    col = lambda ch: ord(ch) - 65
+    # ---- J / O / U ----
+    base = s4g.matrix_by_name("BLOSUM_62")
+    for j in "JOU":
+        assert np.array_equal(base[col(j)], base[col("X")]) and np.array_equal(base[:, col(j)], base[:, col("X")])
+    monkeypatch.setenv("S4G_JOU_POLICY", "similar")
+    sim = s4g.matrix_by_name("BLOSUM_62")
+    std = [c for c in range(26) if chr(65 + c) not in "JOU"]
+    for j, like in (("J", "L"), ("O", "K"), ("U", "C")):
+        assert np.array_equal(sim[col(j)][std], base[col(like)][std]) and sim[col(j), col(j)] == base[col(like), col(like)]
+    assert sim[col("U"), col("C")] == 9 and base[col("U"), col("C")] == -2
+    monkeypatch.setenv("S4G_JOU_POLICY", "stop")
+    stop = s4g.matrix_by_name("PAM_30")
+    assert (stop[col("O")][std] == -17).all() and stop[col("O"), col("O")] == 1           # the '*' row of PAM30
+    monkeypatch.setenv("S4G_JOU_POLICY", "nonsense")
+    with pytest.raises(RuntimeError):
+        s4g.matrix_by_name("BLOSUM_62")
+    monkeypatch.delenv("S4G_JOU_POLICY")
+    assert np.array_equal(s4g.matrix_by_name("BLOSUM_62"), base)
+    # the host API builds its scorer tables from the same function
+    monkeypatch.setenv("S4G_JOU_POLICY", "similar")
+    s = sw.scorer(10, 1)
+    assert L.scorerScore(s, col("U"), col("C")) == 9
+    L.scorerDelete(s)
+    monkeypatch.delenv("S4G_JOU_POLICY")
+
+    # ---- traceback ties: the host traceback follows the switch exactly as the oracle does ----
+    pairs = _tie_pairs(oracle_mod, blosum62, monkeypatch)
+    assert len(pairs) >= 3
+    s = sw.scorer(3, 3)
+    for mode in ("up", "left"):
+        monkeypatch.setenv("S4G_TRACEBACK_TIES", mode)
+        for q, t in pairs:
+            cq, ct = sw.chain("q", q), sw.chain("t", t)
+            a = vp()
+            L.alignPair(ctypes.byref(a), 0, cq, ct, s, None, 0, None)
+            o = oracle_mod.sw_align(q, t, blosum62, 3, 3)
+            assert L.alignmentGetScore(a) == o["score"]
+            assert sw.path_of(L.alignmentGetPathLen, L.alignmentGetMove, a) == [sw.ORACLE_TO_MOVE[m] for m in o["path"]], mode
+            L.alignmentDelete(a); L.chainDelete(cq); L.chainDelete(ct)
+    monkeypatch.delenv("S4G_TRACEBACK_TIES")
+    L.scorerDelete(s)
+
+    # ---- selection ties: three copies of one target (same score, same length, same e-value), one hit reported ----
+    rng = np.random.default_rng(7)
+    q = rand_seqs(rng, 1, 120, 120)[0]
+    s = sw.scorer(10, 1)
+    cq = sw.chain("query", q)
+    targets = [sw.chain(n, q.copy()) for n in ("zeta", "alpha", "mid")] + [sw.chain("noise", rand_seqs(rng, 1, 90, 90)[0])]
+    self_score = int(blosum62[q, q].sum())
+    scores = [self_score, self_score, self_score, 0]
+    for mode, first in ((None, 0), ("index", 0), ("reverse", 2), ("name", 1)):
+        if mode: monkeypatch.setenv("S4G_SELECTION_TIES", mode)
+        out, n = _lists_from_scores(cq, targets, scores, s, 1, 1e-4, 10 ** 6)
+        assert n.value == 1 and L.dbAlignmentGetTargetIdx(out[0]) == first, mode
+        L.dbAlignmentDelete(out[0]); sw.libc.free(out)
+        out, n = _lists_from_scores(cq, targets, scores, s, 400, 1e-4, 10 ** 6)
+        assert n.value == 3
+        for k in range(3): L.dbAlignmentDelete(out[k])
+        sw.libc.free(out)
+        if mode: monkeypatch.delenv("S4G_SELECTION_TIES")
+    for t in targets: L.chainDelete(t)
+    L.chainDelete(cq); L.scorerDelete(s)
