@@ -21,7 +21,7 @@
  *   s4g_scorer_create / s4g_scorer_destroy
  *       scorerCreateMatrix(Scorer**, char*, int, int) / scorerDelete
  *       /root/reference/sift4g/src/main.cpp:208,223
- *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_scattered / s4g_db_create_cached / s4g_chain_cache_info / s4g_db_create_from_device / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
+ *   s4g_db_create / s4g_db_create_tiled / s4g_db_create_scattered / s4g_db_create_cached / s4g_chain_cache_info / s4g_db_create_from_device / s4g_db_open_streamed / s4g_db_stream_stats / s4g_db_destroy / s4g_db_info / s4g_db_tiles / s4g_db_save / s4g_db_load
  *       chainDatabaseCreate(Chain**, int, int, int* cards, int cardsLen) /
  *       chainDatabaseDelete
  *       /root/reference/sift4g/src/database_alignment.cpp:80,92
@@ -129,6 +129,18 @@ int s4g_db_destroy(s4g_db* db);
  * sequences; s4g_db_load places a saved one on `device` without parsing or packing. */
 int s4g_db_save(const s4g_db* db, const char* path);
 int s4g_db_load(s4g_db** out, int device, const char* path);
+/* A saved database scanned WITHOUT being resident: only the tile headers are read here and two tile slots are allocated (pinned
+ * host + device, the size of the largest tile).  s4g_scan_topk / s4g_scan_topk_host then walk the file tile by tile -- while the
+ * kernels of one tile run, the host reads the next one and queues its upload -- with the resident scan's results; the other
+ * entry points return S4G_ERR_INVALID for such a database.  This is the reference's own access pattern (readFastaChainsPart in
+ * 1 GB parts while it works, /root/reference/sift4g/src/database_search.cpp:80-97) applied to the packed format: BASELINE configs[3],
+ * or any database beyond HBM.  Queries whose score bound exceeds the int16 windows run in the int32 kernel (no speculative tier:
+ * its exact recheck would need the tiles resident).
+ * s4g_db_stream_stats: out[0] = bytes read from the file by the scans so far, out[1] = seconds inside the reads, out[2] = seconds
+ * the reader waited for a free slot (the device was the slower side), out[3] = tiles loaded, out[4] = wall seconds of the scans,
+ * out[5] = bytes of one tile slot.  cap >= 6. */
+int s4g_db_open_streamed(s4g_db** out, int device, const char* path);
+int s4g_db_stream_stats(const s4g_db* db, double* out, uint32_t cap);
 /* number of tiles and (optionally, up to cap entries) sequences per tile */
 int s4g_db_tiles(const s4g_db* db, uint32_t* n_tiles, uint32_t* tile_seqs, uint32_t cap);
 /* any out pointer may be NULL */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "s4g_db_tiles": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.c_uint32]),
     "s4g_db_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "s4g_db_load": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.c_char_p]),
+    "s4g_db_open_streamed": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.c_char_p]),
+    "s4g_db_stream_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),
     "s4g_db_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "s4g_db_info": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u64p, c_u64p, c_u64p]),
     "s4g_queries_create": (ctypes.c_int, [c_vpp, ctypes.c_int, c_u8p, c_u64p, ctypes.c_uint32]),

@@ -112,7 +112,7 @@ int warm_core_kernels(DeviceCtx* cx) {
 
 // ---------------------------------------------------------------------------
 S4G_API const char* s4g_last_error(void) { return g_err.c_str(); }
-S4G_API int s4g_abi_version(void) { return 4; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info
+S4G_API int s4g_abi_version(void) { return 4; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info, s4g_db_open_streamed, s4g_db_stream_stats
 
 S4G_API int s4g_device_count(int* count) {
     if (!count) return fail(S4G_ERR_INVALID, "count is NULL");
@@ -597,6 +597,7 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
         std::lock_guard<std::mutex> lk(cx->mu);
         if (cx->last_use) (void)hipEventSynchronize(cx->last_use);
     }
+    if (db->stream) { db_stream_close(db); db->tiles.clear(); }         // (its tiles own no device memory)
     for (Tile& t : db->tiles) free_tile(t, device_ctx(db->device));
     if (db->cached) chain_cache_release(db);
     else if (!db->seq_tables_in_block) { (void)hipFree(db->d_seq_addr); (void)hipFree(db->d_seq_len); }
@@ -642,6 +643,7 @@ bool get_dev(FILE* f, T** d, size_t n, uint64_t* hbm) {
 S4G_API int s4g_db_save(const s4g_db* db, const char* path) {
     if (!db || !path) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->cached) return fail(S4G_ERR_INVALID, "a database of cached chains (s4g_db_create_cached) has no tiles to save");
+    if (db->stream) return fail(S4G_ERR_INVALID, "a streamed database is a file already");
     DeviceGuard guard(db->device);
     FILE* f = fopen(path, "wb");
     if (!f) return fail(S4G_ERR_INVALID, "cannot open '%s' for writing", path);

@@ -71,6 +71,8 @@ struct Tile {
     uint64_t pos0 = 0;                  // position of the tile's first sequence in the global length-sorted order
 };
 
+struct DbStream;                 // s4g_stream.hip: a packed database file scanned tile by tile (s4g_db_open_streamed)
+
 struct s4g_db {
     int device = 0;
     uint32_t n_seqs = 0;
@@ -89,8 +91,15 @@ struct s4g_db {
     bool cached = false;
     char* d_cached_block = nullptr;
     uint64_t cached_block_bytes = 0;
+    mutable DbStream* stream = nullptr;         // s4g_db_open_streamed: no resident tiles, only s4g_scan_topk* serve it
 };
 void chain_cache_release(s4g_db* db);           // s4g_chains.hip
+// s4g_stream.hip: tiles of a streamed database (db->stream != NULL) live in the file; two slots on the device
+void db_stream_close(s4g_db* db);
+int db_stream_load(const s4g_db* db, size_t ti);                                  // read tile ti (blocking) and queue its upload
+int db_stream_tile(const s4g_db* db, size_t ti, hipStream_t stream, Tile* out);   // `stream` waits for the upload; *out points into the slot
+int db_stream_consumed(const s4g_db* db, size_t ti, hipStream_t stream);          // record: everything queued so far is done with the slot
+void db_stream_note_scan(const s4g_db* db, double wall_s);
 
 // Per-device scratch shared by every database on that device: strip-boundary workspace, work-queue counters, query
 // lists, the streaming score buffer, a grow-only arena for the traceback.  sift4g's wrapper creates and destroys one

@@ -404,6 +404,7 @@ S4G_API int s4g_score_pairs_host(const s4g_db* db, const s4g_queries* q, const s
     if (n_pairs >= 0xFFFFFFFFull) return fail(S4G_ERR_INVALID, "too many pairs in one call");
     if (((flags & S4G_PAIRS_FORCE_SCAN) != 0) + ((flags & S4G_PAIRS_FORCE_WAVE) != 0) + ((flags & S4G_PAIRS_FORCE_LISTS) != 0) > 1)
         return fail(S4G_ERR_INVALID, "contradictory flags");
+    if (db->stream) return fail(S4G_ERR_INVALID, "a streamed database (s4g_db_open_streamed) serves s4g_scan_topk / s4g_scan_topk_host only");
     if (db->cached) flags = S4G_PAIRS_FORCE_WAVE;        // no tiles to scan, no length order to gather from: one wave per pair
     // One pass: range checks and, per query, what the route estimate needs (cells, longest pair, pair count).
     // Two exact routes per query.  "wave": its pairs one by one (sw_pair_scan / sw_pair_scan_band, or the packed list kernel for

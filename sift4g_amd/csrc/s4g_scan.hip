@@ -484,7 +484,7 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
-    if (scan_prefers_pairs(db, q, 0, q->n, 0)) {        // a call this small takes the latency route (one wave per pair)
+    if (!db->stream && scan_prefers_pairs(db, q, 0, q->n, 0)) {        // a call this small takes the latency route (one wave per pair)
         int rc0 = device_props(cx);
         if (rc0) return rc0;
         if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", q->max_len > (uint32_t)kPairMaxRows ? "sw_pair_scan_band<16>" : "sw_pair_scan<RPL>");
@@ -518,6 +518,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (rc) return rc;
     if (q_count == 0 || db->n_seqs == 0) return S4G_OK;
     if (!d_scores) return fail(S4G_ERR_INVALID, "d_scores is NULL");
+    if (db->stream) return fail(S4G_ERR_INVALID, "a streamed database (s4g_db_open_streamed) serves s4g_scan_topk / s4g_scan_topk_host only");
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
@@ -948,11 +949,46 @@ static int scan_topk_impl(const s4g_db* db, const s4g_queries* q, uint32_t q_beg
         const uint32_t cnt = std::min(batch, q_count - b);
         if (b) HIP_TRY(hipStreamSynchronize(stream));   // the next batch rewrites the query lists the previous launches read
         Plan p;
-        rc = make_plan(db, q, q_begin + b, cnt, scorer, flags, &p);
+        // (a streamed database has no resident tiles for the exact recheck pass to read: tiers by score bound only)
+        rc = make_plan(db, q, q_begin + b, cnt, scorer, db->stream ? (flags | S4G_SCAN_NO_SPEC) : flags, &p);
         if (rc) return rc;
         stats_add(cx, p);
         rc = ensure_scratch(db, scorer, p, stream);
         if (rc) return rc;
+        if (db->stream) {
+            // ---- tiles come from the file: while tile ti's kernels run, the host reads tile ti + 1 and queues its upload ----
+            const auto t_scan0 = std::chrono::steady_clock::now();
+            int32_t* buf = cx->d_tile_scores;
+            uint32_t* l_ids = reinterpret_cast<uint32_t*>(buf + (uint64_t)batch * cols);
+            int32_t* l_sc = reinterpret_cast<int32_t*>(l_ids + lists_max * k);
+            uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_sc + lists_max * k);
+            const size_t T = db->tiles.size();
+            if (T) { rc = db_stream_load(db, 0); if (rc) return rc; }
+            for (size_t ti = 0; ti < T; ++ti) {
+                Tile lt;
+                rc = db_stream_tile(db, ti, stream, &lt);
+                if (rc) return rc;
+                if (lt.n_seqs) {
+                    rc = launch_tile(db, lt, p.tiles[ti], q, scorer, p, q_begin + b, buf, lt.n_seqs, lt.d_perm_local, stream, false);
+                    if (rc) return rc;
+                    const uint32_t segs = std::max(1u, std::min(std::min(16u, 256u / std::max(1u, cnt)), (lt.n_seqs + 16383u) / 16384u));
+                    const uint32_t seg_len = ((lt.n_seqs + segs - 1) / segs + 255u) / 256u * 256u;
+                    hipLaunchKernelGGL(topk_rows, dim3(cnt, segs), dim3(kTopkBlock), 0, stream, buf, lt.n_seqs, seg_len, k, kpad, min_score, l_ids,
+                                       l_sc, l_cnt, (const uint32_t*)lt.d_col_ids, d_min_scores ? d_min_scores + b : (const int32_t*)nullptr);
+                    for (uint32_t sgm = 0; sgm < segs; ++sgm)
+                        hipLaunchKernelGGL(merge_rows, dim3(cnt), dim3(kTopkBlock), 0, stream, d_ids + (uint64_t)b * k,
+                                           d_top_scores + (uint64_t)b * k, d_counts + b, l_ids + (uint64_t)sgm * cnt * k,
+                                           l_sc + (uint64_t)sgm * cnt * k, l_cnt + (uint64_t)sgm * cnt, k, kpad2);
+                    HIP_TRY(hipGetLastError());
+                }
+                rc = db_stream_consumed(db, ti, stream);
+                if (rc) return rc;
+                if (ti + 1 < T) { rc = db_stream_load(db, ti + 1); if (rc) return rc; }
+            }
+            HIP_TRY(hipStreamSynchronize(stream));           // the slots are rewritten by the next batch (and the timing below means the scan)
+            db_stream_note_scan(db, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scan0).count());
+            continue;
+        }
         // Kinds of tile: entirely on the scan kernels (g0 = 0), entirely on the pair kernels (the long-sequence tile of a real
         // database), or split (its longest groups as pairs on the side stream, the rest on the scan kernels).  With two sets:
         //   * a pair tile runs on the side stream with the second set, beside the scan tiles;

@@ -16,6 +16,7 @@ S4G_API int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, con
     if (!pair_q || !pair_t || !pair_score || !h_out || !path_off || !h_paths) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
     if ((flags & S4G_PAIRS_FORCE_SCAN) && (flags & S4G_PAIRS_FORCE_WAVE)) return fail(S4G_ERR_INVALID, "contradictory flags");
+    if (db->stream) return fail(S4G_ERR_INVALID, "a streamed database (s4g_db_open_streamed) serves s4g_scan_topk / s4g_scan_topk_host only");
     if (db->cached) flags = S4G_PAIRS_FORCE_WAVE;        // a database of cached chains has no tiles for the strip kernels
     for (uint32_t i = 0; i < n_pairs; ++i) {
         if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %u out of range", i);

@@ -108,6 +108,23 @@ class Database(_SeqSet):
         return self
 
     @classmethod
+    def open_streamed(cls, path, device=0):
+        """a saved database scanned tile by tile out of its file (s4g_db_open_streamed): scan_topk only"""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        check(lib.s4g_db_open_streamed(ctypes.byref(self._h), device, str(path).encode()), "s4g_db_open_streamed")
+        self.device = device
+        self.n = self.info()["n_seqs"]
+        self.codes = self.offsets = None
+        self.lengths = None
+        return self
+
+    def stream_stats(self):
+        out = (ctypes.c_double * 6)()
+        check(lib.s4g_db_stream_stats(self._h, out, 6), "s4g_db_stream_stats")
+        return dict(bytes_read=out[0], read_s=out[1], wait_s=out[2], tiles=int(out[3]), scan_wall_s=out[4], slot_bytes=int(out[5]))
+
+    @classmethod
     def from_arrays(cls, seqs, device=0):
         """seqs: list of separate uint8 code arrays, one per target (s4g_db_create_scattered: what chainDatabaseCreate passes)."""
         arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in seqs]

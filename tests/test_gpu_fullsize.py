@@ -49,6 +49,11 @@ def _oracle_sample(oracle_mod, cfg, got, n_random, planted, seed):
     assert np.array_equal(have, exp)
 
 
+def s4gd_cells(s4g, db, q):
+    from sift4g_amd import device as s4gd
+    return s4gd.scan_cells(db, q)
+
+
 def test_configs1_all_1000_queries(s4g, oracle_mod):
     """BASELINE configs[1] as bench.py runs it: all 1000 queries x 100 000 targets (1.2e13 cells).  Properties over the WHOLE matrix,
     idempotence, the int32 kernel on a query range against the packed tier, the oracle on 4000 random and 400 planted pairs, and
@@ -285,3 +290,60 @@ def test_configs3_prefilter_streams_one_gpus_share(s4g, oracle_mod):
             t = int(sample[j])
             if t not in members:                                              # equal to the cut and a higher index than every kept tie
                 assert sc[j] == cut and t > max(int(x) for x, s_ in zip(ids[i, :MAXC], scores[i, :MAXC]) if s_ == cut), (i, t)
+
+
+def test_configs3_share_streamed_from_storage(s4g, tmp_path_factory):
+    """BASELINE configs[3] from storage (missing 3): one GPU's share of a UniRef-scale database -- 24 M device-generated
+    targets, 8.2e9 residues, more than 8 GB as a packed file -- saved, dropped from HBM, and scanned out of the file tile by tile
+    (s4g_db_open_streamed: two tile slots, the host reads tile i + 1 while tile i runs).  The streaming top-400 of 16 queries
+    equals the resident scan's, list for list; the test prints the file's read rate next to the rate the scan consumes tiles at."""
+    import shutil
+    import time
+    from sift4g_amd import synth
+    base = tmp_path_factory.mktemp("s4g_stream")
+    free = shutil.disk_usage(base).free
+    N = 24_000_000 if free > 20 * 2**30 else (6_000_000 if free > 6 * 2**30 else 1_500_000)       # 8.6 GB / 2.2 GB / 0.55 GB files
+    Q, K = 16, 400
+    dev = torch.device("cuda", 0)
+    codes, offsets = synth.device_database(N, synth.SEED_BASE + 4 + 0x3000, dev)
+    ql = synth.query_lengths(synth.SEED_BASE + 4 + 0x100, Q)
+    q_codes, q_off = synth.random_set(synth.SEED_BASE + 4 + 0x200, ql)
+    lens = (offsets[1:] - offsets[:-1])
+    for i in range(Q):                                   # a copy of every query somewhere in the share
+        p = (i + 1) * (N // (Q + 1))
+        while int(lens[p]) < ql[i]:
+            p += 1
+        o = int(offsets[p])
+        codes[o:o + int(ql[i])] = torch.from_numpy(q_codes[int(q_off[i]):int(q_off[i + 1])].copy()).to(dev)
+    torch.cuda.synchronize()
+    db = s4g.Database.from_device(codes, offsets)
+    del codes, offsets
+    q = s4g.QuerySet(codes=q_codes, offsets=q_off)
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    want = [x.cpu().numpy() for x in s4g.scan_topk(db, q, scorer, K)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    [x.cpu() for x in s4g.scan_topk(db, q, scorer, K)]
+    t_resident = time.perf_counter() - t0
+    path = base / "share.s4g"
+    t0 = time.perf_counter()
+    db.save(path)
+    t_save = time.perf_counter() - t0
+    n_tiles, cells = len(db.tiles()), s4gd_cells(s4g, db, q)
+    db.close()
+    torch.cuda.empty_cache()
+    size = os.path.getsize(path)
+    assert size > (8 * 2**30 if N == 24_000_000 else 2**28)
+    sdb = s4g.Database.open_streamed(path)
+    assert len(sdb.tiles()) == n_tiles
+    t0 = time.perf_counter()
+    got = [x.cpu().numpy() for x in s4g.scan_topk(sdb, q, scorer, K)]
+    t_stream = time.perf_counter() - t0
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    st = sdb.stream_stats()
+    print(f"\nconfigs[3] share from storage: {N} targets, file {size / 1e9:.2f} GB in {n_tiles} tiles (written in {t_save:.1f} s); "
+          f"{Q} queries: resident scan {t_resident:.2f} s = {cells / t_resident / 1e9:.0f} GCUPS, streamed from the file {t_stream:.2f} s = "
+          f"{cells / t_stream / 1e9:.0f} GCUPS; reads {st['bytes_read'] / 1e9:.2f} GB at {st['bytes_read'] / max(st['read_s'], 1e-9) / 1e9:.2f} GB/s, "
+          f"the scan consumes tiles at {size / t_resident / 1e9:.2f} GB/s; the reader waited {st['wait_s']:.2f} s for the device")
+    sdb.close()
+    os.remove(path)

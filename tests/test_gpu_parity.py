@@ -544,6 +544,44 @@ def test_packed_database_file_roundtrip(s4g, oracle_mod, blosum62, scorer, tmp_p
         s4g.Database.load(path.parent / "junk.s4g")
 
 
+def test_streamed_database_scans_like_the_resident_one(s4g, oracle_mod, blosum62, scorer, tmp_path):
+    """s4g_db_open_streamed: the packed file scanned tile by tile through two device slots (the host reads tile i + 1 while tile i
+    runs) -- the streaming top-k of 7 tiles equals the resident database's and the oracle's, twice in a row (slot reuse), with a
+    long query whose score bound leaves the int16 windows (int32 tier instead of the speculative one); the byte count of the reads
+    is the file's tiles; the entry points that need resident tiles refuse it."""
+    rng = np.random.default_rng(130)
+    qs = rand_seqs(rng, 5, 40, 200) + [rand_seqs(rng, 1, 6500, 6500)[0]]
+    ts = rand_seqs(rng, 420, 1, 280) + [qs[0][10:150].copy(), qs[5][100:6400].copy(), rand_seqs(rng, 1, 12400, 12400)[0]]
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    db = s4g.Database(ts, tile_seqs=64)
+    path = tmp_path / "db.s4g"
+    db.save(path)
+    sdb = s4g.Database.open_streamed(path)
+    assert sdb.n == len(ts) and sdb.tiles() == db.tiles() and len(sdb.tiles()) >= 7
+    q = s4g.QuerySet(qs)
+    want = s4g.scan_topk(db, q, scorer, 25, 1)
+    for rep in range(2):
+        got = s4g.scan_topk(sdb, q, scorer, 25, 1)
+        assert all(np.array_equal(x.cpu().numpy(), y.cpu().numpy()) for x, y in zip(got, want)), rep
+    ids, sc, cnt = (x.cpu().numpy() for x in got)
+    for i in range(len(qs)):
+        order = sorted(range(len(ts)), key=lambda t: (-int(exp[i, t]), t))
+        keep = [t for t in order if exp[i, t] >= 1][:25]
+        assert ids[i, :cnt[i]].tolist() == keep and sc[i, :cnt[i]].tolist() == [int(exp[i, t]) for t in keep]
+    st = sdb.stream_stats()
+    assert st["tiles"] == 2 * len(sdb.tiles()) and 0 < st["bytes_read"] <= 2 * os.path.getsize(path) and st["scan_wall_s"] > 0
+    with pytest.raises(RuntimeError):
+        s4g.scan_host(sdb, q, scorer)
+    with pytest.raises(RuntimeError):
+        s4g.score_pairs(sdb, q, scorer, [0], [0])
+    with pytest.raises(RuntimeError):
+        sdb.save(tmp_path / "again.s4g")
+    (tmp_path / "short.s4g").write_bytes(open(path, "rb").read()[:-1000])
+    with pytest.raises(RuntimeError):
+        s4g.Database.open_streamed(tmp_path / "short.s4g")
+    sdb.close()
+
+
 def test_randomized_configurations(s4g, oracle_mod):
     """seeded fuzz over everything at once: random symmetric/asymmetric tables, gap penalties, length mixes (empties,
     singletons, long tails), tile sizes and kernel choice; scan, streaming top-k and traceback against the oracle."""
