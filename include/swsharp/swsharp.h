@@ -63,11 +63,18 @@ void readFastaChains(Chain*** chains, int* chainsLen, const char* path);
 void readFastaChainsPartInit(Chain*** chains, int* chainsLen, FILE** handle, int* serialized, const char* path);
 int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, int serialized, const size_t maxBytes);
 void deleteFastaChains(Chain** chains, int chainsLen);
+/* Extension: the part readFastaChainsPart would return (database_search.cpp:93-97) as flat residue codes: no Chain objects to
+ * delete again (:125-129).  codes[offsets[i] .. offsets[i + 1]) = chainGetCodes of record i; *codes and *offsets (records + 1
+ * entries) are malloc'ed, the caller frees both.  Returns 1 if more parts remain.  A handle is read with one kind of reader only. */
+int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes);
+/* ... and the header text of every record beside it (names[nameOffsets[i] .. nameOffsets[i + 1]), not terminated; malloc'ed):
+ * what chainDatabaseCreateFlat takes. */
+int readFastaCodesPartNamed(char** codes, size_t** offsets, char** names, size_t** nameOffsets, int* recordsLen, FILE* handle,
+                            int serialized, const size_t maxBytes);
 /* Extension: totals of a FASTA file (records, residues as chainGetLength counts them) without keeping any chain: from the header of
  * the serialized cache when there is a valid one (S4G_FASTA_CACHE=1), else by one pass over the file.  Used by the full-scan
  * build in place of the k-mer prefilter's pass (sift4g_amd/csrc/dropin/count_database_search.cpp). */
-int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes);   /* extension: the part readFastaChainsPart would return (database_search.cpp:93-97), as flat residue codes: no Chain objects to delete again (:125-129); caller frees both arrays */
-void fastaResidueCount(const char* path, long long* records, long long* residues);                      /* skips NULL entries */
+void fastaResidueCount(const char* path, long long* records, long long* residues);
 
 /* ---- Scorer (main.cpp:208,223; names main.cpp:304-314) ---- */
 void scorerCreateMatrix(Scorer** scorer, char* name, int gapOpen, int gapExtend);
@@ -91,6 +98,16 @@ int swsharpPreferredCard(void);
 /* ---- ChainDatabase (database_alignment.cpp:80,92): targets packed and resident in HBM ---- */
 ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, int databaseLen, int* cards, int cardsLen);
 void chainDatabaseDelete(ChainDatabase* chainDatabase);
+/* Extension: a ChainDatabase over a part kept FLAT (readFastaCodesPartNamed's four arrays; borrowed: they must outlive the
+ * database).  No Chain is built for a sequence until it appears in an alignment: the library scores straight out of the codes,
+ * hands value functions placeholder chains that carry the LENGTH only (eValues needs nothing else; a callback that reads names or
+ * residues of database chains must use chainDatabaseCreate), and creates the real chain -- name, letters, codes -- of every
+ * target it reports.  Those chains belong to the caller (dbAlignmentGetTarget; chainDelete them), everything else goes with
+ * chainDatabaseDelete.  This is what lets the drop-in read the database once: the prefilter's pass keeps the parts flat, the
+ * alignment stage builds a chain for a few hundred hits per query instead of every record
+ * (/root/reference/sift4g/src/database_alignment.cpp:36-47,106-113 reads everything again and deletes what carried no hit). */
+ChainDatabase* chainDatabaseCreateFlat(const char* codes, const size_t* offsets, const char* names, const size_t* nameOffsets,
+                                       int recordsLen, int* cards, int cardsLen);
 
 /* ---- database alignment (database_alignment.cpp:83-86): score all, value, threshold, top maxAlignments, traceback ---- */
 void alignDatabase(DbAlignment*** dbAlignments, int* dbAlignmentsLen, int type, Chain* query,

@@ -26,6 +26,7 @@
 
 #include "utils.hpp"                   // the reference's own: databaseLog
 #include "database_alignment.hpp"      // the reference's own: the declaration this file implements
+#include "flat_database.hpp"           // the database as the device prefilter's pass left it, if it did (dropin-devsearch)
 
 namespace {
 
@@ -93,6 +94,85 @@ struct PartJob {
     }
 };
 
+// The stage when the prefilter's pass left the database behind as flat parts (flat_database.hpp): nothing is read again and no
+// chain is built for a record unless it ends up in an alignment.  Per part: every query's candidates inside the part as positions
+// in it (the consumed prefix removed, as createFilteredDatabase does), ONE flat ChainDatabase over the whole part
+// (chainDatabaseCreateFlat: the codes go to the device as they are), one shotgunDatabaseCandidates call, merge in part order.
+// The `database` array handed back holds the chains of the reported targets and NULL everywhere else -- what the reference's
+// array looks like after it deleted the chains without an alignment (database_alignment.cpp:106-113).
+void align_flat_database(s4g_dropin::FlatDatabase& flat, DbAlignment**** alignments, int** alignments_lengths, Chain*** database_out,
+                         int32_t* database_length_out, Chain** queries, int32_t queries_length, std::vector<std::vector<uint32_t>>& indices,
+                         int32_t algorithm, EValueParams* evalue_params, double max_evalue, uint32_t max_alignments, Scorer* scorer,
+                         int32_t* cards, int32_t cards_length) {
+    size_t total = 0;
+    for (const s4g_dropin::FlatPart& p : flat.parts) total += (size_t)p.n;
+    Chain** database = (Chain**)calloc(total ? total : 1, sizeof(Chain*));           // malloc domain: main.cpp frees it with deleteFastaChains
+    double t_lists = 0, t_lib = 0, t_rest = 0;
+    auto lap = [](std::chrono::steady_clock::time_point& t) {
+        const auto now = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(now - t).count();
+        t = now;
+        return s;
+    };
+    uint32_t part_no = 1;
+    for (const s4g_dropin::FlatPart& p : flat.parts) {
+        auto clock = std::chrono::steady_clock::now();
+        const float part_gb = (p.n ? p.off[p.n] : 0) / 1e9f;
+        databaseLog(part_no, part_gb, 0);
+        const uint32_t begin = p.first_id, end = p.first_id + (uint32_t)p.n;
+        std::vector<std::vector<int>> lists(queries_length);
+        size_t pairs = 0;
+        for (int32_t q = 0; q < queries_length; ++q) {
+            std::vector<uint32_t>& v = indices[q];
+            size_t n = 0;
+            while (n < v.size() && v[n] < end) { if (v[n] >= begin) lists[q].push_back((int)(v[n] - begin)); ++n; }
+            v.erase(v.begin(), v.begin() + n);
+            pairs += lists[q].size();
+        }
+        t_lists += lap(clock);
+        DbAlignment*** found = nullptr;
+        int* found_lengths = nullptr;
+        if (pairs == 0) {
+            found = (DbAlignment***)calloc(queries_length ? queries_length : 1, sizeof(DbAlignment**));
+            found_lengths = (int*)calloc(queries_length ? queries_length : 1, sizeof(int));
+        } else {
+            databaseLog(part_no, part_gb, 50);
+            ChainDatabase* part_db = chainDatabaseCreateFlat(p.codes, p.off, p.names, p.name_off, p.n, cards, cards_length);
+            std::vector<int*> list_ptrs(queries_length);
+            std::vector<int> list_lens(queries_length);
+            for (int32_t q = 0; q < queries_length; ++q) { list_ptrs[q] = lists[q].empty() ? nullptr : lists[q].data(); list_lens[q] = (int)lists[q].size(); }
+            shotgunDatabaseCandidates(&found, &found_lengths, algorithm, queries, queries_length, part_db, scorer, (int)max_alignments,
+                                      evalue_callback, evalue_params, max_evalue, list_ptrs.data(), list_lens.data(), cards, cards_length, nullptr);
+            // the chains the library made for the reported targets are ours now
+            for (int32_t q = 0; q < queries_length; ++q)
+                for (int k = 0; k < found_lengths[q]; ++k) database[begin + (uint32_t)dbAlignmentGetTargetIdx(found[q][k])] = dbAlignmentGetTarget(found[q][k]);
+            chainDatabaseDelete(part_db);
+        }
+        t_lib += lap(clock);
+        if (*alignments == nullptr) {
+            *alignments = found;
+            *alignments_lengths = found_lengths;
+        } else {
+            dbAlignmentsMerge(*alignments, *alignments_lengths, found, found_lengths, queries_length, (int)max_alignments);
+            deleteShotgunDatabase(found, found_lengths, queries_length);
+        }
+        databaseLog(part_no, part_gb, 100);
+        ++part_no;
+        t_rest += lap(clock);
+    }
+    fprintf(stderr, "\n\n");
+    if (*alignments == nullptr) {            // a database without records
+        *alignments = (DbAlignment***)calloc(queries_length ? queries_length : 1, sizeof(DbAlignment**));
+        *alignments_lengths = (int*)calloc(queries_length ? queries_length : 1, sizeof(int));
+    }
+    if (getenv("S4G_PROFILE"))
+        fprintf(stderr, "[s4g profile] aligning stage (flat parts of the prefilter's pass: the file is not read again): candidate lists %.3f s, library "
+                        "(database + scores + traceback + chains of the hits) %.3f s, merge %.3f s\n", t_lists, t_lib, t_rest);
+    flat.clear();
+    *database_out = database;
+    *database_length_out = (int32_t)total;
+}
+
 }  // namespace
 
 void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain*** database_out, int32_t* database_length_out,
@@ -100,6 +180,16 @@ void alignDatabase(DbAlignment**** alignments, int** alignments_lengths, Chain**
                    std::vector<std::vector<uint32_t>>& indices, int32_t algorithm, EValueParams* evalue_params, double max_evalue,
                    uint32_t max_alignments, Scorer* scorer, int32_t* cards, int32_t cards_length) {
     fprintf(stderr, "** Aligning queries with candidate sequences **\n");
+
+    {   // the database as the device prefilter's pass left it (dropin-devsearch): one pass over the file
+        s4g_dropin::FlatDatabase& flat = s4g_dropin::flat_database();
+        if (flat.complete && flat.path == database_path && !getenv("S4G_READ_DATABASE_TWICE")) {
+            align_flat_database(flat, alignments, alignments_lengths, database_out, database_length_out, queries, queries_length, indices,
+                                algorithm, evalue_params, max_evalue, max_alignments, scorer, cards, cards_length);
+            return;
+        }
+        flat.clear();
+    }
 
     Chain** database = nullptr;
     int database_length = 0;

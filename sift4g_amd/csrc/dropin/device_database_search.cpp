@@ -25,6 +25,7 @@
 
 #include "utils.hpp"              // the reference's own: databaseLog
 #include "database_search.hpp"    // the reference's own: the declaration this file implements
+#include "flat_database.hpp"
 #include "s4g_hip.h"
 
 namespace {
@@ -52,6 +53,8 @@ void die(const char* what) {
 struct Part {                       // one part of the database as the device takes it
     char* codes = nullptr;
     size_t* off = nullptr;
+    char* names = nullptr;          // the records' header text: not for the device, for the alignment stage (flat_database.hpp)
+    size_t* name_off = nullptr;
     uint32_t n = 0, first_id = 0;
 };
 static_assert(sizeof(size_t) == sizeof(uint64_t), "offsets are handed to the device ABI as they are");
@@ -104,15 +107,33 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     const float part_size = database_chunk / (float)1000000000;
     Part parts[2];
     std::future<int> pending;                            // the device's work on the previous part
+    // the parts stay behind for the alignment stage (one pass over the file) while they fit the budget
+    s4g_dropin::FlatDatabase& keep = s4g_dropin::flat_database();
+    keep.clear();
+    keep.path = database_path;
+    bool keeping = s4g_dropin::flat_database_budget() > 0;
+    auto retire = [&](Part& p) {                         // a part the device is through with: kept or freed
+        if (!p.codes) return;
+        const size_t b = p.off[p.n] + p.name_off[p.n] + (size_t)(p.n + 1) * 2 * sizeof(size_t);
+        if (keeping && keep.bytes + b <= s4g_dropin::flat_database_budget()) {
+            s4g_dropin::FlatPart f;
+            f.codes = p.codes; f.off = p.off; f.names = p.names; f.name_off = p.name_off; f.n = (int)p.n; f.first_id = p.first_id;
+            keep.parts.push_back(f);
+            keep.bytes += b;
+        } else {
+            if (keeping) { keeping = false; keep.clear(); }
+            free(p.codes); free(p.off); free(p.names); free(p.name_off);
+        }
+        p = Part();
+    };
     while (true) {
         // the part as flat residue codes (readFastaCodesPart: the records and part boundaries of readFastaChainsPart, :93-97,
         // without building the chains this stage would delete again at :125-129)
         auto t0 = std::chrono::steady_clock::now();
         Part& p = parts[part & 1];                       // the other one may still be on its way to the device
-        free(p.codes); free(p.off);
-        p.codes = nullptr; p.off = nullptr;
+        retire(p);                                       // (the part two steps back: the device finished it before the last one started)
         int records = 0;
-        const int status = readFastaCodesPart(&p.codes, &p.off, &records, handle, serialized, database_chunk);
+        const int status = readFastaCodesPartNamed(&p.codes, &p.off, &p.names, &p.name_off, &records, handle, serialized, database_chunk);
         p.n = (uint32_t)records;
         p.first_id = database_start;
         database_cells += p.off[records];
@@ -137,7 +158,10 @@ uint64_t searchDatabase(std::vector<std::vector<uint32_t>>& dst, const std::stri
     t_wait += seconds_since(t0);
     t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "\n\n");
-    for (Part& p : parts) { free(p.codes); free(p.off); }
+    // in database order: the part two steps back was retired inside the loop, the last two are left
+    { Part& a = parts[part & 1]; Part& b = parts[(part + 1) & 1]; if (a.codes && b.codes && a.first_id > b.first_id) { retire(b); retire(a); } else { retire(a); retire(b); } }
+    keep.complete = keeping;
+    if (!keeping) keep.clear();
 
     fclose(handle);
     deleteFastaChains(database, database_length);

@@ -156,15 +156,66 @@ SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, i
     return db;
 }
 
+// A part kept flat (readFastaCodesPartNamed): placeholder chains now, real ones for the targets that get reported.
+SW_API ChainDatabase* chainDatabaseCreateFlat(const char* codes, const size_t* offsets, const char* names, const size_t* nameOffsets,
+                                              int recordsLen, int* cards, int cardsLen) {
+    SW_ASSERT(recordsLen >= 0 && (recordsLen == 0 || (codes != NULL && offsets != NULL && names != NULL && nameOffsets != NULL)),
+              "chainDatabaseCreateFlat: invalid arguments");
+    static ChainData nobody = {(char*)"", (char*)"", (char*)"", 0, 1 << 30};       // what a placeholder's name / letters / codes read as
+    ChainDatabase* db = new ChainDatabase();
+    db->length = recordsLen;
+    db->device = pick_device(cards, cardsLen);
+    db->cached = NULL;
+    if (cards && cardsLen > 0) db->cards.assign(cards, cards + cardsLen); else db->cards.assign(1, 0);
+    db->replicas.assign(db->cards.size(), (s4g_db*)NULL);
+    db->flat_codes = codes; db->flat_off = offsets; db->flat_names = names; db->flat_name_off = nameOffsets;
+    db->stubs.resize((size_t)recordsLen);
+    db->stub_ptrs.resize((size_t)recordsLen ? (size_t)recordsLen : 1);
+    db->real.assign((size_t)recordsLen, (Chain*)NULL);
+    for (int i = 0; i < recordsLen; ++i) {
+        Chain& c = db->stubs[i];
+        memset(&c, 0, sizeof c);
+        c.data = &nobody; c.length = (int)(offsets[i + 1] - offsets[i]); c.embedded = true;
+        db->stub_ptrs[i] = &c;
+    }
+    db->chains = db->stub_ptrs.data();
+    db->residues = recordsLen ? (long long)(offsets[recordsLen] - offsets[0]) : 0;
+    for (size_t slot = 0; slot < db->cards.size(); ++slot) (void)swimpl::packed_replica(db, (int)slot);
+    return db;
+}
+
 namespace swimpl {
+
+Chain* real_chain(ChainDatabase* db, int idx) {
+    if (!db->flat_off) return db->chains[idx];
+    if (!db->real[idx]) {
+        const size_t n = db->flat_off[idx + 1] - db->flat_off[idx];
+        std::string letters(n, 'A');
+        for (size_t k = 0; k < n; ++k) letters[k] = (char)('A' + db->flat_codes[db->flat_off[idx] + k]);
+        const size_t nb = db->flat_name_off[idx], ne = db->flat_name_off[idx + 1];
+        db->real[idx] = chainCreate(const_cast<char*>(db->flat_names + nb), (int)(ne - nb), &letters[0], (int)n);
+    }
+    return db->real[idx];
+}
 
 // the cached form: up to this many chains (a per-query candidate list is <= 5000, main.cpp:69) and only where it is wanted
 static const bool g_chain_cache_on = getenv("S4G_NO_CHAIN_CACHE") == NULL;
-bool cached_form_fits(const ChainDatabase* db) { return g_chain_cache_on && db->length > 0 && db->length <= 32768; }
+bool cached_form_fits(const ChainDatabase* db) { return g_chain_cache_on && !db->flat_off && db->length > 0 && db->length <= 32768; }
 
 s4g_db* packed_replica(ChainDatabase* db, int slot) {
     if (db->replicas[slot]) return db->replicas[slot];
     Phase ph(0);
+    if (db->flat_off) {             // codes back to back already: one upload, packed on the device
+        static_assert(sizeof(size_t) == sizeof(uint64_t), "offsets go to the device ABI as they are");
+        std::vector<uint64_t> rel((size_t)db->length + 1);
+        for (int i = 0; i <= db->length; ++i) rel[i] = db->flat_off[i] - db->flat_off[0];
+        s4g_db* rep = NULL;
+        int rc = s4g_db_create(&rep, db->cards[slot], reinterpret_cast<const uint8_t*>(db->flat_codes + (db->length ? db->flat_off[0] : 0)), rel.data(), (uint32_t)db->length);
+        if (rc != S4G_OK)
+            SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->cards[slot], s4g_last_error());
+        db->replicas[slot] = rep;
+        return rep;
+    }
     std::vector<const uint8_t*> seqs((size_t)db->length);
     std::vector<uint32_t> lens((size_t)db->length);
     for (int i = 0; i < db->length; ++i) {
@@ -399,7 +450,7 @@ static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** que
             const Survivor& sv = keep[i][k];
             DbAlignment* a = (DbAlignment*)xcalloc(1, sizeof(DbAlignment));
             a->query = queries[i]; a->query_idx = query_idx0 + (int)i;
-            a->target = cdb->chains[sv.idx]; a->target_idx = sv.idx;
+            a->target = swimpl::real_chain(cdb, sv.idx); a->target_idx = sv.idx;
             a->query_start = out5[(size_t)x * 5]; a->query_end = out5[(size_t)x * 5 + 1];
             a->target_start = out5[(size_t)x * 5 + 2]; a->target_end = out5[(size_t)x * 5 + 3];
             a->score = sv.score; a->value = sv.value; a->scorer = swimpl::scorer_retain(scorer);

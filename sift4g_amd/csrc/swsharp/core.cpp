@@ -240,6 +240,9 @@ struct FlatSink {
     size_t used = 0, cap = 0;
     std::vector<size_t> off;        // off[i] = first code of record i; a final entry is appended when the part ends
     size_t raw = 0;
+    bool want_names = false;        // readFastaCodesPartNamed: the header text of every record, back to back
+    std::string names;
+    std::vector<size_t> name_off;
     void reserve(size_t n) {
         if (used + n <= cap) return;
         cap = std::max(used + n + (4u << 20), cap + cap / 2);
@@ -278,6 +281,7 @@ int fasta_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
     auto flush = [&]() {
         if (!st->have_pending) return;
         if (flat) {                              // the record's codes are in place already; it only has to be closed
+            if (flat->want_names) { flat->name_off.push_back(flat->names.size()); flat->names.append(st->pending_name); }
             consumed += flat->raw;
             flat->raw = 0;
             st->have_pending = false;
@@ -376,6 +380,7 @@ int cache_read(FastaState* st, Chain*** chains, int* len, size_t max_bytes, Flat
         if (flat) {
             const size_t at = flat->used;
             flat->off.push_back(at);
+            if (flat->want_names) { flat->name_off.push_back(flat->names.size()); flat->names.append(name); }
             flat->reserve(hdr[1]);
             SW_ASSERT(!hdr[1] || fread(flat->codes + at, hdr[1], 1, st->fh) == 1, "truncated serialized database cache");
             for (uint32_t i = 0; i < hdr[1]; ++i) flat->codes[at + i] = (char)(flat->codes[at + i] - 'A');
@@ -449,11 +454,13 @@ SW_API int readFastaChainsPart(Chain*** chains, int* chainsLen, FILE* handle, in
 // (chainGetCodes of the chains readFastaChainsPart would have returned, back to back) and the same part boundaries.  *codes and
 // *offsets (records + 1 entries, offsets[0] = 0) are malloc'ed; the caller frees them.  Returns 1 if more parts remain.  A handle
 // is read either with this function or with readFastaChainsPart, not both.
-SW_API int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes) {
+static int read_codes_part(char** codes, size_t** offsets, char** names, size_t** nameOffsets, int* recordsLen, FILE* handle, int serialized,
+                           const size_t maxBytes) {
     FastaState* st = fasta_state(handle, true);
     SW_ASSERT((serialized != 0) == st->serialized_in, "readFastaCodesPart: `serialized` does not belong to this handle");
-    cache_abandon(st);          // a pass that keeps no names cannot write the serialized cache (S4G_FASTA_CACHE=1): none is left behind
+    cache_abandon(st);          // a pass that builds no chains cannot write the serialized cache (S4G_FASTA_CACHE=1): none is left behind
     FlatSink flat;
+    flat.want_names = names != NULL;
     const int more = st->serialized_in ? cache_read(st, NULL, NULL, maxBytes, &flat) : fasta_read(st, NULL, NULL, maxBytes, &flat);
     flat.off.push_back(flat.used);
     *recordsLen = (int)flat.off.size() - 1;
@@ -461,8 +468,28 @@ SW_API int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, F
     *codes = flat.codes;
     *offsets = (size_t*)xmalloc(sizeof(size_t) * flat.off.size());
     memcpy(*offsets, flat.off.data(), sizeof(size_t) * flat.off.size());
+    if (names) {
+        SW_ASSERT((int)flat.name_off.size() == *recordsLen, "internal error: %zu names for %d records", flat.name_off.size(), *recordsLen);
+        flat.name_off.push_back(flat.names.size());
+        *names = (char*)xmalloc(flat.names.size() + 1);
+        memcpy(*names, flat.names.data(), flat.names.size());
+        *nameOffsets = (size_t*)xmalloc(sizeof(size_t) * flat.name_off.size());
+        memcpy(*nameOffsets, flat.name_off.data(), sizeof(size_t) * flat.name_off.size());
+    }
     if (!more) fasta_forget(handle);
     return more;
+}
+
+SW_API int readFastaCodesPart(char** codes, size_t** offsets, int* recordsLen, FILE* handle, int serialized, const size_t maxBytes) {
+    return read_codes_part(codes, offsets, NULL, NULL, recordsLen, handle, serialized, maxBytes);
+}
+
+// The same with the header text of every record (names[nameOffsets[i] .. nameOffsets[i + 1]), not terminated): everything a
+// Chain is made of, so that a caller can keep a part flat and create the few chains it turns out to need (chainDatabaseCreateFlat).
+SW_API int readFastaCodesPartNamed(char** codes, size_t** offsets, char** names, size_t** nameOffsets, int* recordsLen, FILE* handle,
+                                   int serialized, const size_t maxBytes) {
+    SW_ASSERT(names != NULL && nameOffsets != NULL, "readFastaCodesPartNamed: NULL argument");
+    return read_codes_part(codes, offsets, names, nameOffsets, recordsLen, handle, serialized, maxBytes);
 }
 
 // Totals of a FASTA file: records and residues (as chainGetLength counts them).  With a valid serialized cache beside the

@@ -70,6 +70,15 @@ struct ChainDatabase {
     //                   or a few queries runs on (one wave per pair), without sending the chains again.
     std::vector<s4g_db*> replicas;
     s4g_db* cached;
+    // chainDatabaseCreateFlat: the part's four arrays (borrowed), a placeholder chain per record (length only) that `chains` points
+    // at, and the real chains made so far (swimpl::real_chain)
+    const char* flat_codes = NULL;
+    const size_t* flat_off = NULL;
+    const char* flat_names = NULL;
+    const size_t* flat_name_off = NULL;
+    std::vector<Chain> stubs;
+    std::vector<Chain*> stub_ptrs;
+    std::vector<Chain*> real;
 };
 
 struct DbAlignment {
@@ -105,6 +114,9 @@ void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc
 
 bool on_pool_thread();             // core.cpp: the calling thread is a worker of the thread pool
 int pool_threads();                // workers of the pool (0: none, tasks run inline)
+
+// the chain of database entry idx that alignments point at: the entry itself, or -- flat databases -- the real chain, built on first use
+Chain* real_chain(ChainDatabase* db, int idx);
 
 // device forms of a ChainDatabase, made on first use (align.cpp)
 bool cached_form_fits(const ChainDatabase* db);

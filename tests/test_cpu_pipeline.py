@@ -101,6 +101,12 @@ def test_device_prefilter_build_on_the_cpu_oracle_reproduces_the_same_outputs(tm
     parts = tmp_path / "parts"
     parts.mkdir()
     assert dropin_synth.run(DEVSEARCH, str(parts), env=dict(env, S4G_PREFILTER_CHUNK_BYTES="30000", S4G_CHUNK_BYTES="30000")) == want
+    # (the runs above align out of the flat parts the prefilter's pass left behind -- one pass over the file, chains only for the
+    # reported targets; the same with the file read a second time into chains, and with a budget too small to keep the parts)
+    for k, extra in enumerate((dict(S4G_READ_DATABASE_TWICE="1"), dict(S4G_FLAT_DB_BYTES="20000", S4G_PREFILTER_CHUNK_BYTES="30000"))):
+        d = tmp_path / f"twice{k}"
+        d.mkdir()
+        assert dropin_synth.run(DEVSEARCH, str(d), env=dict(env, **extra)) == want
 
 
 FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
