@@ -191,6 +191,10 @@ SW_API EValueParams* createEValueParams(long long length, Scorer* scorer) {
     }
     const GumbelRow& g = tab->rows[row];
     const GumbelRow& u = tab->rows[0];
+    if (getenv("S4G_PROFILE"))      // which published row this scorer's statistics come from (the lookup convention is a switch, see above)
+        fprintf(stderr, "[s4g profile] e-value statistics: matrix %s, gap penalties %d/%d looked up %s (%s convention) -> row %d/%d%s: lambda %.4f K %.4f H %.3f alpha %.2f\n",
+                tab->matrix, scorerGetGapOpen(scorer), extension, blast ? "as existence = open - extend" : "as they are", blast ? "blast" : "swsharp",
+                g.open, g.extension, p->gapped_row_found ? "" : " (no such row: the matrix's default)", g.lambda, g.K, g.H, g.Alpha);
     const double G = (double)(g.open + g.extension);
     p->lambda = g.lambda; p->K = g.K; p->logK = log(g.K); p->H = g.H;
     p->a = g.a; p->alpha = g.Alpha; p->sigma = g.Sigma;
