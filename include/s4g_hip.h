@@ -178,6 +178,9 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */
 #define S4G_SCAN_NO_PAIRS  16u  /* scan kernels only: no group goes to the one-wave-per-pair kernels; any other flag implies this */
 #define S4G_SCAN_NO_SPEC   32u  /* no speculative use of the drifting-frame kernel: tiers by score bound only */
+#define S4G_SCAN_BLOCK_PIPE 64u /* every tile whose queries fit the drifting-frame window runs on the block-cooperative strip pipeline
+                                   (sw_scan_lists in scan mode: the four waves of a block on one (group, query pair) item) whatever the
+                                   query count; by default calls of 3 to 16 queries (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,

@@ -21,6 +21,7 @@ S4G_SCAN_F16_ARITH = 4
 S4G_SCAN_NO_DRIFT = 8
 S4G_SCAN_NO_PAIRS = 16
 S4G_SCAN_NO_SPEC = 32
+S4G_SCAN_BLOCK_PIPE = 64
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)

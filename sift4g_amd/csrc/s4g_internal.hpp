@@ -155,6 +155,7 @@ struct DeviceCtx {
     uint32_t* d_lst_res = nullptr;
     uint64_t lst_res_bytes = 0;
     uint32_t grid_lists = 0;
+    uint32_t grid_pipe = 0;                 // blocks of sw_scan_lists<R, true> the device holds (scan_tile_pipelined)
     uint64_t stat_tier[4] = {0, 0, 0, 0};
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
     // clock samples of the scan launches of the last call (s4g_scan_clock; sw_kernels.hip.h clk_enter / clk_leave): a region of
@@ -270,6 +271,9 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
 // s4g_lists.hip
 int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used);
+// s4g_lists.hip: a tile scanned by a few queries on the block-cooperative strip pipeline (sw_scan_lists<R, true>); *used = false: not applicable
+int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                        int32_t* d_scores, uint64_t stride, const uint32_t* d_perm, hipStream_t stream, bool* used);
 int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                   int32_t* d_scores, uint64_t stride, bool local_cols, hipStream_t stream, uint32_t n_pos);
 uint32_t split_groups(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, uint32_t flags);

@@ -460,3 +460,101 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
     return scope.release();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A database tile scanned by a FEW queries on the block-cooperative strip pipeline (sw_scan_lists<R, true>).
+// The scan kernels give a (group, query pair) item to one wave, and a launch cannot end before the wave that holds the longest
+// group has walked its whole DP (~37 clocks per cell: 16 ms for 350 rows x 3000 columns however idle the chip is); with a
+// thousand queries that tail is nothing, with four it is the launch.  Round 1 answered with a cost model that hands the longest
+// groups to pair waves (split_groups); here the same items go through the list kernel's pipeline instead -- the four waves of a
+// block take the strips of ONE item round-robin, each trailing its predecessor by a 4-column chunk -- so an item's latency is
+// its strips / 4 and no model is needed.  A scan item is a list item whose two halves read the SAME target, each half with a
+// query of its own: residues straight out of the tile (no gather), scores straight into the caller's matrix.
+// *used = false: not applicable (a query outside the drifting-frame window, a tile of very long sequences); nothing was launched.
+int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
+                        int32_t* d_scores, uint64_t stride, const uint32_t* d_perm, hipStream_t stream, bool* used) {
+    *used = false;
+    if (!q_count || !t.n_groups || t.h_grp_off.size() < t.n_groups) return S4G_OK;
+    if (!(scorer->open < 32768 && scorer->ext < 32768) || (uint64_t)t.max_len4 * 4 > kListMaxTarget) return S4G_OK;
+    ensure_bounds(q, scorer);
+    const uint64_t cap = 0x7BFF;
+    const uint64_t bias = (uint64_t)std::max(std::max(-kPadScore, -scorer->min_score), std::max(scorer->open, 2 * scorer->ext));
+    // query pairs: neighbours in length order (an item runs to the longer one)
+    std::vector<uint32_t> order(q_count);
+    for (uint32_t i = 0; i < q_count; ++i) order[i] = q_begin + i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
+    const uint64_t cols = (uint64_t)t.max_len4 * 4 + 8;
+    for (uint32_t i = 0; i < q_count; ++i) {
+        const uint32_t longer = order[i & ~1u];
+        if (q->len[order[i]] == 0) return S4G_OK;
+        if (q->score_bound[order[i]] + bias + ((uint64_t)q->len[longer] + 2 * kListRows + cols) * (uint64_t)scorer->ext > cap) return S4G_OK;
+    }
+    const uint32_t n_pairs = (q_count + 1) / 2;
+    const uint64_t n_items64 = (uint64_t)t.n_groups * n_pairs;
+    if (n_items64 > (1u << 22)) return S4G_OK;
+    const uint32_t n_items = (uint32_t)n_items64;
+
+    DeviceCtx* cx = device_ctx(db->device);
+    int rc = device_props(cx);
+    if (rc) return rc;
+    rc = ensure_max3(cx);
+    if (rc) return rc;
+    const uint64_t b_items = align256((uint64_t)n_items * sizeof(ListItem));
+    if (cx->lst_stage_bytes < b_items) {
+        if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+        if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
+        cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
+        const uint64_t want = std::max<uint64_t>(b_items + b_items / 4, 1u << 20);
+        HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, want, hipHostMallocDefault));
+        cx->lst_stage_bytes = want;
+    } else if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+    if (!cx->lst_stage_done) HIP_TRY(hipEventCreateWithFlags(&cx->lst_stage_done, hipEventDisableTiming));
+    if (cx->lst_bytes < b_items) {
+        if (cx->d_lst) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst)); }
+        cx->d_lst = nullptr; cx->lst_bytes = 0;
+        const uint64_t want = std::max<uint64_t>(b_items + b_items / 4, 1u << 20);
+        HIP_TRY(hipMalloc((void**)&cx->d_lst, want));
+        cx->lst_bytes = want;
+    }
+    ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage);
+    uint32_t at = 0;
+    for (uint32_t g = 0; g < t.n_groups; ++g) {                 // groups are in length order: the longest items start first
+        const uint64_t end = g + 1 < t.n_groups ? t.h_grp_off[g + 1] : t.padded_residues / 4;
+        const uint32_t len4 = (uint32_t)((end - t.h_grp_off[g]) / 64);
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            ListItem it;
+            it.qa = order[2 * p]; it.qb = 2 * p + 1 < q_count ? order[2 * p + 1] : order[2 * p];
+            it.first_a = g; it.first_b = 0; it.na = 64; it.nb = 64; it.len4 = len4; it.res_off = t.h_grp_off[g];
+            h_items[at++] = it;
+        }
+    }
+    if (cx->grid_pipe == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, true>, kBlock, 0));
+        cx->grid_pipe = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(cx->grid_pipe, n_items));
+    const uint64_t ws_slot = 2ull * std::max(1u, t.max_len4) * 64 * 4;
+    const uint64_t ws_bytes = ws_slot * 4 * kListBufs * grid;
+    if (cx->ws_bytes < ws_bytes) {
+        if (cx->d_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_ws)); }
+        cx->d_ws = nullptr; cx->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_ws, ws_bytes));
+        cx->ws_bytes = ws_bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(cx->d_lst, h_items, (size_t)n_items * sizeof(ListItem), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(cx->lst_stage_done, stream));
+    HIP_TRY(hipMemsetAsync(cx->d_counter + kListCounter, 0, 4, stream));
+    ListArgs a;
+    a.items = reinterpret_cast<const ListItem*>(cx->d_lst); a.res = t.d_res; a.entries = nullptr;
+    a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+    a.scores = nullptr; a.ws = cx->d_ws; a.ws_slot = ws_slot; a.counter = cx->d_counter + kListCounter; a.n_items = n_items;
+    a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.floor_bits = (uint32_t)(bias | (bias << 16));
+    a.prio_cost = 0;        // (raised wave priority for the longest items was measured: no change -- their latency is their own strips', not their neighbours')
+    a.grp_perm = d_perm; a.scan_scores = d_scores; a.score_stride = stride; a.q_begin = q_begin;
+    hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    *used = true;
+    return S4G_OK;
+}

@@ -468,6 +468,12 @@ S4G_API int s4g_scan_clock(int device, double* out, uint32_t cap) {
     return S4G_OK;
 }
 
+// the largest query count the block-pipelined route takes by default (S4G_SCAN_PIPE_MAX_QUERIES overrides; 0 turns the route off)
+static uint32_t pipe_max_queries() {
+    static const uint32_t v = []() { const char* e = getenv("S4G_SCAN_PIPE_MAX_QUERIES"); return e ? (uint32_t)std::max(0, atoi(e)) : 16u; }();
+    return v;
+}
+
 int check_scan_args(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t q_begin, uint32_t q_count) {
     if (!db || !q || !scorer) return fail(S4G_ERR_INVALID, "NULL argument");
     if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
@@ -537,6 +543,37 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         any_pairs = any_pairs || g0s[ti] != 0;
     }
     ScratchScope scope(db, stream);
+    // A few queries against a big database: the block-cooperative strip pipeline (s4g_lists.hip, scan_tile_pipelined) -- no
+    // launch tail behind a lone wave that walks the longest group.  Taken when the call asks for it, or by default for 3 to
+    // pipe_max_queries() queries when the call is not small enough for the all-pairs route below.  Measured, 100 000 targets of
+    // the bench distribution, ms per call, pipeline | split model (profiles/r03_scan_latency.txt):
+    //   1 query 5.5 | 2.6-3.7    2: 5.6 | 3.6    3: 5.7 | 6.3    4: 5.7 | 6.5    6: 6.8 | 8.6    8: 8.8 | 10.4    12: 13.1 | 13.5    16: 17.1 | 17.2    32: 34.5 | 33.9
+    // (one or two queries: the longest group is 5 ms of four waves whatever else happens, and only the pair waves spread it over CUs)
+    const bool want_pipe = (flags & S4G_SCAN_BLOCK_PIPE) != 0 ||
+                           (flags == 0 && q_count >= 3 && q_count <= pipe_max_queries() && !(all_pairs && any_pairs) && db->n_seqs >= 256u * 64u);
+    flags &= ~S4G_SCAN_BLOCK_PIPE;
+    if (want_pipe) {
+        rc = scope.acquire();
+        if (rc) return rc;
+        rc = stats_begin(cx, stream);
+        if (rc) return rc;
+        rc = ensure_mat(cx, scorer, stream);
+        if (rc) return rc;
+        size_t refused = 0;
+        for (size_t ti = 0; ti < db->tiles.size() && !refused; ++ti) {
+            const Tile& t = db->tiles[ti];
+            if (!t.n_seqs) continue;
+            bool used = false;
+            rc = scan_tile_pipelined(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, t.d_perm_global, stream, &used);
+            if (rc) return rc;
+            if (used) { cx->stat_list_pairs += (uint64_t)q_count * t.n_seqs; } else ++refused;
+        }
+        if (!refused) return scope.release();
+        // a tile the pipeline does not take (a query beyond the drifting-frame window): the general route scores the whole call,
+        // behind whatever was launched above on the same stream
+        rc = scope.release();
+        if (rc) return rc;
+    }
     if (all_pairs && any_pairs) {       // nothing for the scan kernels: one submission, no plan, no strip workspace
         rc = scope.acquire();
         if (rc) return rc;

@@ -55,6 +55,13 @@ struct ListArgs {
     uint32_t n_items;
     uint32_t open, ext, floor_bits;
     uint32_t prio_cost;
+    // SCAN mode (sw_scan_lists<R, true>: a database tile scanned by a few queries, s4g_lists.hip scan_tile_pipelined): an item is
+    // (group first_a of the tile, queries qa / qb), `res` the tile's residues, res_off the group's offset; both halves of a lane
+    // read the SAME target
+    const uint32_t* __restrict__ grp_perm;      // [G * 64] output column of (group, lane); ~0u = empty lane
+    int32_t* __restrict__ scan_scores;          // [query - q_begin][score_stride]
+    uint64_t score_stride;
+    uint32_t q_begin;
 };
 
 // items[i].len4 and the item's size in dwords (input of the exclusive scan that yields res_off)
@@ -143,9 +150,10 @@ constexpr unsigned kListPublishEvery = 1;     // chunks between two publications
 constexpr int kListBufs = 4;             // workspace buffers (and best-score rows) per block: item k uses buffer k % 4; a wave may
                                          // run at most 3 items ahead of the slowest wave of its block
 
+template <int W>
 struct ListSync {
-    unsigned long long prog[kWavesPerBlock];   // (strip number + 1) << 32 | chunks finished, per wave
-    unsigned cur[kWavesPerBlock];              // item (position in the block's stream) a wave is working on
+    unsigned long long prog[W];                // (strip number + 1) << 32 | chunks finished, per wave
+    unsigned cur[W];                           // item (position in the block's stream) a wave is working on
     unsigned fetched;                          // items in the ring
     unsigned lock;
     ListItem ring[kListRing];
@@ -161,7 +169,7 @@ __device__ __forceinline__ unsigned lds_load32(const unsigned* p) {
 
 // One strip of RR rows over all columns of the item; res points at the item's block + lane (low half; high half 64 dwords on).
 // prod: progress word of the wave that owns the strip above (FIRST: unused), need_tag = that strip's tag; mine / my_tag: this wave's.
-template <int R, int RR, bool FIRST>
+template <int R, int RR, bool FIRST, bool SCAN>
 __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
                                           bool last, int& best, int eo, int e2, int zrow0,
                                           const unsigned long long* prod, unsigned long long need_tag,
@@ -186,7 +194,8 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
             }
         }
     };
-    uint32_t ra_n = res[0], rb_n = res[64];
+    constexpr unsigned kStride = SCAN ? 64u : 128u;          // dwords per 4-column chunk of the item's block
+    uint32_t ra_n = res[0], rb_n = SCAN ? ra_n : res[64];
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
     if (!first && len4) { wait_for(1); hb_n = wsH[lane]; fb_n = wsF[lane]; }
     v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(profb, pk_taddr(rb_n, 0), 0);
@@ -194,8 +203,8 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
         const uint32_t ra = ra_n, rb = rb_n;
         const v4i hb = hb_n, fb = fb_n;
         const unsigned cn = (c + 1 < len4) ? c + 1 : c;
-        ra_n = res[(uint64_t)cn * 128];
-        rb_n = res[(uint64_t)cn * 128 + 64];
+        ra_n = res[(uint64_t)cn * kStride];
+        rb_n = SCAN ? ra_n : res[(uint64_t)cn * kStride + 64];
         if (!first) { wait_for(cn + 1); hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
         v4i ho, fo;
 #pragma unroll
@@ -232,19 +241,25 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
     }
 }
 
-template <int R>
+// SCAN: a database tile scanned by a few queries (s4g_lists.hip, scan_tile_pipelined) -- an item is one group of the tile under a
+// PAIR OF QUERIES: both halves read the same residues, in place (64 dwords per chunk), and the maxima go straight into the score
+// matrix.  (Twelve waves to a block, one block to a CU -- every strip of a 350-row query on a wave of its own -- were measured too:
+// the longest group of the bench tile, 11 strips x 3000 columns x 64 lanes, is 2.7 ms of ONE CU's issue slots however its strips
+// are spread; that form reached 3.8 ms for it against 5.2 ms here, but only 8.9 TCUPS once the chip is full against 10.9.)
+template <int R, bool SCAN = false>
 __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
-    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 256];
-    __shared__ ListSync sy;
+    constexpr int W = kWavesPerBlock, kThreads = kBlock;
+    __shared__ __attribute__((aligned(16))) char lds[1024 + W * R * 256];
+    __shared__ ListSync<W> sy;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     signed char* lmat = reinterpret_cast<signed char*>(lds);
     char* prof = lds + 1024 + wave * (R * 256);        // PA then PB, each [R/4 blocks][32 residues][4 rows x int32]
-    for (int i = threadIdx.x; i < 256; i += kBlock)
+    for (int i = threadIdx.x; i < 256; i += kThreads)
         reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
-    for (int i = threadIdx.x; i < kListBufs * 128; i += kBlock) (&sy.best[0][0])[i] = 0;
-    if (threadIdx.x < kWavesPerBlock) { sy.prog[threadIdx.x] = 0; sy.cur[threadIdx.x] = 0; }
+    for (int i = threadIdx.x; i < kListBufs * 128; i += kThreads) (&sy.best[0][0])[i] = 0;
+    if (threadIdx.x < W) { sy.prog[threadIdx.x] = 0; sy.cur[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { sy.fetched = 0; sy.lock = 0; }
     __syncthreads();
 
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     asm volatile("" : "+v"(eo));                       // ... in a VGPR: the two-VGPR v_add_u32 issues a little faster (tools/valu_issue.hip)
     const int B2 = (int)a.floor_bits;
     const int two_e = 2 * (int)a.ext;
-    const int prev_wave = (wave + kWavesPerBlock - 1) % kWavesPerBlock;
+    const int prev_wave = (wave + W - 1) % W;
 
     // item k of this block's stream (fetched from the global queue by whichever wave needs it first); n == 0: end of the queue
     auto get_item = [&](unsigned k) -> ListItem {
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     ListItem it = get_item(0);
     unsigned lq = item_rows(it);
     unsigned nstrips = (lq + R - 1) / R;
-    for (unsigned g = (unsigned)wave;; g += kWavesPerBlock) {
+    for (unsigned g = (unsigned)wave;; g += W) {
         while (it.na && g >= base + nstrips) {
             base += nstrips;
             ++k;
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
         // workspace buffer and best row k % 4 were last used by item k - 4: wait until no wave of the block is still there
         if (lane == 0) __hip_atomic_store(&sy.cur[wave], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k >= kListBufs - 1) {
-            for (int w = 0; w < kWavesPerBlock; ++w)
+            for (int w = 0; w < W; ++w)
                 while (lds_load32(&sy.cur[w]) + (kListBufs - 1) < k) __builtin_amdgcn_s_sleep(1);
         }
         const unsigned buf = k % kListBufs;
@@ -361,16 +376,16 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
 #define S4G_LAST_STRIP(RR_)                                                                                  \
         if constexpr (R > RR_) {                                                                             \
             if (!done && rr == RR_) {                                                                        \
-                if (first) lst_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag); \
-                else lst_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);    \
+                if (first) lst_strip<R, RR_, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag); \
+                else lst_strip<R, RR_, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);    \
                 done = true;                                                                                 \
             }                                                                                                \
         }
         S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
 #undef S4G_LAST_STRIP
         if (!done) {
-            if (first) lst_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
-            else lst_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
+            if (first) lst_strip<R, R, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
+            else lst_strip<R, R, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
         }
         // merge this strip's maximum into the item's, THEN publish the strip as finished: the wave that ends the item's last strip
         // has seen every strip above finished (each waited for its predecessor's last chunk), so the row is complete for it
@@ -390,8 +405,16 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
                 sy.best[buf][2 * lane] = 0;
                 sy.best[buf][2 * lane + 1] = 0;
             }
-            if ((unsigned)lane < it.na) a.scores[(uint32_t)a.entries[it.first_a + lane]] = lo;
-            if ((unsigned)lane < it.nb) a.scores[(uint32_t)a.entries[it.first_b + lane]] = hi;
+            if constexpr (SCAN) {
+                const unsigned p = a.grp_perm[(uint64_t)it.first_a * 64 + lane];
+                if (p != 0xFFFFFFFFu) {
+                    a.scan_scores[(uint64_t)(it.qa - a.q_begin) * a.score_stride + p] = lo;
+                    if (it.qb != it.qa) a.scan_scores[(uint64_t)(it.qb - a.q_begin) * a.score_stride + p] = hi;
+                }
+            } else {
+                if ((unsigned)lane < it.na) a.scores[(uint32_t)a.entries[it.first_a + lane]] = lo;
+                if ((unsigned)lane < it.nb) a.scores[(uint32_t)a.entries[it.first_b + lane]] = hi;
+            }
         }
     }
     if (lane == 0) __hip_atomic_store(&sy.cur[wave], 0xFFFFFFF0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -29,8 +29,9 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     # without the drift kernel, the f16-arithmetic form of the maximum3 tier, no maximum3 at all, int32 alone
     # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
     # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
-    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True),
-                 dict(force_i32=True, no_drift=True)):
+    # block_pipe: the block-cooperative strip pipeline (sw_scan_lists in scan mode) wherever the queries fit its window
+    for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
+                 dict(force_i32=True), dict(force_i32=True, no_drift=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
         assert bad.size == 0, (f"{mode}: {len(bad)} mismatches, first {bad[:5].tolist()} "
@@ -415,8 +416,9 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
             assert len(tiles) >= 11 and tiles[0] == 2          # the two > 12288-residue sequences form their own tile (side stream)
         # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
     # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
-    for mode in (dict(), dict(no_pairs=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True), dict(force_i32=True),
-                 dict(force_i32=True, no_drift=True)):
+    # block_pipe: the block-cooperative strip pipeline (sw_scan_lists in scan mode) wherever the queries fit its window
+    for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
+                 dict(force_i32=True), dict(force_i32=True, no_drift=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
 
@@ -1190,9 +1192,11 @@ def test_long_tile_pair_route_inside_a_large_scan(s4g, oracle_mod, blosum62, sco
 
 
 def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
-    """a few queries against 20k targets with a long-tailed length distribution: s4g_scan gives the longest groups of the
-    tile to pair waves and the rest to the scan kernels; the matrix equals the scan kernels' and the oracle's, for several
-    query counts (different split points) and through the streaming top-k."""
+    """a few queries against 20k targets with a long-tailed length distribution: one or two queries -- s4g_scan gives the
+    longest groups of the tile to pair waves and the rest to the scan kernels (as the streaming top-k does for any count);
+    three to eight -- the whole call runs on the block-cooperative strip pipeline (sw_scan_lists in scan mode).  The matrix
+    equals the scan kernels' and the oracle's, for several query counts (different split points), the pipeline also forced."""
+    from sift4g_amd import device
     rng = np.random.default_rng(42)
     lens = np.clip(np.exp(rng.normal(5.6, 0.6, size=20000)), 20, 3000).astype(int)
     ts = [rand_seqs(rng, 1, int(l), int(l), 26)[0] for l in lens]
@@ -1205,9 +1209,20 @@ def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
     if exp is None:
         exp = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, 10, 1, threads=8)
     q = s4g.QuerySet(qs)
-    for nq in (1, 2, 4, 6):
+    for nq in (1, 2, 3, 4, 6):
         assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=0, q_count=nq), exp[:nq]), nq
+        st = device.scan_stats(0)
+        assert st["list_pairs"] == (nq * len(ts) if nq >= 3 else 0), st      # 3..8 queries: the whole call on the list kernel's pipeline
         assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=0, q_count=nq, no_pairs=True), exp[:nq]), nq
+        assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=6 - nq, q_count=nq, block_pipe=True), exp[6 - nq:]), nq
+    # a query beyond the drifting-frame window: the pipeline refuses the tile and the general route scores the call
+    long_q = rand_seqs(rng, 1, 6000, 6000, 20) + qs[:2]
+    ql = s4g.QuerySet(long_q)
+    sub = ts[:4000]
+    dbs = s4g.Database(sub)
+    exp_l = oracle_mod.scan(long_q, sub, blosum62, 10, 1, threads=8)
+    assert np.array_equal(s4g.scan_host(dbs, ql, scorer, block_pipe=True), exp_l)
+    assert device.scan_stats(0)["list_pairs"] == 0
     ids, sc, cnt = s4g.scan_topk(db, q, scorer, 30, 1)
     ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
     for i in range(len(qs)):

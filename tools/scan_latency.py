@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time of one s4g_scan call for query counts between 1 and a few hundred (where launches are latency-bound): the library's
-routing (scan kernels / one wave per pair / a split of each tile between the two) against the scan kernels alone.
+routing (block-cooperative strip pipeline / scan kernels / one wave per pair / a split of each tile between the last two;
+S4G_SCAN_PIPE_MAX_QUERIES=0 takes the pipeline out of it) against the pipeline forced and the scan kernels alone.
 usage: tools/scan_latency.py [n_targets=100000] [query counts ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,7 @@ for nq in counts:
     out = torch.empty((nq, nt), dtype=torch.int32, device="cuda:0")
     line = f"{nq:4d} queries x {nt} targets:"
     keep = {}
-    for name, kw in (("library routing", {}), ("scan kernels only", dict(no_pairs=True))):
+    for name, kw in (("library routing", {}), ("block pipeline", dict(block_pipe=True)), ("scan kernels only", dict(no_pairs=True))):
         best = 1e9
         for rep in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -30,5 +31,5 @@ for nq in counts:
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         keep[name] = out.clone()
         line += f"  {name} {best * 1e3:8.2f} ms ({cells / best / 1e9:7.0f} GCUPS)"
-    assert torch.equal(keep["library routing"], keep["scan kernels only"])
+    assert torch.equal(keep["library routing"], keep["scan kernels only"]) and torch.equal(keep["block pipeline"], keep["scan kernels only"])
     print(line)
