@@ -45,14 +45,15 @@ DeviceCtx* device_ctx(int device) {
 }
 
 // ---------------------------------------------------------------------------
-// Persistent host workers for parallel_for (s4g_internal.hpp): 7 threads started on first use, woken per job, joined when the
+// Persistent host workers for parallel_for (s4g_internal.hpp): up to 15 threads (one less than the host's cores) started on first use, woken per job, joined when the
 // library is unloaded.  One job at a time (callers hold no lock they could deadlock on: jobs are pure host loops).
 namespace {
 struct HostPool {
-    static constexpr unsigned kWorkers = 7;
+    static constexpr unsigned kMaxWorkers = 15;
+    unsigned n_workers = 0;
     std::mutex mu, job_mu;
     std::condition_variable wake, done_cv;
-    std::thread th[kWorkers];
+    std::thread th[kMaxWorkers];
     bool started = false, quit = false;
     uint64_t generation = 0;
     unsigned parts = 0, remaining = 0;
@@ -81,12 +82,17 @@ struct HostPool {
         std::lock_guard<std::mutex> job(job_mu);
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (!started) { for (unsigned w = 0; w < kWorkers; ++w) th[w] = std::thread(&HostPool::worker, this, w); started = true; }
-            fn = f; ctx = c; parts = n_parts; remaining = kWorkers;
+            if (!started) {
+                n_workers = std::max(1u, std::min(kMaxWorkers, std::max(2u, std::thread::hardware_concurrency()) - 1));
+                for (unsigned w = 0; w < n_workers; ++w) th[w] = std::thread(&HostPool::worker, this, w);
+                started = true;
+            }
+            fn = f; ctx = c; parts = n_parts; remaining = n_workers;
             ++generation;
         }
         wake.notify_all();
         f(c, 0);
+        for (unsigned p = n_workers + 1; p < n_parts; ++p) f(c, p);          // (more parts than threads: the caller takes the rest)
         std::unique_lock<std::mutex> lk(mu);
         done_cv.wait(lk, [&] { return remaining == 0; });
     }
@@ -99,7 +105,6 @@ struct HostPool {
 }  // namespace
 
 void host_pool_run(unsigned parts, void (*fn)(void* ctx, unsigned part), void* ctx) {
-    if (parts > HostPool::kWorkers + 1) parts = HostPool::kWorkers + 1;
     g_host_pool.run(parts, fn, ctx);
 }
 
@@ -601,6 +606,7 @@ S4G_API int s4g_db_destroy(s4g_db* db) {
     for (Tile& t : db->tiles) free_tile(t, device_ctx(db->device));
     if (db->cached) chain_cache_release(db);
     else if (!db->seq_tables_in_block) { (void)hipFree(db->d_seq_addr); (void)hipFree(db->d_seq_len); }
+    if (db->d_pos_of_id) (void)hipFree(db->d_pos_of_id);
     delete db;
     return S4G_OK;
 }

@@ -84,6 +84,7 @@ struct s4g_db {
     // per-sequence tables for the pair kernels (built on first use, under the device mutex)
     mutable uint64_t* d_seq_addr = nullptr;     // [n_seqs] device address of the sequence's first residue dword
     mutable uint32_t* d_seq_len = nullptr;      // [n_seqs]
+    mutable uint32_t* d_pos_of_id = nullptr;    // [n_seqs] pos_of_id on the device (built by the first list call, s4g_lists.hip)
     mutable std::vector<uint32_t> id_of_pos;    // position in the length-sorted order -> original index
     bool seq_tables_in_block = false;           // d_seq_addr / d_seq_len are part of tiles[0].d_block (or of d_cached_block)
     // s4g_db_create_cached (s4g_chains.hip): no tiles -- the sequences live in the device's chain arena, the database is its two
@@ -202,9 +203,9 @@ constexpr uint32_t kLongSeq = 12288;                   // sequences longer than 
 // small persistent pool (s4g_core.hip): starting a std::thread costs ~100 us on the GPU box, as much as the work of a part.
 inline unsigned parallel_parts(uint64_t n, uint64_t min_per_part) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(hw, 8u), n / std::max<uint64_t>(1, min_per_part)));
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(hw, 16u), n / std::max<uint64_t>(1, min_per_part)));
 }
-void host_pool_run(unsigned parts, void (*fn)(void* ctx, unsigned part), void* ctx);     // parts <= 8; part 0 runs on the caller
+void host_pool_run(unsigned parts, void (*fn)(void* ctx, unsigned part), void* ctx);     // parts <= 16; part 0 runs on the caller
 template <class F>
 inline void parallel_for(uint64_t n, unsigned parts, F f) {
     if (parts <= 1) { f(0u, 1u, (uint64_t)0, n); return; }

@@ -24,6 +24,7 @@ constexpr double kListCyclesPerRowCol = 20.0, kListCyclesPerQueuedItem = 5.5, kC
 constexpr double kListItemsToFill = 700.0;
 constexpr double kListFixedCost = 250e-6;            // sort + item tables + gather + one host round trip
 constexpr uint32_t kListPairSlack = 64;              // two queries share an item (one per register half) when their lengths differ by no more than this
+constexpr uint64_t kListResBoundBytes = 2ull << 30;  // gathered residues: up to this much is allocated by the worst case instead of asking the device
 constexpr uint32_t kListMaxTarget = 4096;            // longer targets always go to the pair waves: the block workspace is 2 KB per residue
                                                      // of the longest member and block (6.4 GB at 4096 residues on 768 blocks)
 
@@ -133,6 +134,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     uint32_t lt_max = 0, lq_max = 0;
     double cells_all = 0, rows_all = 0;
     const unsigned parts = parallel_parts(n_sel, 1u << 16);
+    // (a large call is estimated from every 8th pair: the estimate only picks the split length, any split gives the same scores;
+    // the longest target of the call is then not known exactly -- lt_hi, what bounds the workspace, falls back to the database's)
+    const uint32_t stride = n_sel >= (1u << 17) && !getenv("S4G_LISTS_FULL_HISTOGRAM") ? 8u : 1u;
     {
         struct Part { std::vector<double> cells; std::vector<uint32_t> pairs; uint32_t lt_max = 0, lq_max = 0; double cells_all = 0, rows_all = 0; };
         std::vector<Part> part(parts);
@@ -142,17 +146,17 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
             std::vector<uint32_t> pairs(n_buckets, 0);
             uint32_t my_lt = 0, my_lq = 0;
             double my_cells = 0, my_rows = 0;
-            for (uint64_t i = b; i < e; ++i) {
+            for (uint64_t i = (b + stride - 1) / stride * stride; i < e; i += stride) {
                 const uint32_t pi = sel[(uint32_t)i];
                 const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi], lq = q->len[qi];
-                const double c = (double)lq * lt;
+                const double c = (double)lq * lt * stride;
                 my_lt = std::max(my_lt, lt);
                 my_lq = std::max(my_lq, lq);
                 my_cells += c;
-                my_rows += lq;
+                my_rows += (double)lq * stride;
                 if (lt == 0 || lt > lt_cap[qi]) continue;
                 cells[lt / 64] += c;
-                ++pairs[lt / 64];
+                pairs[lt / 64] += stride;
             }
             Part& P = part[p];
             P.cells.swap(cells); P.pairs.swap(pairs);
@@ -164,6 +168,8 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
             for (size_t b = 0; b < n_buckets; ++b) { cells_le[b] += P.cells[b]; pairs_in[b] += P.pairs[b]; }
         }
     }
+    if (stride > 1) for (uint32_t i = 0; i < q->n; ++i) lq_max = std::max(lq_max, q->len[i]);      // (an upper bound is all the estimate needs)
+    const uint32_t lt_hi = stride > 1 ? lt_db : lt_max;
     ListHist hist;
     hist.cells_all = cells_all; hist.lq_max = lq_max; hist.lt_max = lt_max;
     hist.cells_le = cells_le; hist.pad_le.assign(n_buckets, 0.0); hist.pairs_le.assign(n_buckets, 0.0);
@@ -182,43 +188,16 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     uint32_t best_ls = 0;
     double best_t = lists_cost(hist, 0);
     const double all_waves = best_t;
-    for (uint32_t ls = 127; ls < std::min(lt_max, kListMaxTarget) + 64; ls += 64) {
+    for (uint32_t ls = 127; ls < std::min(lt_hi, kListMaxTarget) + 64; ls += 64) {
         const double t = lists_cost(hist, ls);
         if (t < best_t) { best_t = t; best_ls = ls; }
     }
-    if (force) best_ls = forced_split ? forced_split : std::max(lt_max, 1u);      // everything the window admits (up to the caller's cut)
+    if (force) best_ls = forced_split ? forced_split : std::max(lt_hi, 1u);      // everything the window admits (up to the caller's cut)
     else if (best_ls == 0 || best_t > 0.9 * all_waves) return S4G_OK;       // the pair kernels take it all
     best_ls = std::min(best_ls, kListMaxTarget);
 
     const auto t_h = now();
-    // ---- one pass: which pairs go where, and per query how many list entries ----
-    static thread_local std::vector<uint32_t> wave_sel;
-    wave_sel.clear();
-    std::vector<uint32_t> count(q->n + 1, 0);
-    uint32_t n = 0;
-    std::vector<uint32_t> part_lists(parts, 0);                         // list entries found by each part, in order
-    {
-        std::vector<std::vector<uint32_t>> part_wave(parts), part_count(parts);
-        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
-            std::vector<uint32_t>& cnt = part_count[p];
-            cnt.assign(q->n + 1, 0);
-            uint32_t mine = 0;
-            for (uint64_t i = b; i < e; ++i) {
-                const uint32_t pi = sel[(uint32_t)i];
-                const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
-                if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { ++mine; ++cnt[qi + 1]; } else part_wave[p].push_back(pi);
-            }
-            part_lists[p] = mine;
-        });
-        for (unsigned p = 0; p < parts; ++p) {
-            n += part_lists[p];
-            wave_sel.insert(wave_sel.end(), part_wave[p].begin(), part_wave[p].end());
-            for (uint32_t i = 0; i <= q->n; ++i) count[i] += part_count[p][i];
-        }
-    }
-    if (n == 0) return S4G_OK;
-    *used = true;
-    const auto t_c = now();
+    *used = true;                           // (from here on the call is the list route's; a call without a single list entry is caught below)
 
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
@@ -236,26 +215,137 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     if (rc) return rc;
     rc = ensure_max3(cx);
     if (rc) return rc;
+    if (!cx->side_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(cx->side_fork, stream));            // where the pair waves of this call may start: before anything below is queued
 
-    // ---- the long / ineligible pairs start first, on the side stream, as pair waves ----
-    static thread_local std::vector<uint32_t> wave_where;
-    int32_t* d_wave_sc = nullptr;
-    if (!wave_sel.empty()) {
-        if (!cx->side_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+    // ---- the device starts on the raw pairs while the host is still sorting them out ----
+    // The entries (key = query, rank of the target in the database's length order; value = target, position in sel) are made on
+    // the device: the host sends 8 bytes per pair instead of 16 and writes nothing per pair but a copy.  A pair that stays with
+    // the pair waves gets the key (q->n, 0): the sort leaves those behind the last query's list.  Upload, entries and sort
+    // (~0.6 ms for 729k pairs) run underneath the host's classification pass and the submission of the pair waves (~0.45 ms).
+    const uint32_t max_items = n_sel / 64 + 2 * q->n + 2;               // (every unit ends with at most two short items)
+    const uint64_t b_keys = align256((uint64_t)n_sel * 8), b_items = align256((uint64_t)max_items * sizeof(ListItem));
+    const uint64_t b_cap = align256((uint64_t)q->n * 4), b_raw = align256((uint64_t)n_sel * 4);
+    const uint64_t stage_bytes = b_cap + 2 * b_raw + b_items;          // lt_cap, pair queries, pair targets (first upload); items (second)
+    { const auto ta = now();
+    const uint64_t stage_need = std::max<uint64_t>(stage_bytes, 2 * (uint64_t)n_sel * 4 + 256);         // (the scores come back through it)
+    if (cx->lst_stage_bytes < stage_need) {
+        if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
+        cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
+        const uint64_t want = stage_need + stage_need / 4;
+        HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, want, hipHostMallocDefault));
+        cx->lst_stage_bytes = want;
+    } else if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
+    t_alloc += us(ta, now()); }
+    if (!cx->lst_stage_done) HIP_TRY(hipEventCreateWithFlags(&cx->lst_stage_done, hipEventDisableTiming));
+    uint32_t* h_cap = reinterpret_cast<uint32_t*>(cx->h_lst_stage);
+    uint32_t* h_pq = reinterpret_cast<uint32_t*>(cx->h_lst_stage + b_cap);
+    uint32_t* h_pt = reinterpret_cast<uint32_t*>(cx->h_lst_stage + b_cap + b_raw);
+    ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage + b_cap + 2 * b_raw);
+    memcpy(h_cap, lt_cap.data(), (size_t)q->n * 4);
+    parallel_for(n_sel, parts, [&](unsigned, unsigned, uint64_t b, uint64_t e) {
+        if (!sel.idx) {
+            memcpy(h_pq + b, pair_q + b, (size_t)(e - b) * 4);
+            memcpy(h_pt + b, pair_t + b, (size_t)(e - b) * 4);
+        } else for (uint64_t i = b; i < e; ++i) { const uint32_t pi = sel.idx[i]; h_pq[i] = pair_q[pi]; h_pt[i] = pair_t[pi]; }
+    });
+    int q_bits = 1, pos_bits = 1;
+    while (q_bits < 31 && (1ull << q_bits) <= q->n) ++q_bits;          // (the key q->n of the pairs that are not list entries included)
+    while (pos_bits < 32 && (1ull << pos_bits) < db->n_seqs) ++pos_bits;        // the sort's passes go with the bits: no more of them than the key has
+    size_t cub_sort = 0, cub_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint64_t*)nullptr,
+                                               (uint64_t*)nullptr, (int)n_sel, 0, pos_bits + q_bits, stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)max_items, stream));
+    const uint64_t b_cub = align256(std::max(cub_sort, cub_scan)), b_dw = align256((uint64_t)max_items * 8), b_sc = align256((uint64_t)n_sel * 4);
+    const uint64_t need = stage_bytes + 4 * b_keys + 2 * b_dw + b_sc + b_cub;
+    { const auto ta = now();
+    if (cx->lst_bytes < need) {
+        if (cx->d_lst) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst)); }
+        cx->d_lst = nullptr; cx->lst_bytes = 0;
+        const uint64_t want = need + need / 4;
+        HIP_TRY(hipMalloc((void**)&cx->d_lst, want));
+        cx->lst_bytes = want;
+    }
+    if (!db->d_pos_of_id) {                 // the length rank of every sequence, for the entries' keys (once per database)
+        HIP_TRY(hipMalloc((void**)&db->d_pos_of_id, (size_t)db->n_seqs * 4));
+        HIP_TRY(hipMemcpy(db->d_pos_of_id, db->pos_of_id.data(), (size_t)db->n_seqs * 4, hipMemcpyHostToDevice));
+    }
+    t_alloc += us(ta, now()); }
+    ListBuffers B;
+    char* p = cx->d_lst;
+    const uint32_t* d_cap = (const uint32_t*)p; p += b_cap;                            // the staging buffer's layout
+    const uint32_t* d_pq = (const uint32_t*)p; p += b_raw;
+    const uint32_t* d_pt = (const uint32_t*)p; p += b_raw;
+    B.items = (ListItem*)p; p += b_items;
+    B.keys_in = (uint64_t*)p; p += b_keys; B.vals_in = (uint64_t*)p; p += b_keys;
+    B.keys_out = (uint64_t*)p; p += b_keys; B.vals_out = (uint64_t*)p; p += b_keys;
+    B.dwords = (uint64_t*)p; p += b_dw; B.offs = (uint64_t*)p; p += b_dw;
+    B.scores = (int32_t*)p; p += b_sc;
+    B.cub = p; B.cub_bytes = b_cub;
+    HIP_TRY(hipMemcpyAsync(cx->d_lst, cx->h_lst_stage, b_cap + 2 * b_raw, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(list_entries, dim3((n_sel + 255) / 256), dim3(256), 0, stream, d_pq, d_pt, n_sel, db->d_seq_len, db->d_pos_of_id, d_cap,
+                       best_ls, q->n, (uint32_t)pos_bits, B.keys_in, B.vals_in);
+    size_t tmp = B.cub_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(B.cub, tmp, B.keys_in, B.keys_out, B.vals_in, B.vals_out, (int)n_sel, 0, pos_bits + q_bits, stream));
+    const auto t_c = now();
+
+    // ---- host, meanwhile: which pairs go where, and per query how many list entries ----
+    static thread_local std::vector<uint32_t> wave_sel;
+    wave_sel.clear();
+    std::vector<uint32_t> count(q->n + 1, 0);
+    uint32_t n = 0;
+    {
+        std::vector<std::vector<uint32_t>> part_wave(parts), part_count(parts);
+        std::vector<uint32_t> part_lists(parts, 0);
+        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
+            std::vector<uint32_t>& cnt = part_count[p];
+            cnt.assign(q->n + 1, 0);
+            uint32_t mine = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t t = h_pt[i], qi = h_pq[i];
+                const uint32_t lt = db->len[t];
+                if (lt != 0 && lt <= best_ls && lt <= lt_cap[qi]) { ++mine; ++cnt[qi + 1]; } else part_wave[p].push_back(sel[(uint32_t)i]);
+            }
+            part_lists[p] = mine;
+        });
+        for (unsigned p = 0; p < parts; ++p) {
+            n += part_lists[p];
+            wave_sel.insert(wave_sel.end(), part_wave[p].begin(), part_wave[p].end());
+            for (uint32_t i = 0; i <= q->n; ++i) count[i] += part_count[p][i];
         }
-        HIP_TRY(hipEventRecord(cx->side_fork, stream));
-        HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
-        scope.forked = true;
-        rc = pairs_enqueue(db, q, scorer, wave_sel, pair_q, pair_t, &wave_where, &d_wave_sc, cx->side_stream);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
     }
     const auto t1 = now();
+    static thread_local std::vector<uint32_t> wave_where;
+    int32_t* d_wave_sc = nullptr;
+    auto submit_waves = [&]() -> int {           // the long / ineligible pairs: pair waves on the side stream
+        if (wave_sel.empty()) return S4G_OK;
+        HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
+        scope.forked = true;
+        const int rcw = pairs_enqueue(db, q, scorer, wave_sel, pair_q, pair_t, &wave_where, &d_wave_sc, cx->side_stream);
+        if (rcw) return rcw;
+        HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
+        return S4G_OK;
+    };
+    if (n == 0) { rc = submit_waves(); if (rc) return rc; }
+    const auto t1b = now();
+    if (n == 0) {           // nothing for the list kernel after all (every pair beyond its query's window): the waves have it all
+        HIP_TRY(hipEventRecord(cx->lst_stage_done, stream));
+        if (!wave_sel.empty()) {
+            HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<int32_t> wsc(wave_sel.size());
+            HIP_TRY(hipMemcpy(wsc.data(), d_wave_sc, wsc.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < wave_sel.size(); ++k) h_scores[wave_sel[k]] = wsc[wave_where[k]];
+        }
+        cx->stat_pair_items = wave_sel.size(); cx->stat_list_pairs = 0;
+        return scope.release();
+    }
 
-    // ---- host: entries (key = query, length rank; value = target, local index) and the item table ----
+    // ---- host: the item table ----
     // Units: two queries of nearly the same length walk their lists in step, 64 candidates each per item; a query without such a
     // partner is a unit of its own (items of 128).  Items of block k of every unit come before block k + 1 of any: the longest
     // members of every list start first.
@@ -284,39 +374,8 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
         n_items += blocks;
         max_blocks = std::max(max_blocks, blocks);
     }
+    if (n_items > max_items) return fail(S4G_ERR_INVALID, "internal: %u list items, expected at most %u", n_items, max_items);
     for (uint32_t i = 0; i < q->n; ++i) count[i + 1] += count[i];               // segment offsets in the sorted order
-    const uint64_t b_keys = align256((uint64_t)n * 8), b_items = align256((uint64_t)n_items * sizeof(ListItem));
-    const uint64_t stage_bytes = 2 * b_keys + b_items;          // >= the results that come back through it (4 bytes per pair of the call)
-    { const auto ta = now();
-    const uint64_t stage_need = std::max<uint64_t>(stage_bytes, ((uint64_t)n_sel + wave_sel.size()) * 4 + 256);
-    if (cx->lst_stage_bytes < stage_need) {
-        if (cx->h_lst_stage) HIP_TRY(hipHostFree(cx->h_lst_stage));
-        cx->h_lst_stage = nullptr; cx->lst_stage_bytes = 0;
-        const uint64_t want = stage_need + stage_need / 4;
-        HIP_TRY(hipHostMalloc((void**)&cx->h_lst_stage, want, hipHostMallocDefault));
-        cx->lst_stage_bytes = want;
-    } else if (cx->lst_stage_done) HIP_TRY(hipEventSynchronize(cx->lst_stage_done));
-    t_alloc += us(ta, now()); }
-    if (!cx->lst_stage_done) HIP_TRY(hipEventCreateWithFlags(&cx->lst_stage_done, hipEventDisableTiming));
-    uint64_t* h_keys = reinterpret_cast<uint64_t*>(cx->h_lst_stage);
-    uint64_t* h_vals = reinterpret_cast<uint64_t*>(cx->h_lst_stage + b_keys);
-    ListItem* h_items = reinterpret_cast<ListItem*>(cx->h_lst_stage + 2 * b_keys);
-    {   // entries: key = (query, rank of the target in the database's length order), value = (target, position in sel); every part
-        // writes its own stretch (the classification is repeated: cheaper than remembering it)
-        std::vector<uint32_t> part_at(parts, 0);
-        for (unsigned p = 1; p < parts; ++p) part_at[p] = part_at[p - 1] + part_lists[p - 1];
-        parallel_for(n_sel, parts, [&](unsigned p, unsigned, uint64_t b, uint64_t e) {
-            uint32_t k = part_at[p];
-            for (uint64_t i = b; i < e; ++i) {
-                const uint32_t pi = sel[(uint32_t)i];
-                const uint32_t lt = db->len[pair_t[pi]], qi = pair_q[pi];
-                if (!(lt != 0 && lt <= best_ls && lt <= lt_cap[qi])) continue;
-                h_keys[k] = ((uint64_t)qi << 32) | db->pos_of_id[pair_t[pi]];
-                h_vals[k] = ((uint64_t)pair_t[pi] << 32) | (uint32_t)i;
-                ++k;
-            }
-        });
-    }
     {
         uint32_t at = 0;
         for (uint32_t blk = 0; blk < max_blocks; ++blk)
@@ -342,52 +401,31 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
                 h_items[at++] = it;
             }
     }
-    int q_bits = 1;
-    while (q_bits < 32 && (1ull << q_bits) < q->n) ++q_bits;
-
-    // ---- device buffers: one grow-only allocation ----
-    size_t cub_sort = 0, cub_scan = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint64_t*)nullptr,
-                                               (uint64_t*)nullptr, (int)n, 0, 32 + q_bits, stream));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n_items, stream));
-    const uint64_t b_cub = align256(std::max(cub_sort, cub_scan)), b_dw = align256((uint64_t)n_items * 8), b_sc = align256((uint64_t)n_sel * 4);
-    const uint64_t need = 4 * b_keys + b_items + 2 * b_dw + b_sc + b_cub;
-    { const auto ta = now();
-    if (cx->lst_bytes < need) {
-        if (cx->d_lst) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst)); }
-        cx->d_lst = nullptr; cx->lst_bytes = 0;
-        const uint64_t want = need + need / 4;
-        HIP_TRY(hipMalloc((void**)&cx->d_lst, want));
-        cx->lst_bytes = want;
-    }
-    t_alloc += us(ta, now()); }
-    ListBuffers B;
-    char* p = cx->d_lst;
-    B.keys_in = (uint64_t*)p; p += b_keys; B.vals_in = (uint64_t*)p; p += b_keys;     // keys_in, vals_in, items: one upload
-    B.items = (ListItem*)p; p += b_items;
-    B.keys_out = (uint64_t*)p; p += b_keys; B.vals_out = (uint64_t*)p; p += b_keys;
-    B.dwords = (uint64_t*)p; p += b_dw; B.offs = (uint64_t*)p; p += b_dw;
-    B.scores = (int32_t*)p; p += b_sc;
-    B.cub = p; B.cub_bytes = b_cub;
-    HIP_TRY(hipMemcpyAsync(B.keys_in, cx->h_lst_stage, stage_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(B.items, h_items, (size_t)n_items * sizeof(ListItem), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->lst_stage_done, stream));
     const auto t2 = now();
-    size_t tmp = B.cub_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(B.cub, tmp, B.keys_in, B.keys_out, B.vals_in, B.vals_out, (int)n, 0, 32 + q_bits, stream));
-    hipLaunchKernelGGL(list_item_len, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.vals_out, db->d_seq_len, B.dwords);
-    tmp = B.cub_bytes;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(B.cub, tmp, B.dwords, B.offs, (int)n_items, stream));
-    hipLaunchKernelGGL(list_item_off, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.offs);
-    HIP_TRY(hipGetLastError());
-    // the one host round trip: the size of the gathered residues and the longest item (workspace) -- item 0 .. are block 0 of
-    // every query, so the longest item is among the first q->n; read offs/dwords of the last item and all len4 of block 0
-    uint64_t tail[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&tail[0], B.offs + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&tail[1], B.dwords + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const uint64_t res_dwords = tail[0] + tail[1];
-    const uint32_t max_len4 = (std::min(best_ls, lt_max) + 3) / 4;         // no member is longer than the split length
+    const uint32_t max_len4 = (std::min(best_ls, lt_hi) + 3) / 4;         // no member is longer than the split length
+    // The gathered residues: an item is at most max_len4 chunks of 128 dwords.  While that bound is affordable every item gets a
+    // slot of that size -- no prefix sum over the items' sizes (a decoupled-lookback scan: its blocks wait for each other, and
+    // next to the pair waves of the side stream one launch of it was seen to take 0.6 ms) and no round trip to the host for the
+    // total; beyond the bound: sizes, scan, offsets, and one round trip for the sum.
+    const uint64_t slot_dwords = (uint64_t)max_len4 * 128;
+    uint64_t res_dwords = (uint64_t)n_items * slot_dwords;
+    const bool slots = res_dwords * 4 <= kListResBoundBytes;
+    hipLaunchKernelGGL(list_item_len, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.vals_out, db->d_seq_len, B.dwords,
+                       slots ? slot_dwords : (uint64_t)0);
     const auto ta2 = now();
+    if (!slots) {
+        tmp = B.cub_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(B.cub, tmp, B.dwords, B.offs, (int)n_items, stream));
+        hipLaunchKernelGGL(list_item_off, dim3((n_items + 255) / 256), dim3(256), 0, stream, B.items, n_items, B.offs);
+        uint64_t tail[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&tail[0], B.offs + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&tail[1], B.dwords + (n_items - 1), 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        res_dwords = tail[0] + tail[1];
+    }
+    HIP_TRY(hipGetLastError());
     if (cx->lst_res_bytes < (res_dwords + kListResSlack) * 4) {
         if (cx->d_lst_res) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_lst_res)); }
         cx->d_lst_res = nullptr; cx->lst_res_bytes = 0;
@@ -411,6 +449,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
     t_alloc += us(ta2, now());
     hipLaunchKernelGGL(list_gather, dim3(n_items), dim3(256), 0, stream, B.items, B.vals_out, db->d_seq_addr, db->d_seq_len, cx->d_lst_res);
+    // the pair waves go out while the device gathers -- and before the list kernel's persistent blocks take every wave slot
+    rc = submit_waves();            // (A/B against submitting them before the item table: 9.96 against 10.09 ms per call, mean of 4 and 3)
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(cx->d_counter + kListCounter, 0, 4, stream));
     ListArgs a;
     a.items = B.items; a.res = cx->d_lst_res; a.entries = B.vals_out;
@@ -423,8 +464,8 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
         // histogram: 128 pairs to an item).
         const uint64_t simds = (uint64_t)cx->prop.multiProcessorCount * 4;
         uint64_t pairs_above = 0;
-        uint32_t lp = std::min(best_ls, lt_max) + 1;
-        for (size_t b = std::min<size_t>(pairs_in.size() - 1, std::min(best_ls, lt_max) / 64);; --b) {
+        uint32_t lp = std::min(best_ls, lt_hi) + 1;
+        for (size_t b = std::min<size_t>(pairs_in.size() - 1, std::min(best_ls, lt_hi) / 64);; --b) {
             if (pairs_above + pairs_in[b] > simds * 3 / 4 * 128) break;
             pairs_above += pairs_in[b];
             lp = (uint32_t)b * 64;
@@ -447,16 +488,19 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
     const auto t3 = now();
     HIP_TRY(hipStreamSynchronize(stream));
-    if (!sel_idx) memcpy(h_scores, sc, (size_t)n_sel * 4);
-    else for (uint32_t i = 0; i < n_sel; ++i) h_scores[sel_idx[i]] = sc[i];
+    parallel_for(n_sel, parts, [&](unsigned, unsigned, uint64_t b, uint64_t e) {
+        if (!sel_idx) memcpy(h_scores + b, sc + b, (size_t)(e - b) * 4);
+        else for (uint64_t i = b; i < e; ++i) h_scores[sel_idx[i]] = sc[i];
+    });
     for (size_t k = 0; k < wave_sel.size(); ++k) h_scores[wave_sel[k]] = wsc[wave_where[k]];
     cx->stat_pair_items = wave_sel.size();          // s4g_scan_stats: what went to the pair waves / the list kernel
     cx->stat_list_pairs = n;
     if (prof) {
         const auto t4 = now();
-        fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: plan+waves %.1f us (histogram %.1f, classify %.1f, %u threads), entries %.1f us, "
-                        "sort+tables+gather+scan %.1f us, wait+download %.1f us; of which growing buffers %.1f us (ws %.0f MB, residues %.0f MB)\n",
-                n, wave_sel.size(), best_ls, n_items, us(t0, t1), us(t0, t_h), us(t_h, t_c), parts, us(t1, t2), us(t2, t3), us(t3, t4), t_alloc, ws_bytes / 1e6, res_dwords * 4 / 1e6);
+        fprintf(stderr, "[s4g profile] lists n=%u (+%zu as waves), split at %u residues, %u items: estimate %.1f us (every %u. pair), raw pairs to the device + entries + sort queued %.1f us, "
+                        "classification meanwhile %.1f us (%u threads), item table %.1f us, tables + gather + pair waves + list kernel queued %.1f us, wait+download %.1f us; of which growing buffers %.1f us "
+                        "(ws %.0f MB, residues %.0f MB)\n",
+                n, wave_sel.size(), best_ls, n_items, us(t0, t_h), stride, us(t_h, t_c), us(t_c, t1), parts, us(t1b, t2), us(t2, t3), us(t3, t4), t_alloc, ws_bytes / 1e6, res_dwords * 4 / 1e6);
     }
     return scope.release();
 }

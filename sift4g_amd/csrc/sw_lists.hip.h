@@ -64,9 +64,25 @@ struct ListArgs {
     uint32_t q_begin;
 };
 
-// items[i].len4 and the item's size in dwords (input of the exclusive scan that yields res_off)
+// The entries of a call out of its raw pairs: key = (query << pos_bits | rank of the target in the database's length order), value = (target,
+// position of the pair in the call).  A pair the list kernel does not take (target longer than the split length or than the
+// query's drifting-frame window, or empty) gets the key (n_queries, 0): it sorts behind every list.
+__global__ void list_entries(const uint32_t* __restrict__ pair_q, const uint32_t* __restrict__ pair_t, uint32_t n,
+                             const uint32_t* __restrict__ seq_len, const uint32_t* __restrict__ pos_of_id, const uint32_t* __restrict__ lt_cap,
+                             uint32_t split_len, uint32_t n_queries, uint32_t pos_bits, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t qi = pair_q[i], t = pair_t[i];
+    const uint32_t lt = seq_len[t];
+    const bool mine = lt != 0 && lt <= split_len && lt <= lt_cap[qi];
+    keys[i] = mine ? ((uint64_t)qi << pos_bits) | pos_of_id[t] : (uint64_t)n_queries << pos_bits;
+    vals[i] = ((uint64_t)t << 32) | i;
+}
+
+// items[i].len4 and the item's size in dwords (input of the exclusive scan that yields res_off); stride != 0: no scan, item i's
+// residues start at i * stride dwords (the buffer was sized by the longest item the call can have)
 __global__ void list_item_len(ListItem* __restrict__ items, uint32_t n_items, const uint64_t* __restrict__ entries,
-                              const uint32_t* __restrict__ seq_len, uint64_t* __restrict__ dwords) {
+                              const uint32_t* __restrict__ seq_len, uint64_t* __restrict__ dwords, uint64_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     const ListItem it = items[i];
@@ -74,7 +90,8 @@ __global__ void list_item_len(ListItem* __restrict__ items, uint32_t n_items, co
     if (it.nb) l = max(l, seq_len[(uint32_t)(entries[it.first_b] >> 32)]);
     const uint32_t len4 = (l + 3) / 4;
     items[i].len4 = len4;
-    dwords[i] = (uint64_t)len4 * 128;
+    if (stride) items[i].res_off = (uint64_t)i * stride;
+    else dwords[i] = (uint64_t)len4 * 128;
 }
 
 __global__ void list_item_off(ListItem* __restrict__ items, uint32_t n_items, const uint64_t* __restrict__ offs) {
