@@ -552,6 +552,8 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     const bool want_pipe = (flags & S4G_SCAN_BLOCK_PIPE) != 0 ||
                            (flags == 0 && q_count >= 3 && q_count <= pipe_max_queries() && !(all_pairs && any_pairs) && db->n_seqs >= 256u * 64u);
     flags &= ~S4G_SCAN_BLOCK_PIPE;
+    std::vector<char> piped(db->tiles.size(), 0);
+    uint64_t pipe_pairs = 0;
     if (want_pipe) {
         rc = scope.acquire();
         if (rc) return rc;
@@ -560,21 +562,28 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         rc = ensure_mat(cx, scorer, stream);
         if (rc) return rc;
         size_t refused = 0;
-        for (size_t ti = 0; ti < db->tiles.size() && !refused; ++ti) {
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            if (!t.n_seqs) continue;
+            if (!t.n_seqs) { piped[ti] = 1; continue; }
             bool used = false;
             rc = scan_tile_pipelined(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, t.d_perm_global, stream, &used);
             if (rc) return rc;
-            if (used) { cx->stat_list_pairs += (uint64_t)q_count * t.n_seqs; } else ++refused;
+            if (used) { piped[ti] = 1; g0s[ti] = 0; pipe_pairs += (uint64_t)q_count * t.n_seqs; } else ++refused;
         }
+        cx->stat_list_pairs = pipe_pairs;
         if (!refused) return scope.release();
-        // a tile the pipeline does not take (a query beyond the drifting-frame window): the general route scores the whole call,
-        // behind whatever was launched above on the same stream
+        // Tiles the pipeline does not take (a query beyond the drifting-frame window there, a tile of titin-sized sequences) go
+        // through the general route below, behind what was launched above on the same stream; the tiles that are done are skipped.
         rc = scope.release();
         if (rc) return rc;
+        all_pairs = true; any_pairs = false;
+        for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
+            if (piped[ti]) continue;
+            all_pairs = all_pairs && g0s[ti] >= db->tiles[ti].n_groups;
+            any_pairs = any_pairs || g0s[ti] != 0;
+        }
     }
-    if (all_pairs && any_pairs) {       // nothing for the scan kernels: one submission, no plan, no strip workspace
+    if (all_pairs && any_pairs && pipe_pairs == 0) {       // nothing for the scan kernels: one submission, no plan, no strip workspace
         rc = scope.acquire();
         if (rc) return rc;
         rc = stats_begin(cx, stream);
@@ -594,6 +603,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     rc = stats_begin(cx, stream);
     if (rc) return rc;
     stats_add(cx, p);
+    cx->stat_list_pairs += pipe_pairs;
     rc = ensure_scratch(db, scorer, p, stream);
     if (rc) return rc;
     // The side stream carries (a) the pair parts and (b) the scan launches of long-sequence tiles (own workspace): their
@@ -604,7 +614,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     if (db->tiles.size() > 1)
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
-            if ((uint64_t)t.max_len4 * 4 <= kLongSeq || g0s[ti] >= t.n_groups) continue;
+            if (piped[ti] || (uint64_t)t.max_len4 * 4 <= kLongSeq || g0s[ti] >= t.n_groups) continue;
             on_side[ti] = 1;
             const TileWork& w = p.tiles[ti];
             const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
@@ -629,6 +639,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         scope.forked = true;
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
+            if (piped[ti]) continue;
             if (g0s[ti]) {
                 cx->stat_pair_items += (uint64_t)q_count * std::min<uint64_t>(t.n_seqs, (uint64_t)g0s[ti] * 64);
                 rc = tile_as_pairs(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, false, cx->side_stream,
@@ -643,7 +654,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
     }
     for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
-        if (on_side[ti]) continue;
+        if (on_side[ti] || piped[ti]) continue;
         const Tile& t = db->tiles[ti];
         rc = launch_tile(db, t, p.tiles[ti], q, scorer, p, q_begin, d_scores, db->n_seqs, t.d_perm_global, stream, false, g0s[ti]);
         if (rc) return rc;

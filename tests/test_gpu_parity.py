@@ -1215,6 +1215,15 @@ def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
         assert st["list_pairs"] == (nq * len(ts) if nq >= 3 else 0), st      # 3..8 queries: the whole call on the list kernel's pipeline
         assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=0, q_count=nq, no_pairs=True), exp[:nq]), nq
         assert np.array_equal(s4g.scan_host(db, q, scorer, q_begin=6 - nq, q_count=nq, block_pipe=True), exp[6 - nq:]), nq
+    # a database with a tile of titin-sized sequences: that tile goes through the general route, the rest through the pipeline
+    giants = rand_seqs(rng, 3, 13000, 15000, 20)
+    mixed = ts[:17000] + giants
+    dbm = s4g.Database(mixed)
+    exp_m = np.concatenate([exp[:4, :17000], oracle_mod.scan(qs[:4], giants, blosum62, 10, 1, threads=8)], axis=1)
+    q4 = s4g.QuerySet(qs[:4])
+    assert np.array_equal(s4g.scan_host(dbm, q4, scorer), exp_m)
+    st = device.scan_stats(0)
+    assert st["list_pairs"] == 4 * 17000 and st["pair_items"] + st["tier_drift"] + st["tier_m3"] + st["tier_i16"] + st["tier_i32"] > 0, st
     # a query beyond the drifting-frame window: the pipeline refuses the tile and the general route scores the call
     long_q = rand_seqs(rng, 1, 6000, 6000, 20) + qs[:2]
     ql = s4g.QuerySet(long_q)
