@@ -126,6 +126,11 @@ struct DeviceCtx {
     uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_band = 0, grid_pair_trace_band = 0, grid_pair_recheck = 0;
+    uint32_t grid_pair_coop[3] = {0, 0, 0}, grid_pair_trace_coop[3] = {0, 0, 0};     // sw_pair_scan_coop / sw_pair_trace_coop<2, 3, 4>
+    hipStream_t coop_stream = nullptr;  // they run next to the one-wave-per-pair launches of the same submission, not behind them
+    hipEvent_t coop_fork = nullptr, coop_join = nullptr;
+    char* d_coop_ws = nullptr;          // their boundary rows (s4g_pairs.hip, ensure_coop_ws)
+    uint64_t coop_ws_bytes = 0;
     char* d_band_ws = nullptr;          // boundary rows of sw_pair_scan_band, one slot per wave
     uint64_t band_ws_bytes = 0;
     // pair lists: pinned staging for the items of the current call, their device copy (+ host-route scores behind it)
@@ -159,6 +164,7 @@ struct DeviceCtx {
     uint32_t grid_pipe = 0;                 // blocks of sw_scan_lists<R, true> the device holds (scan_tile_pipelined)
     uint64_t stat_tier[4] = {0, 0, 0, 0};
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
+    uint64_t stat_coop_scan = 0, stat_coop_trace = 0;      // pairs of the last pair submission / traceback call on the cooperative kernels
     // clock samples of the scan launches of the last call (s4g_scan_clock; sw_kernels.hip.h clk_enter / clk_leave): a region of
     // 4 counters per block for each of the call's first kClkLaunches launches
     int max3_state = 0;                  // ensure_max3: 0 not yet checked, 1 the integer-max3-on-f16-patterns argument holds here, -1 it does not

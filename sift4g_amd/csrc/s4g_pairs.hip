@@ -2,6 +2,7 @@
 // the pair route of s4g_scan, and the traceback of the survivors of a per-query alignDatabase call
 // (/root/reference/sift4g/src/database_alignment.cpp:70-92).
 #include "s4g_internal.hpp"
+#include "sw_pair_coop.hip.h"
 
 // ---------------------------------------------------------------------------
 // Pair lists (the latency path, sw_pair.hip.h): explicit (query, target) pairs, one wave per pair.
@@ -9,6 +10,15 @@
 constexpr int kPairClasses = 6;                 // row-block classes of sw_pair_scan / sw_pair_trace
 constexpr int kPairRpl[kPairClasses] = {2, 4, 6, 8, 12, 16};
 constexpr int kScanClasses = kPairClasses + 1;  // + the banded kernel (sw_pair_scan_band) for queries beyond 1024 residues
+// + the cooperative kernels (sw_pair_coop.hip.h: the four waves of a block on one pair) for pairs whose own latency would dominate
+// their launch; classes by rows per lane
+constexpr int kCoopClasses = 3;
+constexpr int kCoopRpl[kCoopClasses] = {2, 3, 4};
+constexpr int kAllClasses = kScanClasses + kCoopClasses;
+inline int coop_class(uint32_t lq) {            // -1: the query has more rows than four waves of 64 lanes x 4 rows hold
+    for (int c = 0; c < kCoopClasses; ++c) if ((uint32_t)kCoopWaves * 64u * kCoopRpl[c] >= lq) return c;
+    return -1;
+}
 inline int pair_class(uint32_t lq) {
     if (lq > (uint32_t)kPairMaxRows) return kPairClasses;
     int c = 0;
@@ -35,6 +45,98 @@ int ensure_band_ws(DeviceCtx* cx, uint32_t max_lt, uint32_t n_items, uint32_t fu
         HIP_TRY(hipMalloc((void**)&cx->d_band_ws, bytes));
         cx->band_ws_bytes = bytes;
     }
+    return S4G_OK;
+}
+
+constexpr int kCoopScanCounter = 50;            // DeviceCtx::d_counter words: work queues of the cooperative scan classes (3) ...
+constexpr int kPairTraceCounter = 53;           // ... and of the traceback launches of a batch, one per class (kAllClasses = 10)
+constexpr uint64_t kCoopWsBudget = 1ull << 30;
+
+// boundary rows of the cooperative kernels: kCoopWaves - 1 rows of `slot` columns per resident block (caller holds cx->mu)
+int ensure_coop_ws(DeviceCtx* cx, uint32_t max_lt, uint32_t n_items, uint32_t full_grid, uint32_t* grid, uint64_t* slot) {
+    *slot = ((uint64_t)std::max(1u, max_lt) + 63) / 64 * 64;
+    const uint64_t per_block = *slot * 8 * (kCoopWaves - 1);
+    *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(full_grid, n_items), kCoopWsBudget / per_block));
+    const uint64_t bytes = per_block * *grid;
+    if (cx->coop_ws_bytes < bytes) {
+        if (cx->d_coop_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(cx->d_coop_ws)); }
+        cx->d_coop_ws = nullptr; cx->coop_ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&cx->d_coop_ws, bytes));
+        cx->coop_ws_bytes = bytes;
+    }
+    return S4G_OK;
+}
+
+// Which pairs of a submission go to the cooperative kernels.  Measured (profiles/r03_pair_coop.txt): a step of 2 rows per lane is
+// not three times shorter than a step of 6 -- the shift from the neighbour lane and two dependent LDS reads (residue, then its profile
+// row) are there either way, and with so little arithmetic between them the step waits for the LDS: ~300 clocks against ~260 for six
+// rows in sw_pair_scan.  So the SCORES gain nothing (a 35 000-column target: 4.6 ms here, 3.8 ms on one wave; a per-query call of
+// 5000 candidates 0.47 against 0.42 ms) and stay on one wave per pair.  The TRACEBACK step is three times heavier per row (direction
+// codes, the end cell): there the cooperative sweep wins, 13.1 against 23.5 ms for that target -- and is used for the pairs whose own
+// time on one wave (cells / kPairWaveRate) is at least a millisecond and half of what the whole call needs on a full chip: a titin
+// among a query's hits.  S4G_COOP_PAIRS=0 turns the route off, =cost applies the cost rule (with a floor of 40 us) to scores as well,
+// =all sends every pair of two bands or more there, scores and traceback (tests).
+struct CoopRule {
+    double min_cells;
+    int mode;           // 0 off, 1 by cost, 2 every eligible pair
+    CoopRule(double cells_total, bool traceback) {
+        static const int m = []() { const char* e = getenv("S4G_COOP_PAIRS"); return !e ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "all") ? 2 : (!strcmp(e, "cost") ? 3 : 1))); }();
+        mode = m == 3 ? 1 : (m == 1 && !traceback ? 0 : m);
+        min_cells = std::max(0.5 * cells_total / kPairChipRate, m == 3 ? 40e-6 : 1e-3) * kPairWaveRate;
+    }
+    int cls(uint32_t lq, uint32_t lt) const {          // class index (kScanClasses + c) or -1
+        if (mode == 0 || lq > (uint32_t)kPairMaxRows || lt == 0 || lt >= 60000) return -1;
+        const int c = coop_class(lq);
+        if (c < 0 || lq <= 64u * (uint32_t)kCoopRpl[c]) return -1;         // (one band: nothing to share)
+        if (mode == 1 && (double)lq * lt < min_cells) return -1;
+        return kScanClasses + c;
+    }
+};
+
+// The cooperative launches of a submission go to a stream of their own (kernels of one stream run one after the other, and these are
+// the pairs that take longest): fork() after the uploads on `stream`, the destructor joins -- on every exit.
+struct CoopFork {
+    DeviceCtx* cx;
+    hipStream_t stream;
+    bool forked = false;
+    CoopFork(DeviceCtx* c, hipStream_t s) : cx(c), stream(s) {}
+    int fork() {
+        if (forked) return S4G_OK;
+        if (!cx->coop_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&cx->coop_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cx->coop_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cx->coop_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(cx->coop_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(cx->coop_stream, cx->coop_fork, 0));
+        forked = true;
+        return S4G_OK;
+    }
+    int join() {
+        if (!forked) return S4G_OK;
+        forked = false;
+        HIP_TRY(hipEventRecord(cx->coop_join, cx->coop_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, cx->coop_join, 0));
+        return S4G_OK;
+    }
+    ~CoopFork() { (void)join(); }
+};
+
+template <int RPL>
+int launch_pairs_coop(DeviceCtx* cx, PairArgs a, uint32_t max_lt, uint32_t* grid_cache, hipStream_t stream) {
+    if (*grid_cache == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan_coop<RPL>, kCoopWaves * 64, 0));
+        *grid_cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    uint64_t slot = 0;
+    uint32_t grid = 0;
+    int rc = ensure_coop_ws(cx, max_lt, a.n_pairs, *grid_cache, &grid, &slot);
+    if (rc) return rc;
+    PairCoopArgs ca;
+    ca.p = a; ca.ws = reinterpret_cast<int2*>(cx->d_coop_ws); ca.ws_slot = slot;
+    hipLaunchKernelGGL(sw_pair_scan_coop<RPL>, dim3(grid), dim3(kCoopWaves * 64), 0, stream, ca);
+    HIP_TRY(hipGetLastError());
     return S4G_OK;
 }
 
@@ -66,6 +168,13 @@ int warm_pair_kernels(DeviceCtx* cx) {
     if (!rc) rc = occ((const void*)sw_pair_scan<8>, &cx->grid_pair[3]);
     if (!rc) rc = occ((const void*)sw_pair_trace<6>, &cx->grid_pair_trace[2]);
     if (!rc) rc = occ((const void*)sw_pair_trace<8>, &cx->grid_pair_trace[3]);
+    if (!rc && cx->grid_pair_coop[0] == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan_coop<2>, kCoopWaves * 64, 0));
+        cx->grid_pair_coop[0] = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace_coop<2>, kCoopWaves * 64, 0));
+        cx->grid_pair_trace_coop[0] = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
     PairItem* items = nullptr;
     if (!rc) rc = pair_stage(cx, 1u << 16, &items);           // pinned staging + device items: a pinned allocation costs milliseconds
     return rc;
@@ -110,8 +219,9 @@ int pair_stage(DeviceCtx* cx, uint64_t n, PairItem** out) {
 }
 
 // uploads the staged items (class-major: cls_begin[c] .. cls_begin[c+1]) and launches one kernel per class
+// (cls_begin has kAllClasses + 1 entries; max_lt_coop = longest target among the cooperative classes)
 int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n, const uint32_t* cls_begin,
-                int32_t* d_scores, hipStream_t stream, uint32_t max_lt_band) {
+                int32_t* d_scores, hipStream_t stream, uint32_t max_lt_band, uint32_t max_lt_coop = 0) {
     DeviceCtx* cx = device_ctx(db->device);
     int rc = device_props(cx);
     if (rc) return rc;
@@ -126,14 +236,29 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     HIP_TRY(hipMemcpyAsync(cx->d_items, cx->h_items, (size_t)n * sizeof(PairItem), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->items_done, stream));
     HIP_TRY(hipMemsetAsync(cx->d_counter + 24, 0, kScanClasses * 4, stream));
-    for (int c = 0; c < kScanClasses; ++c) {
+    if (cls_begin[kAllClasses] != cls_begin[kScanClasses]) HIP_TRY(hipMemsetAsync(cx->d_counter + kCoopScanCounter, 0, kCoopClasses * 4, stream));
+    // the cooperative classes first, on their own stream: they are the submission's longest pairs
+    CoopFork coop_fork(cx, stream);
+    for (int cc = 0; cc < kAllClasses; ++cc) {
+        const int c = cc < kCoopClasses ? kScanClasses + cc : cc - kCoopClasses;
         const uint32_t b = cls_begin[c], e = cls_begin[c + 1];
         if (b == e) continue;
         PairArgs a;
         a.items = cx->d_items + b; a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
         a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
-        a.scores = d_scores; a.counter = cx->d_counter + 24 + c; a.n_pairs = e - b;
+        a.scores = d_scores; a.counter = c >= kScanClasses ? cx->d_counter + kCoopScanCounter + (c - kScanClasses) : cx->d_counter + 24 + c; a.n_pairs = e - b;
         a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+        if (c >= kScanClasses) {
+            rc = coop_fork.fork();
+            if (rc) return rc;
+            switch (c - kScanClasses) {
+                case 0: rc = launch_pairs_coop<2>(cx, a, max_lt_coop, &cx->grid_pair_coop[0], cx->coop_stream); break;
+                case 1: rc = launch_pairs_coop<3>(cx, a, max_lt_coop, &cx->grid_pair_coop[1], cx->coop_stream); break;
+                default: rc = launch_pairs_coop<4>(cx, a, max_lt_coop, &cx->grid_pair_coop[2], cx->coop_stream); break;
+            }
+            if (rc) return rc;
+            continue;
+        }
         if (c == kPairClasses) {        // banded kernel: per-wave boundary workspace sized by the launch's longest target
             if (cx->grid_pair_band == 0) {
                 int per_cu = 0;
@@ -160,6 +285,8 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
         }
         if (rc) return rc;
     }
+    rc = coop_fork.join();
+    if (rc) return rc;
     return scope.release();
 }
 
@@ -206,19 +333,28 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
     if (rc) return rc;
     constexpr uint32_t kBuckets = 2048;
     static thread_local std::vector<uint32_t> count;
-    count.assign((size_t)kScanClasses * kBuckets + 1, 0);
-    uint32_t max_lt_band = 0;
+    count.assign((size_t)kAllClasses * kBuckets + 1, 0);
+    uint32_t max_lt_band = 0, max_lt_coop = 0;
+    double cells_total = 0;
+    for (uint32_t i = 0; i < n; ++i) cells_total += (double)q->len[pair_q[sel[i]]] * db->len[pair_t[sel[i]]];
+    const CoopRule coop(cells_total, false);
+    auto class_of = [&](uint32_t pi) {
+        const int cc = coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]);
+        return cc >= 0 ? cc : pair_class(q->len[pair_q[pi]]);
+    };
     auto key_of = [&](uint32_t pi) {
         const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
-        return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
+        return (uint32_t)class_of(pi) * kBuckets + (kBuckets - 1 - b);
     };
     for (uint32_t i = 0; i < n; ++i) {
         ++count[key_of(sel[i]) + 1];
-        if (pair_class(q->len[pair_q[sel[i]]]) == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[sel[i]]]);
+        const int c = class_of(sel[i]);
+        if (c == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[sel[i]]]);
+        if (c >= kScanClasses) max_lt_coop = std::max(max_lt_coop, db->len[pair_t[sel[i]]]);
     }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
-    uint32_t cls_begin[kScanClasses + 1];
-    for (int c = 0; c <= kScanClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    uint32_t cls_begin[kAllClasses + 1];
+    for (int c = 0; c <= kAllClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
     where->resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t pi = sel[i];
@@ -226,8 +362,9 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
         items[at] = {pair_q[pi], pair_t[pi], at};
         (*where)[i] = at;                      // where this pair's score will sit
     }
+    cx->stat_coop_scan = cls_begin[kAllClasses] - cls_begin[kScanClasses];
     *d_sc_out = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
-    return pair_submit(db, q, scorer, n, cls_begin, *d_sc_out, stream, max_lt_band);
+    return pair_submit(db, q, scorer, n, cls_begin, *d_sc_out, stream, max_lt_band, max_lt_coop);
 }
 
 // Explicit list -> host scores (synchronous).
@@ -332,7 +469,7 @@ int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_
             t.h_col_of_pos[p] = (uint32_t)(std::lower_bound(ids.begin(), ids.end(), db->id_of_pos[t.pos0 + p]) - ids.begin());
     }
     const std::vector<uint32_t>& col = t.h_col_of_pos;
-    uint32_t cls_begin[kScanClasses + 1];
+    uint32_t cls_begin[kAllClasses + 1];
     uint32_t at = 0;
     std::vector<uint32_t> qs;
     for (int c = 0; c < kScanClasses; ++c) {
@@ -346,7 +483,7 @@ int tile_as_pairs(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_
             for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * stride + column)};
         }
     }
-    cls_begin[kScanClasses] = at;
+    for (int c = kScanClasses; c <= kAllClasses; ++c) cls_begin[c] = at;         // (no cooperative classes on this route)
     return pair_submit(db, q, scorer, at, cls_begin, d_scores, stream, t.max_len4 * 4);
 }
 
@@ -374,7 +511,7 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
     rc = pair_stage(cx, n_items, &items);
     if (rc) return rc;
     // class-major; inside a class the targets in length-sorted order (longest first), queries innermost
-    uint32_t cls_begin[kScanClasses + 1];
+    uint32_t cls_begin[kAllClasses + 1];
     uint32_t at = 0;
     std::vector<uint32_t> qs;
     for (int c = 0; c < kScanClasses; ++c) {
@@ -387,7 +524,7 @@ int scan_as_pairs(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint
             for (uint32_t i : qs) items[at++] = {q_begin + i, id, (uint32_t)((uint64_t)i * db->n_seqs + id)};
         }
     }
-    cls_begin[kScanClasses] = at;
+    for (int c = kScanClasses; c <= kAllClasses; ++c) cls_begin[c] = at;         // (no cooperative classes on this route)
     rc = pair_submit(db, q, scorer, at, cls_begin, d_scores, stream, max_t);
     if (rc) return rc;
     *done = true;
@@ -558,43 +695,56 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
     if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
     { const int rcm = ensure_mat(cx, scorer, stream); if (rcm) return rcm; }
-    // class-major, longest target first (32-residue granularity), as in score_pairs_device
+    // class-major (the cooperative classes first: the longest pairs start first), longest target first inside a class (32-residue
+    // granularity), as in pairs_enqueue
     const uint32_t n = (uint32_t)sel.size();
     constexpr uint32_t kBuckets = 2048;
-    std::vector<uint32_t> count((size_t)kScanClasses * kBuckets + 1, 0), order(n);
+    std::vector<uint32_t> count((size_t)kAllClasses * kBuckets + 1, 0), order(n);
+    double cells_total = 0;
+    for (uint32_t i = 0; i < n; ++i) cells_total += (double)q->len[pair_q[sel[i]]] * db->len[pair_t[sel[i]]];
+    const CoopRule coop(cells_total, true);
+    auto class_of = [&](uint32_t pi) {
+        const int cc = (pair_score[pi] > 0) ? coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]) : -1;
+        return cc >= 0 ? cc : pair_class(q->len[pair_q[pi]]);
+    };
+    auto slot_of = [](int c) { return c >= kScanClasses ? c - kScanClasses : c + kCoopClasses; };      // position of class c in the order
     auto key_of = [&](uint32_t pi) {
         const uint32_t b = std::min<uint32_t>(db->len[pair_t[pi]] >> 5, kBuckets - 1);
-        return (uint32_t)pair_class(q->len[pair_q[pi]]) * kBuckets + (kBuckets - 1 - b);
+        return (uint32_t)slot_of(class_of(pi)) * kBuckets + (kBuckets - 1 - b);
     };
     for (uint32_t i = 0; i < n; ++i) ++count[key_of(sel[i]) + 1];
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
-    uint32_t cls_begin[kScanClasses + 1];
-    for (int c = 0; c <= kScanClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    uint32_t slot_begin[kAllClasses + 1];
+    for (int c = 0; c <= kAllClasses; ++c) slot_begin[c] = count[(size_t)c * kBuckets];
     for (uint32_t i = 0; i < n; ++i) order[count[key_of(sel[i])]++] = sel[i];
+    cx->stat_coop_trace = slot_begin[kCoopClasses];
     auto dir_bytes = [&](uint32_t pi) {
-        const int c = pair_class(q->len[pair_q[pi]]);
-        if (c == kPairClasses) {        // banded: every band has the block of a full band of sw_pair_trace<16>
-            const uint64_t nbands = ((uint64_t)q->len[pair_q[pi]] + kPairMaxRows - 1) / kPairMaxRows;
-            return nbands * ((((uint64_t)db->len[pair_t[pi]] + 63) + 1) & ~1ull) * 64 * 16;
+        const int c = class_of(pi);
+        const uint64_t lt = db->len[pair_t[pi]], lq = q->len[pair_q[pi]];
+        if (c == kPairClasses)          // banded: every band has the block of a full band of sw_pair_trace<16>
+            return ((lq + kPairMaxRows - 1) / kPairMaxRows) * (((lt + 63) + 1) & ~1ull) * 64 * 16;
+        if (c >= kScanClasses) {        // cooperative: a band of 64 * RPL rows per wave, each with the block of a full band
+            const uint64_t rpl = (uint64_t)kCoopRpl[c - kScanClasses];
+            return ((lq + 64 * rpl - 1) / (64 * rpl)) * (((lt + 63) + 1) & ~1ull) * 64 * 4;
         }
         const uint32_t rpl = (uint32_t)kPairRpl[c], nw = rpl <= 4 ? 1 : (rpl <= 8 ? 2 : 4);
-        const uint64_t steps = (uint64_t)db->len[pair_t[pi]] + (q->len[pair_q[pi]] + rpl - 1) / rpl - 1;
+        const uint64_t steps = lt + (lq + rpl - 1) / rpl - 1;
         return ((steps + 1) & ~1ull) * 64 * nw * 4;
     };
     const uint64_t dir_budget = 8ull << 30;
     std::vector<PairTraceItem> items;
     std::vector<uint8_t> back;
     for (uint32_t b0 = 0; b0 < n;) {
-        // a batch: consecutive pairs of ONE class whose direction blocks fit the budget
-        int c = 0;
-        while (cls_begin[c + 1] <= b0) ++c;
+        // a batch: consecutive pairs (of any classes) whose direction blocks fit the budget; one launch per class in it, one download
         uint32_t b1 = b0;
         uint64_t dir_total = 0, path_total = 0;
-        uint32_t max_lt = 0;
+        uint32_t max_lt_band = 0, max_lt_coop = 0;
         items.clear();
-        while (b1 < cls_begin[c + 1] && (b1 == b0 || dir_total + dir_bytes(order[b1]) <= dir_budget)) {
+        while (b1 < n && (b1 == b0 || dir_total + dir_bytes(order[b1]) <= dir_budget)) {
             const uint32_t pi = order[b1];
-            max_lt = std::max(max_lt, db->len[pair_t[pi]]);
+            const int c = class_of(pi);
+            if (c == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[pi]]);
+            if (c >= kScanClasses) max_lt_coop = std::max(max_lt_coop, db->len[pair_t[pi]]);
             const uint64_t cap = (uint64_t)q->len[pair_q[pi]] + db->len[pair_t[pi]];
             path_total += cap;
             items.push_back({pair_q[pi], pair_t[pi], pair_score[pi], b1 - b0, dir_total, path_total});
@@ -618,38 +768,69 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         }
         char* A = cx->arena;
         HIP_TRY(hipMemcpyAsync(A + o_items, items.data(), (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(cx->d_counter + 32, 0, 4, stream));
-        PairTraceArgs a;
-        a.items = reinterpret_cast<const PairTraceItem*>(A + o_items); a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
-        a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
-        a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
-        a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
-        a.counter = cx->d_counter + 32; a.n_pairs = ni; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
-        a.left_first = traceback_left_first();
-        if (c == kPairClasses) {
-            if (cx->grid_pair_trace_band == 0) {
-                int per_cu = 0;
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace_band<16>, 64, 0));
-                cx->grid_pair_trace_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+        HIP_TRY(hipMemsetAsync(cx->d_counter + kPairTraceCounter, 0, kAllClasses * 4, stream));
+        CoopFork coop_fork(cx, stream);
+        for (int sl = 0; sl < kAllClasses; ++sl) {
+            // the pairs of class slot sl inside [b0, b1)
+            const uint32_t lo = std::max(b0, slot_begin[sl]), hi = std::min(b1, slot_begin[sl + 1]);
+            if (lo >= hi) continue;
+            const int c = sl < kCoopClasses ? kScanClasses + sl : sl - kCoopClasses;
+            PairTraceArgs a;
+            a.items = reinterpret_cast<const PairTraceItem*>(A + o_items) + (lo - b0); a.seq_addr = db->d_seq_addr; a.seq_len = db->d_seq_len;
+            a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
+            a.dirs = big_dirs ? d_dirs_big.p : reinterpret_cast<uint8_t*>(A + o_dirs); a.paths = reinterpret_cast<uint8_t*>(A + o_paths);
+            a.out5 = reinterpret_cast<int32_t*>(A + o_out); a.best = reinterpret_cast<int32_t*>(A + o_best);
+            a.counter = cx->d_counter + kPairTraceCounter + sl; a.n_pairs = hi - lo; a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
+            a.left_first = traceback_left_first();
+            if (c >= kScanClasses) {
+                uint32_t* cache = &cx->grid_pair_trace_coop[c - kScanClasses];
+                const void* fn = c - kScanClasses == 0 ? (const void*)sw_pair_trace_coop<2> : (c - kScanClasses == 1 ? (const void*)sw_pair_trace_coop<3> : (const void*)sw_pair_trace_coop<4>);
+                if (*cache == 0) {
+                    int per_cu = 0;
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCoopWaves * 64, 0));
+                    *cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+                }
+                uint64_t slot = 0;
+                uint32_t grid = 0;
+                rc = ensure_coop_ws(cx, max_lt_coop, a.n_pairs, *cache, &grid, &slot);
+                if (rc) return rc;
+                rc = coop_fork.fork();
+                if (rc) return rc;
+                PairTraceCoopArgs ca;
+                ca.p = a; ca.ws = reinterpret_cast<int2*>(cx->d_coop_ws); ca.ws_slot = slot;
+                switch (c - kScanClasses) {
+                    case 0: hipLaunchKernelGGL(sw_pair_trace_coop<2>, dim3(grid), dim3(kCoopWaves * 64), 0, cx->coop_stream, ca); break;
+                    case 1: hipLaunchKernelGGL(sw_pair_trace_coop<3>, dim3(grid), dim3(kCoopWaves * 64), 0, cx->coop_stream, ca); break;
+                    default: hipLaunchKernelGGL(sw_pair_trace_coop<4>, dim3(grid), dim3(kCoopWaves * 64), 0, cx->coop_stream, ca); break;
+                }
+                HIP_TRY(hipGetLastError());
+            } else if (c == kPairClasses) {
+                if (cx->grid_pair_trace_band == 0) {
+                    int per_cu = 0;
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_trace_band<16>, 64, 0));
+                    cx->grid_pair_trace_band = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+                }
+                uint64_t slot = 0;
+                uint32_t grid = 0;
+                rc = ensure_band_ws(cx, max_lt_band, a.n_pairs, cx->grid_pair_trace_band, &grid, &slot);
+                if (rc) return rc;
+                PairTraceBandArgs ba;
+                ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
+                hipLaunchKernelGGL(sw_pair_trace_band<16>, dim3(grid), dim3(64), 0, stream, ba);
+                HIP_TRY(hipGetLastError());
+            } else {
+                switch (c) {
+                    case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
+                    case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
+                    case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
+                    case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
+                    case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
+                    default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
+                }
             }
-            uint64_t slot = 0;
-            uint32_t grid = 0;
-            rc = ensure_band_ws(cx, max_lt, ni, cx->grid_pair_trace_band, &grid, &slot);
             if (rc) return rc;
-            PairTraceBandArgs ba;
-            ba.p = a; ba.band_ws = reinterpret_cast<int2*>(cx->d_band_ws); ba.band_ws_slot = slot;
-            hipLaunchKernelGGL(sw_pair_trace_band<16>, dim3(grid), dim3(64), 0, stream, ba);
-            HIP_TRY(hipGetLastError());
-        } else {
-            switch (c) {
-                case 0: rc = launch_pair_trace<2>(cx, a, &cx->grid_pair_trace[0], stream); break;
-                case 1: rc = launch_pair_trace<4>(cx, a, &cx->grid_pair_trace[1], stream); break;
-                case 2: rc = launch_pair_trace<6>(cx, a, &cx->grid_pair_trace[2], stream); break;
-                case 3: rc = launch_pair_trace<8>(cx, a, &cx->grid_pair_trace[3], stream); break;
-                case 4: rc = launch_pair_trace<12>(cx, a, &cx->grid_pair_trace[4], stream); break;
-                default: rc = launch_pair_trace<16>(cx, a, &cx->grid_pair_trace[5], stream); break;
-            }
         }
+        rc = coop_fork.join();
         if (rc) return rc;
         // out5, best and the paths sit back to back in the arena: one download
         back.resize(o_paths + path_total - o_out);

@@ -1237,3 +1237,18 @@ def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
     for i in range(len(qs)):
         order = sorted(range(len(ts)), key=lambda j: (-exp[i, j], j))[:30]
         assert ids[i].tolist() == order and sc[i].tolist() == [int(exp[i, j]) for j in order]
+
+
+@pytest.mark.parametrize("mode", ["all", None, "0"])
+def test_cooperative_pair_kernels(mode):
+    """sw_pair_scan_coop / sw_pair_trace_coop (the four waves of a block on one pair, bands of 64 x RPL rows that run concurrently):
+    scores and tracebacks equal the oracle's for every band count of every class, alignments across band boundaries, targets around
+    the publication window, cheap and expensive gaps -- with every eligible pair forced there (S4G_COOP_PAIRS=all), under the
+    library's own rule (a per-query call sends its longest pairs, a batch does not), and with the route off."""
+    import subprocess, sys
+    env = dict(os.environ)
+    env.pop("S4G_COOP_PAIRS", None)
+    if mode is not None:
+        env["S4G_COOP_PAIRS"] = mode
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "coop_pairs_check.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
