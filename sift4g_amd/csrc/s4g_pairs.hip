@@ -733,7 +733,6 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     };
     const uint64_t dir_budget = 8ull << 30;
     std::vector<PairTraceItem> items;
-    std::vector<uint8_t> back;
     for (uint32_t b0 = 0; b0 < n;) {
         // a batch: consecutive pairs (of any classes) whose direction blocks fit the budget; one launch per class in it, one download
         uint32_t b1 = b0;
@@ -767,7 +766,20 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
             cx->arena_bytes = want;
         }
         char* A = cx->arena;
-        HIP_TRY(hipMemcpyAsync(A + o_items, items.data(), (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
+        // items up and results back through pinned memory (pageable transfers are staged by the runtime: tens of microseconds per
+        // call of a per-query traceback); the two regions do not overlap, the download is waited for before the next batch
+        const uint64_t back_bytes = o_paths + path_total - o_out;
+        const uint64_t pin_items = ((uint64_t)ni * sizeof(PairTraceItem) + 255) / 256 * 256;
+        if (cx->trace_pin_bytes < pin_items + back_bytes) {
+            if (cx->h_trace_pin) HIP_TRY(hipHostFree(cx->h_trace_pin));
+            cx->h_trace_pin = nullptr; cx->trace_pin_bytes = 0;
+            const uint64_t want = std::max<uint64_t>((pin_items + back_bytes) * 5 / 4, 1u << 20);
+            HIP_TRY(hipHostMalloc((void**)&cx->h_trace_pin, want, hipHostMallocDefault));
+            cx->trace_pin_bytes = want;
+        }
+        memcpy(cx->h_trace_pin, items.data(), (size_t)ni * sizeof(PairTraceItem));
+        uint8_t* const back = reinterpret_cast<uint8_t*>(cx->h_trace_pin) + pin_items;
+        HIP_TRY(hipMemcpyAsync(A + o_items, cx->h_trace_pin, (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(cx->d_counter + kPairTraceCounter, 0, kAllClasses * 4, stream));
         CoopFork coop_fork(cx, stream);
         for (int sl = 0; sl < kAllClasses; ++sl) {
@@ -833,12 +845,11 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         rc = coop_fork.join();
         if (rc) return rc;
         // out5, best and the paths sit back to back in the arena: one download
-        back.resize(o_paths + path_total - o_out);
-        HIP_TRY(hipMemcpyAsync(back.data(), A + o_out, back.size(), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(back, A + o_out, back_bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        const int32_t* out5 = reinterpret_cast<const int32_t*>(back.data());
-        const int32_t* best = reinterpret_cast<const int32_t*>(back.data() + (o_best - o_out));
-        const uint8_t* paths = back.data() + (o_paths - o_out);
+        const int32_t* out5 = reinterpret_cast<const int32_t*>(back);
+        const int32_t* best = reinterpret_cast<const int32_t*>(back + (o_best - o_out));
+        const uint8_t* paths = back + (o_paths - o_out);
         for (uint32_t x = 0; x < ni; ++x) {
             const uint32_t pi = order[b0 + x];
             const int32_t want = pair_score[pi] > 0 && q->len[pair_q[pi]] && db->len[pair_t[pi]] ? pair_score[pi] : 0;

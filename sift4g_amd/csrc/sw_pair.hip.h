@@ -402,6 +402,131 @@ __global__ __launch_bounds__(64) void sw_pair_recheck(const RecheckArgs r) {
     }
 }
 
+// The cells of one step of a traced sweep (rows r = 0 .. RPL-1 of this lane's block at its current column): H, E, F as in the
+// score kernels, plus per cell the direction code (bits 0-1: source of H -- 0 none, 1 diagonal, 2 up (F), 3 left (E); bit 2: E of
+// this cell was opened from H; bit 3: F was) and the search for the end cell.  hu = H of the row above at this column, fin = F
+// coming from above | its "opened" bit << 31.  Written for few instructions per cell -- a per-query call's traceback launch is one
+// wave per hit walking this loop, and it was 35 instructions per cell with six branches per step: the tie rule is folded into one
+// compare against E or F (lf picks which), the "opened" bits are kept where the code wants them, and cells that equal the wanted
+// score are only looked for (row by row) in the rare step where some lane has one.  Returns the RPL codes, byte r = row r.
+template <int RPL, int NW>
+__device__ __forceinline__ typename PackOf<NW>::type
+trace_cells(int (&H)[RPL], unsigned (&E)[RPL], unsigned (&eo4)[RPL], int& hu_prev, unsigned& f_out, int& best, unsigned& key,
+            const typename PackOf<NW>::type& sc, int hu, unsigned fin, int want, unsigned cell0, unsigned open, unsigned ext,
+            bool lf, unsigned s_hit, unsigned s_miss) {
+    unsigned F = fin & 0x7FFFFFFFu;
+    unsigned fo8 = (fin >> 31) << 3;
+    int d[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int w = pk_get(sc, r / 4);
+        const int s = (int)(signed char)(w >> (8 * (r % 4)));
+        d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
+    }
+    int D[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) D[w] = 0;
+    bool anyeq = false;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int h = imax(imax(d[r], (int)E[r]), (int)F);
+        const int X = lf ? (int)E[r] : (int)F;                  // the gap source the tie rule looks at first
+        const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (h == X ? s_hit : s_miss));
+        D[r / 4] |= (int)((src | eo4[r] | fo8) << (8 * (r % 4)));
+        anyeq |= (h == want);
+        best = imax(best, h);
+        const unsigned hm = usub_sat((unsigned)h, open);
+        const unsigned En = umax_s(usub_sat(E[r], ext), hm);
+        const unsigned Fn = umax_s(usub_sat(F, ext), hm);
+        eo4[r] = En == hm ? 4u : 0u;
+        fo8 = Fn == hm ? 8u : 0u;
+        E[r] = En;
+        F = Fn;
+        H[r] = h;
+    }
+    if (anyeq) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const unsigned kc = H[r] == want ? cell0 + ((unsigned)r << 16) : 0xFFFFFFFFu;
+            key = kc < key ? kc : key;
+        }
+    }
+    f_out = F | (fo8 << 28);
+    hu_prev = hu;
+    typename PackOf<NW>::type Dv;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
+    return Dv;
+}
+
+// The backward walk of a traced pair, for the whole wave.  Lane 0 follows the direction codes from the end cell; every code it reads
+// depends on the one before, and read from HBM/L2 one at a time that is ~0.7 us per move -- 250 us for a 350-move path, most of what
+// sw_pair_trace took for a per-query call's hits (profiles/r03_dropin/).  So the wave fetches the codes in TILES into LDS -- the 64
+// step lines at and below the current step, 16 lanes wide: a path moves one or two lines down per move and one lane per RPL rows --
+// and lane 0 walks inside the tile until it leaves it.  BAND = rows per band (0: the block has one band); `tile` = 4096 * NW bytes
+// of LDS the sweep no longer needs.  Writes the moves from pe backwards and out[0..4]; tie rules as before.
+template <int RPL, int NW, int BAND>
+__device__ __forceinline__ void pair_walk(const uint8_t* __restrict__ dirs, uint64_t band_bytes, uint8_t* pe, unsigned key, unsigned cap,
+                                          int32_t* out, char* tile, int lane) {
+    constexpr int kLines = 64, kLanes = 16, kRow = kLanes * NW;         // dwords per tile line
+    int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
+    const int ei = i, ej = j;
+    unsigned n = 0, state = 0;
+    bool done = false;
+    for (;;) {
+        // the tile for the current cell (uniform: i, j are lane 0's, broadcast below)
+        const unsigned bd = BAND ? (unsigned)i / (unsigned)(BAND ? BAND : 1) : 0u;
+        const unsigned ib = BAND ? (unsigned)i % (unsigned)(BAND ? BAND : 1) : (unsigned)i;
+        const int l = (int)(ib / RPL);
+        const int k = j + l;
+        const int l_lo = l >= kLanes - 1 ? l - (kLanes - 1) : 0;
+        const int k_lo = k >= kLines - 1 ? k - (kLines - 1) : 0;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(dirs + (uint64_t)bd * band_bytes) + ((uint64_t)k_lo * 64 + l_lo) * NW;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e0 = 0; e0 < kLines * kRow; e0 += 64) {
+            const int e = e0 + lane;
+            const int t = e / kRow, c = e % kRow;
+            uint32_t v = 0;
+            if (k_lo + t <= k) v = src[(uint64_t)t * 64 * NW + c];
+            reinterpret_cast<uint32_t*>(tile)[e] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+            for (;;) {
+                if (!(i >= 0 && j >= 0 && n < cap)) { done = true; break; }
+                const unsigned bd2 = BAND ? (unsigned)i / (unsigned)(BAND ? BAND : 1) : 0u;
+                const unsigned ib2 = BAND ? (unsigned)i % (unsigned)(BAND ? BAND : 1) : (unsigned)i;
+                const int l2 = (int)(ib2 / RPL), r2 = (int)(ib2 % RPL);
+                const int k2 = j + l2;
+                if (bd2 != bd || k2 < k_lo || l2 < l_lo) break;                 // left the tile: fetch the next one
+                const unsigned c = tb[(((k2 - k_lo) * kLanes + (l2 - l_lo)) * NW) * 4 + r2];
+                if (state == 0) {
+                    const unsigned s0 = c & 3u;
+                    if (s0 == 0u) { done = true; break; }
+                    if (s0 == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }      // MOVE_DIAG
+                    else state = (s0 == 2u) ? 2u : 1u;
+                } else if (state == 1) {
+                    *(pe - 1 - n) = 2; ++n;                                      // MOVE_LEFT
+                    if (c & 4u) state = 0;
+                    --j;
+                } else {
+                    *(pe - 1 - n) = 3; ++n;                                      // MOVE_UP
+                    if (c & 8u) state = 0;
+                    --i;
+                }
+            }
+        }
+        done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+        i = __builtin_amdgcn_readfirstlane(i);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (done) break;
+    }
+    if (lane == 0) { out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Traceback of a pair (step 4 of alignDatabase for the survivors), same sweep: every cell also emits the 4-bit
 // direction code of sw_trace.hip.h (TB_*: source of H, "E opened here", "F opened here"), stored per step as one
@@ -479,51 +604,20 @@ __global__ __launch_bounds__(64) void sw_pair_trace(const PairTraceArgs a) {
         for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
         int hu_prev = 0;
         unsigned f_out = 0;         // F for the block below | "F opened here" << 31
-        unsigned eopen = 0;         // bit r: E(row r, current column) was opened from H(row r, previous column)
+        unsigned eo4[RPL];          // 4 where E(row r, current column) was opened from H(row r, previous column)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) eo4[r] = 0;
         int best = 0;
         unsigned key = 0xFFFFFFFFu;
         const char* prof_lane = prof + lane * (NW * 4);
         vnw* dst = reinterpret_cast<vnw*>(a.dirs + it.dir_off) + lane;     // step k writes dst[k * 64]
         unsigned cell0 = ((unsigned)(lane * RPL) << 16) - (unsigned)lane;  // + k = (row of r = 0) << 16 | column
+        const bool lf = a.left_first != 0;
+        const unsigned s_hit = lf ? 3u : 2u, s_miss = lf ? 2u : 3u;
         auto step = [&](const vnw& sc) {
             const int hu = wave_shr1(H[RPL - 1]);
             const unsigned fin = (unsigned)wave_shr1((int)f_out);
-            unsigned F = fin & 0x7FFFFFFFu;
-            unsigned fopen = fin >> 31;
-            int d[RPL];
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const int w = pk_get(sc, r / 4);
-                const int s = (int)(signed char)(w >> (8 * (r % 4)));
-                d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
-            }
-            int D[NW];
-#pragma unroll
-            for (int w = 0; w < NW; ++w) D[w] = 0;
-            unsigned eopen_next = 0;
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (a.left_first ? (h == (int)E[r] ? 3u : 2u) : (h == (int)F ? 2u : 3u)));
-                D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
-                if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
-                best = imax(best, h);
-                const unsigned hm = usub_sat((unsigned)h, open);
-                const unsigned En = umax_s(usub_sat(E[r], ext), hm);
-                const unsigned Fn = umax_s(usub_sat(F, ext), hm);
-                eopen_next |= (En == hm ? 1u : 0u) << r;
-                fopen = (Fn == hm) ? 1u : 0u;
-                E[r] = En;
-                F = Fn;
-                H[r] = h;
-            }
-            eopen = eopen_next;
-            f_out = F | (fopen << 31);
-            hu_prev = hu;
-            vnw Dv;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
-            *dst = Dv;
+            *dst = trace_cells<RPL, NW>(H, E, eo4, hu_prev, f_out, best, key, sc, hu, fin, want, cell0, open, ext, lf, s_hit, s_miss);
             dst += 64;
             ++cell0;
         };
@@ -564,36 +658,11 @@ __global__ __launch_bounds__(64) void sw_pair_trace(const PairTraceArgs a) {
         // the codes were written by all lanes of this wave; make them visible to lane 0's loads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (lane == 0) {
-            a.best[it.slot] = best;
-            if (key == 0xFFFFFFFFu) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; }
-            else {
-                const uint8_t* dirs = a.dirs + it.dir_off;
-                uint8_t* pe = a.paths + it.path_end;
-                int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
-                const int ei = i, ej = j;
-                unsigned n = 0, state = 0;
-                const unsigned cap = lq + lt;
-                while (i >= 0 && j >= 0 && n < cap) {
-                    const unsigned l = (unsigned)i / RPL, r = (unsigned)i % RPL;
-                    const unsigned b = dirs[((uint64_t)((unsigned)j + l) * 64 + l) * (NW * 4) + r];
-                    if (state == 0) {
-                        const unsigned src = b & 3u;
-                        if (src == 0u) break;
-                        if (src == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }      // MOVE_DIAG
-                        else state = (src == 2u) ? 2u : 1u;
-                    } else if (state == 1) {
-                        *(pe - 1 - n) = 2; ++n;                                      // MOVE_LEFT
-                        if (b & 4u) state = 0;
-                        --j;
-                    } else {
-                        *(pe - 1 - n) = 3; ++n;                                      // MOVE_UP
-                        if (b & 8u) state = 0;
-                        --i;
-                    }
-                }
-                out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n;
-            }
+        if (lane == 0) a.best[it.slot] = best;
+        if (key == 0xFFFFFFFFu) { if (lane == 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; } }
+        else {
+            pair_walk<RPL, NW, 0>(a.dirs + it.dir_off, 0, a.paths + it.path_end, key, lq + lt, out, prof, lane);
+            have_q = 0xFFFFFFFFu;          // (the tile sits where the lane profile was)
         }
     }
 }
@@ -664,52 +733,20 @@ __global__ __launch_bounds__(64) void sw_pair_trace_band(const PairTraceBandArgs
             for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
             int hu_prev = 0;
             unsigned f_out = 0;
-            unsigned eopen = 0;
+            unsigned eo4[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) eo4[r] = 0;
             vnw* dst = reinterpret_cast<vnw*>(a.dirs + it.dir_off + band * band_bytes) + lane;
             unsigned cell0 = ((row0 + (unsigned)(lane * RPL)) << 16) - (unsigned)lane;
+            const bool lf = a.left_first != 0;
+            const unsigned s_hit = lf ? 3u : 2u, s_miss = lf ? 2u : 3u;
             auto step = [&](const vnw& sc, const int2 top) {
                 const int hu = __builtin_amdgcn_update_dpp(top.x, H[RPL - 1], 0x138, 0xf, 0xf, false);
                 const unsigned fin = (unsigned)__builtin_amdgcn_update_dpp(top.y, (int)f_out, 0x138, 0xf, 0xf, false);
-                unsigned F = fin & 0x7FFFFFFFu;
-                unsigned fopen = fin >> 31;
-                int d[RPL];
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int w = pk_get(sc, r / 4);
-                    const int s = (int)(signed char)(w >> (8 * (r % 4)));
-                    d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
-                }
-                int D[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) D[w] = 0;
-                unsigned eopen_next = 0;
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                    const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (a.left_first ? (h == (int)E[r] ? 3u : 2u) : (h == (int)F ? 2u : 3u)));
-                    D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
-                    if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
-                    best = imax(best, h);
-                    const unsigned hm = usub_sat((unsigned)h, open);
-                    const unsigned En = umax_s(usub_sat(E[r], ext), hm);
-                    const unsigned Fn = umax_s(usub_sat(F, ext), hm);
-                    eopen_next |= (En == hm ? 1u : 0u) << r;
-                    fopen = (Fn == hm) ? 1u : 0u;
-                    E[r] = En;
-                    F = Fn;
-                    H[r] = h;
-                }
-                eopen = eopen_next;
-                f_out = F | (fopen << 31);
-                hu_prev = hu;
-                vnw Dv;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
-                *dst = Dv;
+                *dst = trace_cells<RPL, NW>(H, E, eo4, hu_prev, f_out, best, key, sc, hu, fin, want, cell0, open, ext, lf, s_hit, s_miss);
                 dst += 64;
                 ++cell0;
             };
-
             for (unsigned w0 = 0; w0 < nsteps; w0 += W) {
                 const unsigned kend = nsteps < w0 + W ? nsteps : w0 + W;
                 pair_stage_window(stage, res, len4, w0, kend, lane);
@@ -762,38 +799,9 @@ __global__ __launch_bounds__(64) void sw_pair_trace_band(const PairTraceBandArgs
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (lane == 0) {
-            a.best[it.slot] = best;
-            if (key == 0xFFFFFFFFu) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; }
-            else {
-                const uint8_t* dirs = a.dirs + it.dir_off;
-                uint8_t* pe = a.paths + it.path_end;
-                int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
-                const int ei = i, ej = j;
-                unsigned n = 0, state = 0;
-                const unsigned cap = lq + lt;
-                while (i >= 0 && j >= 0 && n < cap) {
-                    const unsigned bd = (unsigned)i / BAND, ib = (unsigned)i % BAND;
-                    const unsigned l = ib / RPL, r = ib % RPL;
-                    const unsigned c = dirs[bd * band_bytes + ((uint64_t)((unsigned)j + l) * 64 + l) * (NW * 4) + r];
-                    if (state == 0) {
-                        const unsigned src = c & 3u;
-                        if (src == 0u) break;
-                        if (src == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }
-                        else state = (src == 2u) ? 2u : 1u;
-                    } else if (state == 1) {
-                        *(pe - 1 - n) = 2; ++n;
-                        if (c & 4u) state = 0;
-                        --j;
-                    } else {
-                        *(pe - 1 - n) = 3; ++n;
-                        if (c & 8u) state = 0;
-                        --i;
-                    }
-                }
-                out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n;
-            }
-        }
+        if (lane == 0) a.best[it.slot] = best;
+        if (key == 0xFFFFFFFFu) { if (lane == 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; } }
+        else pair_walk<RPL, NW, BAND>(a.dirs + it.dir_off, band_bytes, a.paths + it.path_end, key, lq + lt, out, prof, lane);
     }
 }
 

@@ -258,48 +258,17 @@ __global__ __launch_bounds__(kCoopWaves * 64) void sw_pair_trace_coop(const Pair
             for (int r = 0; r < RPL; ++r) { H[r] = 0; E[r] = 0; }
             int hu_prev = 0;
             unsigned f_out = 0;         // F for the block below | "F opened here" << 31
-            unsigned eopen = 0;
+            unsigned eo4[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) eo4[r] = 0;
             vnw* dst = reinterpret_cast<vnw*>(a.dirs + it.dir_off + (uint64_t)wave * band_bytes) + lane;
             unsigned cell0 = ((row0 + (unsigned)(lane * RPL)) << 16) - (unsigned)lane;
+            const bool lf = a.left_first != 0;
+            const unsigned s_hit = lf ? 3u : 2u, s_miss = lf ? 2u : 3u;
             auto step = [&](const vnw& sc, const int2 top) {
                 const int hu = __builtin_amdgcn_update_dpp(top.x, H[RPL - 1], 0x138, 0xf, 0xf, false);
                 const unsigned fin = (unsigned)__builtin_amdgcn_update_dpp(top.y, (int)f_out, 0x138, 0xf, 0xf, false);
-                unsigned F = fin & 0x7FFFFFFFu;
-                unsigned fopen = fin >> 31;
-                int d[RPL];
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int w = pk_get(sc, r / 4);
-                    const int s = (int)(signed char)(w >> (8 * (r % 4)));
-                    d[r] = (r == 0 ? hu_prev : H[r - 1]) + s;
-                }
-                int D[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) D[w] = 0;
-                unsigned eopen_next = 0;
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const int h = imax(imax(d[r], (int)E[r]), (int)F);
-                    const unsigned src = h == 0 ? 0u : (h == d[r] ? 1u : (a.left_first ? (h == (int)E[r] ? 3u : 2u) : (h == (int)F ? 2u : 3u)));
-                    D[r / 4] |= (int)((src | (((eopen >> r) & 1u) << 2) | (fopen << 3)) << (8 * (r % 4)));
-                    if (h == want) { const unsigned kc = cell0 + ((unsigned)r << 16); key = kc < key ? kc : key; }
-                    best = imax(best, h);
-                    const unsigned hm = usub_sat((unsigned)h, open);
-                    const unsigned En = umax_s(usub_sat(E[r], ext), hm);
-                    const unsigned Fn = umax_s(usub_sat(F, ext), hm);
-                    eopen_next |= (En == hm ? 1u : 0u) << r;
-                    fopen = (Fn == hm) ? 1u : 0u;
-                    E[r] = En;
-                    F = Fn;
-                    H[r] = h;
-                }
-                eopen = eopen_next;
-                f_out = F | (fopen << 31);
-                hu_prev = hu;
-                vnw Dv;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) pk_set(Dv, w, D[w]);
-                *dst = Dv;
+                *dst = trace_cells<RPL, NW>(H, E, eo4, hu_prev, f_out, best, key, sc, hu, fin, want, cell0, open, ext, lf, s_hit, s_miss);
                 dst += 64;
                 ++cell0;
             };
@@ -364,41 +333,14 @@ __global__ __launch_bounds__(kCoopWaves * 64) void sw_pair_trace_coop(const Pair
         // the codes were written by all waves of the block; make them visible to the one lane that walks them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wave == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             for (int w = 0; w < kCoopWaves; ++w) { best = imax(best, sy.best[w]); key = sy.key[w] < key ? sy.key[w] : key; }
-            if (lq == 0 || lt == 0 || want <= 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; a.best[it.slot] = 0; }
+            if (lq == 0 || lt == 0 || want <= 0) { if (lane == 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; a.best[it.slot] = 0; } }
             else {
-                a.best[it.slot] = best;
-                if (key == 0xFFFFFFFFu) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; }
-                else {
-                    const uint8_t* dirs = a.dirs + it.dir_off;
-                    uint8_t* pe = a.paths + it.path_end;
-                    int i = (int)(key >> 16), j = (int)(key & 0xFFFFu);
-                    const int ei = i, ej = j;
-                    unsigned n = 0, state = 0;
-                    const unsigned cap = lq + lt;
-                    while (i >= 0 && j >= 0 && n < cap) {
-                        const unsigned bd = (unsigned)i / BAND, ib = (unsigned)i % BAND;
-                        const unsigned l = ib / RPL, r = ib % RPL;
-                        const unsigned c = dirs[bd * band_bytes + ((uint64_t)((unsigned)j + l) * 64 + l) * (NW * 4) + r];
-                        if (state == 0) {
-                            const unsigned src = c & 3u;
-                            if (src == 0u) break;
-                            if (src == 1u) { *(pe - 1 - n) = 1; ++n; --i; --j; }
-                            else state = (src == 2u) ? 2u : 1u;
-                        } else if (state == 1) {
-                            *(pe - 1 - n) = 2; ++n;
-                            if (c & 4u) state = 0;
-                            --j;
-                        } else {
-                            *(pe - 1 - n) = 3; ++n;
-                            if (c & 8u) state = 0;
-                            --i;
-                        }
-                    }
-                    out[0] = i + 1; out[1] = ei; out[2] = j + 1; out[3] = ej; out[4] = (int)n;
-                }
+                if (lane == 0) a.best[it.slot] = best;
+                if (key == 0xFFFFFFFFu) { if (lane == 0) { out[0] = out[1] = out[2] = out[3] = -1; out[4] = 0; } }
+                else pair_walk<RPL, NW, BAND>(a.dirs + it.dir_off, band_bytes, a.paths + it.path_end, key, lq + lt, out, prof, lane);
             }
         }
     }
