@@ -731,7 +731,9 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         const uint64_t steps = lt + (lq + rpl - 1) / rpl - 1;
         return ((steps + 1) & ~1ull) * 64 * nw * 4;
     };
-    const uint64_t dir_budget = 8ull << 30;
+    // direction blocks of a batch: in the grow-only arena (a buffer of many GB made and freed per call costs a cold process a
+    // quarter of a second in page tables alone); 10 000 pairs of 350 x 350 to a batch
+    const uint64_t dir_budget = 2ull << 30;
     std::vector<PairTraceItem> items;
     for (uint32_t b0 = 0; b0 < n;) {
         // a batch: consecutive pairs (of any classes) whose direction blocks fit the budget; one launch per class in it, one download
@@ -751,7 +753,7 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
             ++b1;
         }
         const uint32_t ni = b1 - b0;
-        const bool big_dirs = dir_total > (256ull << 20);
+        const bool big_dirs = dir_total > dir_budget + (dir_budget >> 2);          // (a single pair beyond the budget: its own allocation)
         DevBuf<uint8_t> d_dirs_big;
         if (big_dirs) HIP_TRY(d_dirs_big.alloc(dir_total));
         uint64_t need = 0;
