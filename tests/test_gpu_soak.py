@@ -2,9 +2,10 @@
 
 * test_soak_every_route: a time-boxed slice (S4G_SOAK_SECONDS, default 45) of random configurations -- scorers, tile sizes,
   lengths from 0 to a few thousand, long queries with copies of themselves -- through every device route (scan with default
-  routing / scan kernels only / int32 in the drifting and in the fixed frame / no speculation, streaming top-k, pair lists wave /
+  routing / scan kernels only / the block-cooperative strip pipeline / int32 in the drifting and in the fixed frame / no speculation, streaming top-k, pair lists wave /
   scan / packed list kernel / automatic, traceback one wave
-  per pair / strip kernels) against the CPU oracle.  `python tests/test_gpu_soak.py 900 7` runs it for 900 s with seed 7.
+  per pair / strip kernels) against the CPU oracle.  `python tests/test_gpu_soak.py 900 7` runs it for 900 s with seed 7
+  (with S4G_COOP_PAIRS=all in the environment the pair routes run on the cooperative kernels).
 * test_heavy_tailed_database: 200 queries x 200 000 targets plus six titin-sized outliers (15k .. 35k residues, one holding a
   planted copy of query 0): tiles, the long-sequence tile's pair route, spot checks against the oracle, streaming top-k against
   the top-k of the full matrix.
@@ -62,7 +63,7 @@ def soak(budget, seed):
         exp = oracle.scan(qs, ts, M, go, ge, threads=8)
         cells += sum(len(x) for x in qs) * sum(len(x) for x in ts)
         ctx = (it, go, ge, nq, nt, qmax, tmax)
-        for mode in (dict(), dict(no_pairs=True), dict(force_i32=True), dict(force_i32=True, no_drift=True), dict(no_spec=True)):
+        for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(force_i32=True), dict(force_i32=True, no_drift=True), dict(no_spec=True)):
             assert np.array_equal(s4g.scan_host(db, q, sc, **mode), exp), ("scan", mode, ctx)
         k = int(rng.integers(1, min(nt, 40) + 1))               # streaming top-k: tiles (alternating when >= 3), segments, both routings
         for mode in (dict(no_pairs=True), dict()):
