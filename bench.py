@@ -220,6 +220,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)       # does not return
 
+    # The contract is ONE line on stdout.  RCCL prints a version banner to the C stdout of every rank when a process group starts
+    # (seen with the single-rank RCCL test: four lines in front of the JSON), and any library may chatter there: from here on file
+    # descriptor 1 is stderr for everybody, and the result line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -626,14 +633,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit, AFTER the JSON:
-        # flush it first so that the JSON line is the last line of stdout
+        # (the C stdout buffer -- RCCL's banner -- goes out first, to what is now stderr)
         import ctypes
         try:
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(line, flush=True)
+        result_out.write(line + "\n")
+        result_out.flush()
         if json.loads(line).get("selfcheck", {}).get("mismatches") or json.loads(line).get("prefilter", {}).get("check", {}).get("mismatches"):
             sys.exit(3)
         # a roofline the kernel's own executed instruction rate exceeds is not a roofline: refuse to pass such a line off

@@ -117,6 +117,24 @@ def test_bench_db_shard_mode_device_generated_shards():
 
 
 @pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    """The collectives of the N > 1 job on the backend the driver's 8-GPU run uses -- RCCL ("nccl"), device tensors -- exercised
+    with a process group of ONE rank on this box's GPU (S4G_BENCH_FORCE_DIST=1): init with a device id, the all-reduce that
+    counts the ranks, the all-gather of the packed hit lists and the merge, in both sharding modes.  (The emulated N-rank tests
+    above run the same job over gloo; two ranks cannot share a device under RCCL.)"""
+    env = {"S4G_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}
+    d = _run_bench("--gpus", "1", "--workload", "configs2", "--steps", "2", "--warmup", "1", "--queries", "20", "--targets", "5000",
+                   "--no-cpu-baseline", "--no-tiers", "--no-prefilter", "--no-scale-ref", env=env)
+    _check_common(d, 1, 2, 1)
+    assert d["backend"] == "RCCL (nccl)" and d["rccl_ranks"] == 1 and not d["emulated"]
+    assert d["selfcheck"]["mismatches"] == 0 and d["selfcheck"]["top_list_entries"] > 0
+    d = _run_bench("--gpus", "1", "--mode", "db-shard", "--steps", "1", "--warmup", "1", "--queries", "6", "--targets", "30000",
+                   "--no-cpu-baseline", env=env)
+    _check_common(d, 1, 1, 1)
+    assert d["backend"] == "RCCL (nccl)" and d["selfcheck"]["planted_not_first"] == 0 and d["selfcheck"]["mismatches"] == 0
+
+
+@pytest.mark.gpu
 def test_bench_eight_rank_rehearsal_on_one_gpu():
     """The job the driver launches on an 8-GPU node, rehearsed with its eight ranks sharing this box's GPU(s): a query count that
     does not divide by 8 (ragged shards), per-phase timings and the all-gather payload in the line, self-check of rank 0's lists;
