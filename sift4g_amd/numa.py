@@ -104,6 +104,8 @@ def pin_to_gpu(local_index, kfd_root=_KFD, node_root="/sys/devices/system/node")
     want = cpus & allowed
     if not want:
         return dict(info, numa_node=node, reason="none of the node's CPUs is in this process's affinity mask")
+    if len(want) < 4 and len(allowed) > len(want):
+        return dict(info, numa_node=node, reason=f"the node offers {len(want)} CPU(s) only: not worth leaving {len(allowed)} for")
     try:
         os.sched_setaffinity(0, want)
     except OSError as exc:
