@@ -215,7 +215,10 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
     uint32_t ra_n = res[0], rb_n = SCAN ? ra_n : res[64];
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
     if (!first && len4) { wait_for(1); hb_n = wsH[lane]; fb_n = wsF[lane]; }
+    // the profile reads run TWO blocks of four rows ahead of the arithmetic: one block (22 instructions) does not cover an LDS round
+    // trip when a wave has its SIMD to itself -- the case of a long item that a call of few queries waits for
     v4i xa_n = lst_load(prof, pk_taddr(ra_n, 0), 0), xb_n = lst_load(profb, pk_taddr(rb_n, 0), 0);
+    v4i xa_m = lst_load(prof, pk_taddr(ra_n, 0), 1), xb_m = lst_load(profb, pk_taddr(rb_n, 0), 1);
     for (unsigned c = 0; c < len4; ++c) {
         const uint32_t ra = ra_n, rb = rb_n;
         const v4i hb = hb_n, fb = fb_n;
@@ -236,8 +239,9 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const v4i xa = xa_n, xb = xb_n;
-                if (b + 1 < NB) { xa_n = lst_load(prof, ta, b + 1); xb_n = lst_load(profb, tb, b + 1); }
-                else { xa_n = lst_load(prof, ta_next, 0); xb_n = lst_load(profb, tb_next, 0); }
+                xa_n = xa_m; xb_n = xb_m;
+                if (b + 2 < NB) { xa_m = lst_load(prof, ta, b + 2); xb_m = lst_load(profb, tb, b + 2); }
+                else { xa_m = lst_load(prof, ta_next, b + 2 - NB); xb_m = lst_load(profb, tb_next, b + 2 - NB); }
                 lst_rows4<R>(H, E, 4 * b, xa, xb, diag, F, best, eo, zcur, e2c);
             }
             hdiag = first ? zcol - e2 : hb[cc];
