@@ -1252,3 +1252,34 @@ def test_cooperative_pair_kernels(mode):
         env["S4G_COOP_PAIRS"] = mode
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "coop_pairs_check.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_scan_pipeline_switch_in_a_fresh_process():
+    """S4G_SCAN_PIPE_MAX_QUERIES (read once per process): 0 keeps every small call on the split model, 5 takes calls of 3..5 queries to
+    the block pipeline -- the score matrices are the oracle's either way and s4g_scan_stats tells which route ran."""
+    import subprocess, sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, oracle, sift4g_amd as s4g
+from sift4g_amd import device
+from conftest import rand_seqs
+rng = np.random.default_rng(9)
+lens = np.clip(np.exp(rng.normal(5.4, 0.6, size=17000)), 20, 2500).astype(int)
+ts = [rand_seqs(rng, 1, int(l), int(l), 20)[0] for l in lens]
+qs = rand_seqs(rng, 7, 200, 380, 20)
+db, q = s4g.Database(ts), s4g.QuerySet(qs)
+sc = s4g.Scorer("BLOSUM_62", 10, 1)
+tc, to = oracle._flat(ts); qc, qo = oracle._flat(qs)
+exp = oracle.scan_simd_flat(qc, qo, tc, to, oracle.blosum62(), 10, 1, threads=8)
+if exp is None: exp = oracle.scan_flat(qc, qo, tc, to, oracle.blosum62(), 10, 1, threads=8)
+want = int(os.environ["S4G_SCAN_PIPE_MAX_QUERIES"])
+for nq in (2, 4, 7):
+    assert np.array_equal(s4g.scan_host(db, q, sc, q_begin=0, q_count=nq), exp[:nq]), nq
+    piped = device.scan_stats(0)["list_pairs"]
+    assert piped == (nq * len(ts) if 3 <= nq <= want else 0), (nq, want, piped)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for limit in ("0", "5"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, S4G_SCAN_PIPE_MAX_QUERIES=limit))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (limit, r.stdout[-500:], r.stderr[-2000:])
