@@ -450,7 +450,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     t_alloc += us(ta2, now());
     hipLaunchKernelGGL(list_gather, dim3(n_items), dim3(256), 0, stream, B.items, B.vals_out, db->d_seq_addr, db->d_seq_len, cx->d_lst_res);
     // the pair waves go out while the device gathers -- and before the list kernel's persistent blocks take every wave slot
-    rc = submit_waves();            // (A/B against submitting them before the item table: 9.96 against 10.09 ms per call, mean of 4 and 3)
+    rc = submit_waves();            // (A/B against submitting them before the item table: 9.96 against 10.09 ms per call, mean of 4 and 3;
+                                    // raised wave priority for the pair kernels, so that they do not crawl underneath the list kernel's
+                                    // blocks: 10.65 against 10.38 ms -- the pipeline's waves stall behind them)
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(cx->d_counter + kListCounter, 0, 4, stream));
     ListArgs a;
