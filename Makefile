@@ -22,7 +22,7 @@ build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 # libs4g_hip.so: one object per translation unit (make -j builds them side by side), every unit depends on every header
-HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip $(CSRC)/s4g_diag.hip $(CSRC)/s4g_lists.hip $(CSRC)/s4g_prefilter.hip $(CSRC)/s4g_chains.hip $(CSRC)/s4g_stream.hip
+HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip $(CSRC)/s4g_diag.hip $(CSRC)/s4g_lists.hip $(CSRC)/s4g_prefilter.hip $(CSRC)/s4g_chains.hip $(CSRC)/s4g_stream.hip $(CSRC)/s4g_gather.hip
 HIPOBJ  := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIPSRC))
 HIPHDR  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/s4g_hip.h
 
@@ -32,7 +32,7 @@ build/obj/%.o: $(CSRC)/%.hip $(HIPHDR)
 
 $(LIBDIR)/libs4g_hip.so: $(HIPOBJ) tools/check_denorm.py
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@.tmp $(HIPOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@.tmp $(HIPOBJ) -ldl
 	@# the packed kernels' integer max3 needs f16 denormals preserved: refuse a build whose kernel descriptors say otherwise
 	python3 tools/check_denorm.py $@.tmp || { rm -f $@.tmp; exit 1; }
 	mv $@.tmp $@

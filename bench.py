@@ -126,7 +126,7 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
     residues = int(t_off[-1])
     d_codes = torch.from_numpy(cfg["t_codes"][:max(residues, 1)]).cuda(dev_index)
     d_off = torch.from_numpy(np.asarray(t_off).astype(np.int64)).cuda(dev_index)
-    best = dict(index=1e9, add=1e9, finish=1e9)
+    best = dict(index=1e9, add=1e9, finish=1e9, call=1e9)
     stats = None
     for _ in range(reps + 1):                          # the first round grows the buffers
         torch.cuda.synchronize()
@@ -137,7 +137,8 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
         p.finish(); t3 = time.perf_counter()
         stats = p.stats()
         p.close()
-        best = dict(index=min(best["index"], t1 - t0), add=min(best["add"], t2 - t1), finish=min(best["finish"], t3 - t2))
+        best = dict(index=min(best["index"], t1 - t0), add=min(best["add"], t2 - t1), finish=min(best["finish"], t3 - t2),
+                    call=min(best["call"], t3 - t0))
     m = min(check_targets, nt)
     sample = [cfg["t_codes"][int(t_off[i]):int(t_off[i + 1])] for i in range(m)]
     t0 = time.perf_counter()
@@ -164,8 +165,9 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
             traffic = pj
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "achieved": round(alg_bytes / best["add"] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg_bytes / best["add"] / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes,
+    # (the rate is over the WHOLE call -- index + add + finish, host to host -- not over the add alone)
+    roof = {"bound": "hbm", "achieved": round(alg_bytes / best["call"] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_bytes / best["call"] / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes,
             "traffic": traffic["hbm_bytes_per_add"] if traffic else None, "traffic_measured_in_run": False,
             "traffic_source": traffic["source"] if traffic else None,
             "note": "integer gather work: the target kernel is bound by vector issue and scattered 4/8-byte lookups (bitmap, bucket bounds, hits), "
@@ -174,7 +176,9 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
             "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues, "roofline": roof,
             "path": "fused" if stats.get("fused") else "general", "general_path_targets": stats.get("general_path_targets"),
             "index_ms": round(best["index"] * 1e3, 3), "add_ms": round(best["add"] * 1e3, 3), "finish_ms": round(best["finish"] * 1e3, 3),
-            "residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],
+            "call_ms": round(best["call"] * 1e3, 3), "residues_per_s": round(residues / best["call"], 1),
+            "residues_per_s_basis": "database residues / (index + add + finish) of the fastest whole call",
+            "add_residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],
             "check": {"targets": m, "mismatches": bad, "against": "oracle/kmer_prefilter.c (CPU restatement, 1 thread)",
                       "cpu_residues_per_s": round(int(t_off[m]) / cpu_s, 1)}}
 
@@ -210,6 +214,7 @@ def main():
     ap.add_argument("--no-drift", action="store_true", help="skip the drifting-frame kernel (maximum3 tier instead)")
     ap.add_argument("--no-spec", action="store_true", help="tiers by score bound only: no speculative use of the drifting-frame kernel for long queries")
     ap.add_argument("--mode", choices=["query-shard", "db-shard"], default="query-shard")
+    ap.add_argument("--step-seconds", type=float, default=120.0, help="db-shard without --targets: size of the shard a step scans, in seconds per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the k-mer prefilter leg after the timed region")
@@ -286,8 +291,15 @@ def main():
 
     if db_shard:
         # ---- configs[3]: this rank's shard of a UniRef90-scale database, generated where it will be scanned ----
-        n_per = args.targets if args.targets is not None else CONFIGS3_TARGETS // 8
         nq = args.queries if args.queries is not None else 32
+        # time-boxed ("run N DB tiles, report measured GCUPS and extrapolated wall time"): the shard a step scans is cut
+        # so that one step is about --step-seconds at ~11 TCUPS, but never below 1.25 M targets (two database tiles): 32 queries
+        # scan the whole 18.75 M-target share, the config's own 10 000 queries scan 1.25 M targets of it per step
+        if args.targets is not None:
+            n_per = args.targets
+        else:
+            fit = int(args.step_seconds * 11.0e12 / (nq * 350.0 * 340.0))
+            n_per = max(1_250_000, min(CONFIGS3_TARGETS // 8, fit))
         qlen = tuple(args.qlen) if args.qlen else (300, 400)
         wl_label = "BASELINE configs[3] (UniRef90 scale, DB sharded)"
         qseed = synth.SEED_BASE + 4
@@ -445,10 +457,14 @@ def main():
         valu_all_full = kern_gcups * ops / 1e3       # round 2's figure: every instruction a full slot
         # executed (not algorithmic) lane-ops per cell: SQ_INSTS_VALU x 64 / cells of a committed rocprofv3 --pmc pass of this
         # command (profiles/valu_executed.json, tagged with the commit it was collected on)
+        # (both stored figures are keyed on a hash of the scan kernels' sources -- sift4g_amd/srchash.py -- and stay null when the
+        # build that is running was made from other sources than the build that was profiled)
+        from sift4g_amd.srchash import kernel_source_sha
+        src_sha = kernel_source_sha()
         exec_ops, exec_src = None, None
         try:
             ve = json.load(open(os.path.join(ROOT, "profiles", "valu_executed.json"))).get(plan["kernel"])
-            if ve and ve.get("workload_cells") == cells_rank:
+            if ve and ve.get("workload_cells") == cells_rank and ve.get("kernel_source_sha") == src_sha:
                 exec_ops, exec_src = ve["lane_ops_per_cell"], ve.get("source")
         except Exception:
             exec_ops = None
@@ -458,18 +474,21 @@ def main():
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
-                if pj.get("kernel") == plan["kernel"] and pj.get("workload_cells") == cells_rank:
+                if pj.get("kernel") == plan["kernel"] and pj.get("workload_cells") == cells_rank and pj.get("kernel_source_sha") == src_sha:
                     traffic, traffic_src = pj.get("hbm_bytes_per_launch"), pj.get("source")
             except Exception:
                 traffic = None
         hbm_achieved = kern_gcups * BYTES_PER_CELL
         tier = "int32" if plan["kernel"].startswith("sw_scan_i32") else ("f16" if "F16" in plan["kernel"] else "int16")
+        dtype = {"int32": "int32",
+                 "int16": "int16x2 packed, exact by score-bound routing; int32 out",
+                 "f16": "f16x2 arithmetic on integers (exact below 4096 by score-bound routing); int32 out"}[tier]
         out = {
             "metric": "GCUPS (SW cell updates/s) on query x DB scan",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak" if db_shard else "strong",
-            "vs_baseline": None, "dtype": tier, "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "rccl_ranks": rccl_ranks, "backend": ("RCCL (nccl)" if backend == "nccl" else backend), "emulated": bool(share and n_dev < world),
             "config": {
                 "workload": (f"{wl_label}: {nq} synthetic queries per step len U[{qlen[0]},{qlen[1]}] x {n_per} device-generated targets per GPU "
@@ -483,15 +502,18 @@ def main():
                 "kernel": plan["kernel"], "grid_blocks": plan["grid_blocks"], "strip_rows": plan["strip_rows"]},
             "roofline": {
                 "bound": "valu", "achieved": round(valu_achieved, 3), "peak": round(valu_peak, 3), "unit": "T lane-ops/s",
-                "frac": round(valu_achieved / valu_peak, 4) if valu_peak else None, "traffic": traffic,
-                "traffic_measured_in_run": False,
+                "frac": round(valu_achieved / valu_peak, 4) if valu_peak else None,
+                # the same launch under the other issue model (every instruction a full slot, none paired): read the two together
+                "frac_every_instruction_a_full_slot": round(valu_all_full / valu_peak, 4) if valu_peak else None,
+                "frac_model": "frac: two-VGPR-source 32-bit add/sub count half an issue slot (a lower bound on what the kernel uses); "
+                              "frac_every_instruction_a_full_slot: no pairing at all (an upper bound)",
+                "traffic": traffic, "traffic_measured_in_run": False, "kernel_source_sha": src_sha,
                 "kernel": plan["kernel"], "kernel_ms": round(kern_ms, 3), "kernel_gcups": round(kern_gcups, 2),
                 "ops_per_cell": ops, "half_slot_ops_per_cell": half_ops, "issue_slots_per_cell": slots,
                 "peak_basis": f"{cus} CU x 4 SIMD x {LANES_PER_CLK_PER_SIMD} lanes/clk x {GUIDE_CLOCK_MHZ:.0f} MHz (guide peak engine clock): one vector "
                               "instruction per SIMD and 4-clock issue slot; two-VGPR-source add/sub/logic/mov count half a slot (they can pair up across waves)",
                 # achieved = algorithmic issue slots per cell (x 64 lanes) x cells / the kernel's HIP-event time; frac_algorithmic = frac
                 "frac_algorithmic": round(valu_achieved / valu_peak, 4) if valu_peak else None,
-                "frac_every_instruction_a_full_slot": round(valu_all_full / valu_peak, 4) if valu_peak else None,
                 "executed_ops_per_cell": exec_ops, "executed": round(valu_executed, 3) if valu_executed else None,
                 "frac_executed": round(valu_executed / valu_peak, 4) if valu_executed else None,
                 "executed_source": exec_src,
@@ -520,6 +542,10 @@ def main():
         if db_shard:
             full_cells = float(CONFIGS3_QUERIES) * (cells_total / nq)
             full_cells *= CONFIGS3_TARGETS / float(n_targets_total)
+            out["config"]["queries"] = nq
+            out["config"]["targets_per_gpu"] = n_per
+            out["config"]["database_tiles_per_gpu"] = len(db.tiles())
+            out["config"]["time_boxed"] = (n_per < CONFIGS3_TARGETS // 8 or nq < CONFIGS3_QUERIES)
             out["config"]["extrapolated"] = {"full_config": f"{CONFIGS3_QUERIES} queries x {CONFIGS3_TARGETS} targets on 8 GPUs",
                                              "cells": full_cells, "wall_s_at_this_rate_per_gpu_x8": round(full_cells / (gcups / world * 8 * 1e9), 1)}
 

@@ -44,6 +44,11 @@
  *       steps 2-3 of swsharp alignDatabase: keep the best maxAlignments
  *       targets per query (database_alignment.cpp:83-86 `max_alignments`),
  *       and the merge semantics of dbAlignmentsMerge (:101-102)
+ *   s4g_comm_unique_id / s4g_comm_create / s4g_comm_info / s4g_comm_destroy / s4g_gather_topk / s4g_merge_topk / s4g_merge_topk_host
+ *       dbAlignmentsMerge across database chunks (/root/reference/sift4g/src/database_alignment.cpp:97-104) applied across the
+ *       GPUs of a node, one process per GPU: the reference runs its cards as threads of one process (main.cpp:254-262 hands the
+ *       `cards` list to alignDatabase) and merges on the host; here every rank keeps its lists on its device and one RCCL
+ *       all-gather over xGMI + a merge on the device give every rank the final lists
  */
 #ifndef S4G_HIP_H
 #define S4G_HIP_H
@@ -330,6 +335,43 @@ int s4g_prefilter_add_device(s4g_prefilter* p, const uint8_t* d_codes, const uin
 int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores);
 int s4g_prefilter_stats(const s4g_prefilter* p, uint64_t* out, uint32_t cap);
 int s4g_prefilter_destroy(s4g_prefilter* p);
+
+/* ---- multi-GPU: the final gather of the per-query top-hit lists ------------------------------------------
+ * One process per GPU.  The scan needs no exchange (pairs are independent); the ranks meet once, after it.
+ *   s4g_comm_unique_id   128 bytes that name a communicator: ONE rank calls it and hands the bytes to the others (a file, a pipe,
+ *                        MPI, torch.distributed ...).  Opens librccl on first use (S4G_ERR_NO_DEVICE if there is none).
+ *   s4g_comm_create      collective: every rank of `world` calls it with the same id, its own rank and the device it scans on.
+ *   s4g_gather_topk      collective, asynchronous on `stream`; all pointers are DEVICE pointers in the layout s4g_topk /
+ *                        s4g_scan_topk write (ids 0xFFFFFFFF = unused, lists ordered by score descending then id ascending).
+ *     S4G_GATHER_QUERY_SHARD  database replicated; this rank holds the lists of queries [n*rank/world, n*(rank+1)/world) of the
+ *                        n_queries in total (d_ids / d_scores [own queries][k], d_counts [own queries]; may be NULL for a rank
+ *                        without queries).  Out: all n_queries lists in query order, on every rank.  k_out must equal k;
+ *                        id_base / d_id_map are ignored.
+ *     S4G_GATHER_DB_SHARD     every rank holds lists of ALL n_queries over its own slice of the database, ids local to the slice:
+ *                        global id = local id + id_base, or d_id_map[local id] when d_id_map != NULL (the map must be
+ *                        ascending, so that a rank's own tie order is the global one).  Out: per query the best k_out of the
+ *                        world * k gathered entries, score descending then global id ascending -- what one scan of the whole
+ *                        database followed by s4g_topk returns.
+ *   s4g_merge_topk       the merge kernel alone, on lists that are in device memory already: d_ids / d_scores [lists][n_queries][k_in]
+ *                        (global ids, every row ordered, 0xFFFFFFFF only at its end) -> [n_queries][k_out]; asynchronous on `stream`.
+ *   s4g_merge_topk_host  the same K-way merge in host memory, no device: ids / scores [lists][n_queries][k_in] (global ids, every
+ *                        row ordered, 0xFFFFFFFF only at its end) -> [n_queries][k_out].  What a host merges with when the
+ *                        lists came to it by other means (the CPU tests' gloo gather). */
+typedef struct s4g_comm s4g_comm;
+#define S4G_GATHER_QUERY_SHARD 0
+#define S4G_GATHER_DB_SHARD    1
+int s4g_comm_unique_id(uint8_t* id128);
+int s4g_comm_create(s4g_comm** out, int device, int rank, int world, const uint8_t* id128);
+/* any out pointer may be NULL; rccl_version as ncclGetVersion reports it */
+int s4g_comm_info(const s4g_comm* comm, int* rank, int* world, int* device, int* rccl_version);
+int s4g_comm_destroy(s4g_comm* comm);
+int s4g_gather_topk(s4g_comm* comm, int mode, uint32_t n_queries, uint32_t k, const uint32_t* d_ids, const int32_t* d_scores,
+                    const uint32_t* d_counts, uint32_t id_base, const uint32_t* d_id_map, uint32_t k_out, uint32_t* d_out_ids,
+                    int32_t* d_out_scores, uint32_t* d_out_counts, void* stream);
+int s4g_merge_topk(int device, uint32_t lists, uint32_t n_queries, uint32_t k_in, const uint32_t* d_ids, const int32_t* d_scores,
+                   uint32_t k_out, uint32_t* d_out_ids, int32_t* d_out_scores, uint32_t* d_out_counts, void* stream);
+int s4g_merge_topk_host(uint32_t lists, uint32_t n_queries, uint32_t k_in, const uint32_t* ids, const int32_t* scores,
+                        uint32_t k_out, uint32_t* out_ids, int32_t* out_scores, uint32_t* out_counts);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,17 @@ SIGNATURES = {
     "s4g_prefilter_finish": (ctypes.c_int, [ctypes.c_void_p, c_u32p, c_u32p, ctypes.POINTER(ctypes.c_float)]),
     "s4g_prefilter_stats": (ctypes.c_int, [ctypes.c_void_p, c_u64p, ctypes.c_uint32]),
     "s4g_prefilter_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "s4g_comm_unique_id": (ctypes.c_int, [c_u8p]),
+    "s4g_comm_create": (ctypes.c_int, [c_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p]),
+    "s4g_comm_info": (ctypes.c_int, [ctypes.c_void_p, c_ip, c_ip, c_ip, c_ip]),
+    "s4g_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "s4g_gather_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
+    "s4g_merge_topk": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s4g_merge_topk_host": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_u32p, c_i32p, ctypes.c_uint32, c_u32p, c_i32p,
+                                           c_u32p]),
 }
 
 # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  If our

@@ -90,7 +90,18 @@ S4G_API int s4g_db_create_cached(s4g_db** out, int device, const uint8_t* const*
         if (A.cur_cap - A.cur_used < pack_bytes) {
             const uint64_t want = std::max(kArenaBlock, pack_bytes);
             char* blk = nullptr;
-            HIP_TRY(hipMalloc((void**)&blk, want));
+            hipError_t me = hipMalloc((void**)&blk, want);
+            if (me != hipSuccess && A.live == 0 && !A.blocks.empty()) {
+                // HBM is full of chains nobody is using: start the arena over and try again.  Tags handed out in THIS call
+                // so far: none (the hits of this call were checked against `tag` above, so they go stale -- send everything)
+                (void)hipGetLastError();
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto& b : A.blocks) (void)hipFree(b.first);
+                A.blocks.clear(); A.cur = nullptr; A.cur_cap = A.cur_used = A.bytes = 0; A.chains = 0;
+                ++A.gen;
+                return fail(S4G_ERR_NOMEM, "chain arena of device %d started over (out of HBM): call again", device);
+            }
+            if (me != hipSuccess) { (void)hipGetLastError(); return fail(S4G_ERR_NOMEM, "no room for a chain arena block of %llu bytes on device %d: %s", (unsigned long long)want, device, hipGetErrorString(me)); }
             A.blocks.emplace_back(blk, want);
             A.cur = blk; A.cur_cap = want; A.cur_used = 0; A.bytes += want;
         }
@@ -156,14 +167,16 @@ S4G_API int s4g_db_create_cached(s4g_db** out, int device, const uint8_t* const*
         if (!blk) {
             blk_bytes = tab_bytes + tab_bytes / 4;
             hipError_t e = hipMalloc((void**)&blk, blk_bytes);
-            if (e != hipSuccess) { delete db; return fail(S4G_ERR_HIP, "hipMalloc of the candidate tables failed: %s", hipGetErrorString(e)); }
+            // (the pack upload above may still be reading h_stage: the next call's stage_reserve waits on stage_done, so every exit
+            // from here on leaves the staging buffer idle first)
+            if (e != hipSuccess) { (void)hipStreamSynchronize(nullptr); delete db; return fail(S4G_ERR_HIP, "hipMalloc of the candidate tables failed: %s", hipGetErrorString(e)); }
         }
         db->d_cached_block = blk; db->cached_block_bytes = blk_bytes;
         char* h_tab = A.h_stage + (pack_bytes + 255) / 256 * 256;
         memcpy(h_tab, addrs, (size_t)n_seqs * 8);
         memcpy(h_tab + (size_t)n_seqs * 8, lens, (size_t)n_seqs * 4);
         hipError_t e = hipMemcpyAsync(blk, h_tab, (size_t)n_seqs * 12, hipMemcpyHostToDevice, nullptr);
-        if (e != hipSuccess) { (void)hipFree(blk); delete db; return fail(S4G_ERR_HIP, "upload of the candidate tables failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(nullptr); (void)hipFree(blk); delete db; return fail(S4G_ERR_HIP, "upload of the candidate tables failed: %s", hipGetErrorString(e)); }
         db->d_seq_addr = reinterpret_cast<uint64_t*>(blk);
         db->d_seq_len = reinterpret_cast<uint32_t*>(blk + (size_t)n_seqs * 8);
         db->seq_tables_in_block = true;

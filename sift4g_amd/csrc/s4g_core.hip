@@ -117,7 +117,7 @@ int warm_core_kernels(DeviceCtx* cx) {
 
 // ---------------------------------------------------------------------------
 S4G_API const char* s4g_last_error(void) { return g_err.c_str(); }
-S4G_API int s4g_abi_version(void) { return 4; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info, s4g_db_open_streamed, s4g_db_stream_stats
+S4G_API int s4g_abi_version(void) { return 5; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info, s4g_db_open_streamed, s4g_db_stream_stats; 5: + s4g_comm_*, s4g_gather_topk, s4g_merge_topk_host
 
 S4G_API int s4g_device_count(int* count) {
     if (!count) return fail(S4G_ERR_INVALID, "count is NULL");

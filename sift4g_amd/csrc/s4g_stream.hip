@@ -70,9 +70,17 @@ S4G_API int s4g_db_open_streamed(s4g_db** out, int device, const char* path) {
     db->len.resize(db->n_seqs); db->pos_of_id.resize(db->n_seqs);
     if ((db->n_seqs && fread(db->len.data(), 4, db->n_seqs, f) != db->n_seqs) || (db->n_seqs && fread(db->pos_of_id.data(), 4, db->n_seqs, f) != db->n_seqs))
         return bad("length tables");
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) return bad("cannot stat the file");
+    uint64_t seqs_seen = 0, padded_seen = 0, residues_seen = 0;
     for (uint32_t i = 0; i < nt; ++i) {
         TileHeaderS h;
         if (fread(&h, sizeof h, 1, f) != 1) return bad("tile header");
+        // the header's numbers against each other (what s4g_db_save guarantees): device pointers are derived from them
+        if (h.n_groups != (h.n_seqs + 63) / 64 || h.dwords * 4 != h.padded_residues || h.residues > h.padded_residues ||
+            h.dwords > (uint64_t)h.n_groups * 64 * h.max_len4 || h.pos0 != seqs_seen)
+            return bad("inconsistent tile header");
+        seqs_seen += h.n_seqs; padded_seen += h.padded_residues; residues_seen += h.residues;
         db->tiles.emplace_back();
         Tile& t = db->tiles.back();
         t.n_seqs = h.n_seqs; t.n_groups = h.n_groups; t.max_len4 = h.max_len4; t.residues = h.residues;
@@ -82,10 +90,10 @@ S4G_API int s4g_db_open_streamed(s4g_db** out, int device, const char* path) {
         s->bytes.push_back(b);
         s->slot_bytes = std::max(s->slot_bytes, b);
         db->max_tile_seqs = std::max(db->max_tile_seqs, t.n_seqs);
+        if (s->file_off.back() + b > (uint64_t)st.st_size) return bad("file shorter than its tiles (truncated?)");     // every tile, not only the last
         if (fseeko(f, (off_t)b, SEEK_CUR) != 0) return bad("tile payload");
     }
-    struct stat st;
-    if (fstat(fileno(f), &st) != 0 || (nt && (uint64_t)st.st_size < s->file_off.back() + s->bytes.back())) return bad("file shorter than its tiles");
+    if (seqs_seen != db->n_seqs || padded_seen != db->padded_residues || residues_seen != db->residues) return bad("tile headers do not add up to the file header");
     s->slot_bytes = (s->slot_bytes + 4095) / 4096 * 4096;
     for (int k = 0; k < 2 && s->slot_bytes; ++k) {
         if (hipHostMalloc((void**)&s->h_pin[k], s->slot_bytes, hipHostMallocDefault) != hipSuccess ||
@@ -114,6 +122,15 @@ int db_stream_load(const s4g_db* db, size_t ti) {
     if (fseeko(s->f, (off_t)s->file_off[ti], SEEK_SET) != 0 || fread(s->h_pin[k], 1, s->bytes[ti], s->f) != s->bytes[ti])
         return fail(S4G_ERR_HIP, "reading tile %zu of the packed database failed", ti);
     const double t2 = now_sec();
+    {   // the group tables of the payload against the header (the kernels index the slot with them)
+        const Tile& m = db->tiles[ti];
+        const uint64_t* goff = reinterpret_cast<const uint64_t*>(s->h_pin[k]);
+        const uint32_t* glen = reinterpret_cast<const uint32_t*>(s->h_pin[k] + (uint64_t)m.n_groups * 8);
+        const uint64_t dwords = m.padded_residues / 4;
+        for (uint32_t g = 0; g < m.n_groups; ++g)
+            if (glen[g] > m.max_len4 || goff[g] > dwords || (uint64_t)glen[g] * 64 > dwords - goff[g])
+                return fail(S4G_ERR_INVALID, "tile %zu of the packed database is corrupt (group %u lies outside the tile)", ti, g);
+    }
     HIP_TRY(hipMemcpyAsync(s->d_slot[k], s->h_pin[k], s->bytes[ti], hipMemcpyHostToDevice, s->copy_stream));
     HIP_TRY(hipEventRecord(s->uploaded[k], s->copy_stream));
     s->slot_used[k] = true;

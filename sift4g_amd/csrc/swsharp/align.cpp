@@ -176,6 +176,7 @@ SW_API ChainDatabase* chainDatabaseCreateFlat(const char* codes, const size_t* o
         Chain& c = db->stubs[i];
         memset(&c, 0, sizeof c);
         c.data = &nobody; c.length = (int)(offsets[i + 1] - offsets[i]); c.embedded = true;
+        c.flat_name = names + nameOffsets[i]; c.flat_name_len = (int)(nameOffsets[i + 1] - nameOffsets[i]);
         db->stub_ptrs[i] = &c;
     }
     db->chains = db->stub_ptrs.data();
@@ -186,8 +187,11 @@ SW_API ChainDatabase* chainDatabaseCreateFlat(const char* codes, const size_t* o
 
 namespace swimpl {
 
+// (one std::thread per card runs candidates_on_card / shotgun_on_card against the same database, and two queries on different
+// cards may report the same target: the real chain is built once, under the database's lock)
 Chain* real_chain(ChainDatabase* db, int idx) {
     if (!db->flat_off) return db->chains[idx];
+    std::lock_guard<std::mutex> lk(db->real_mu);
     if (!db->real[idx]) {
         const size_t n = db->flat_off[idx + 1] - db->flat_off[idx];
         std::string letters(n, 'A');
@@ -198,9 +202,27 @@ Chain* real_chain(ChainDatabase* db, int idx) {
     return db->real[idx];
 }
 
-// the cached form: up to this many chains (a per-query candidate list is <= 5000, main.cpp:69) and only where it is wanted
+int chain_name_cmp(const Chain* a, const Chain* b) {
+    const char* na = a->flat_name ? a->flat_name : chainGetName(const_cast<Chain*>(a));
+    const char* nb = b->flat_name ? b->flat_name : chainGetName(const_cast<Chain*>(b));
+    const size_t la = a->flat_name ? (size_t)a->flat_name_len : strlen(na), lb = b->flat_name ? (size_t)b->flat_name_len : strlen(nb);
+    const int c = memcmp(na, nb, std::min(la, lb));
+    return c ? c : (la < lb ? -1 : la > lb ? 1 : 0);
+}
+
+// the cached form: up to this many chains (a per-query candidate list is <= 5000, main.cpp:69) and only where it is wanted.
+// A Chain carries ONE (dev_tag, dev_addr) pair, so the process has ONE chain-cache device: the first card of the first database
+// that takes the cached form claims it; databases whose first card is another device take the packed form instead (a chain
+// looked up in another device's arena would miss every time and be appended again).
 static const bool g_chain_cache_on = getenv("S4G_NO_CHAIN_CACHE") == NULL;
-bool cached_form_fits(const ChainDatabase* db) { return g_chain_cache_on && !db->flat_off && db->length > 0 && db->length <= 32768; }
+static std::atomic<int> g_cache_device{-1};
+static std::mutex g_cache_mu;                 // the chains' cache words are shared between databases (and host threads)
+bool cached_form_fits(const ChainDatabase* db) {
+    if (!(g_chain_cache_on && !db->flat_off && db->length > 0 && db->length <= 32768)) return false;
+    int want = -1;
+    const int mine = db->cards.empty() ? db->device : db->cards[0];
+    return g_cache_device.compare_exchange_strong(want, mine) || want == mine;
+}
 
 s4g_db* packed_replica(ChainDatabase* db, int slot) {
     if (db->replicas[slot]) return db->replicas[slot];
@@ -233,6 +255,7 @@ s4g_db* packed_replica(ChainDatabase* db, int slot) {
 // Two tables into the first card's chain arena: chains the device holds already are not sent again (their Chain objects say
 // where they are), the others are appended to the arena.  Serves s4g_score_pairs_host / s4g_traceback_host only.
 s4g_db* cached_replica(ChainDatabase* db) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     if (db->cached) return db->cached;
     Phase ph(0);
     const size_t n = (size_t)db->length;
@@ -247,6 +270,9 @@ s4g_db* cached_replica(ChainDatabase* db) {
     }
     s4g_db* rep = NULL;
     int rc = s4g_db_create_cached(&rep, db->cards[0], seqs.data(), lens.data(), tags.data(), addrs.data(), (uint32_t)n);
+    if (rc == S4G_ERR_NOMEM)        // the arena had to start over (or HBM is short): once more, then the packed form serves the call
+        rc = s4g_db_create_cached(&rep, db->cards[0], seqs.data(), lens.data(), tags.data(), addrs.data(), (uint32_t)n);
+    if (rc == S4G_ERR_NOMEM) return packed_replica(db, 0);
     if (rc != S4G_OK)
         SW_FATAL("cannot place the database on MI355X device %d: %s (this build has no CPU scoring path)", db->cards[0], s4g_last_error());
     for (size_t i = 0; i < n; ++i) { db->chains[i]->dev_tag = tags[i]; db->chains[i]->dev_addr = addrs[i]; }
@@ -367,7 +393,7 @@ static void sort_survivors(std::vector<Survivor>& keep, Chain** database) {
         if (a.value != b.value) return a.value < b.value;
         if (a.score != b.score) return a.score > b.score;
         if (mode == 1) return a.idx > b.idx;
-        if (mode == 2) { const int c = strcmp(chainGetName(database[a.idx]), chainGetName(database[b.idx])); if (c) return c < 0; }
+        if (mode == 2) { const int c = swimpl::chain_name_cmp(database[a.idx], database[b.idx]); if (c) return c < 0; }   // (placeholders of a flat database: their records' names)
         return a.idx < b.idx;
     });
 }

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,7 +47,12 @@ struct Chain {
     char* rev_codes;
     // where this chain's residues live on a device, if it has been sent there (s4g_db_create_cached keeps these up to date;
     // zero = never sent).  A chain is a candidate of many queries: the wrapper's per-query chainDatabaseCreate finds it here.
+    // Both words belong to ONE device, the process's chain-cache device (align.cpp g_cache_device: the first card of the first
+    // database that could take the cached form); they are read and written under align.cpp's g_cache_mu only.
     uint64_t dev_tag, dev_addr;
+    // a placeholder chain of a flat database (chainDatabaseCreateFlat): the record's header text, not terminated.  NULL elsewhere.
+    const char* flat_name;
+    int flat_name_len;
 };
 
 struct Scorer {
@@ -79,6 +86,7 @@ struct ChainDatabase {
     std::vector<Chain> stubs;
     std::vector<Chain*> stub_ptrs;
     std::vector<Chain*> real;
+    std::mutex real_mu;      // swimpl::real_chain builds real[idx] on first use, from any card's thread
 };
 
 struct DbAlignment {
@@ -117,6 +125,9 @@ int pool_threads();                // workers of the pool (0: none, tasks run in
 
 // the chain of database entry idx that alignments point at: the entry itself, or -- flat databases -- the real chain, built on first use
 Chain* real_chain(ChainDatabase* db, int idx);
+
+// strcmp of the names two database entries are reported under (a placeholder's name is its record's header text)
+int chain_name_cmp(const Chain* a, const Chain* b);
 
 // device forms of a ChainDatabase, made on first use (align.cpp)
 bool cached_form_fits(const ChainDatabase* db);

@@ -9,9 +9,105 @@ all-gather of the per-query top-K records after the scan.
   the semantics of dbAlignmentsMerge across database chunks
   (/root/reference/sift4g/src/database_alignment.cpp:97-104) applied across GPUs.
 Ordering everywhere: score descending, then global target id ascending.  Unused slots: id -1, score 0.
+
+The gather itself lives BELOW Python: `Comm` wraps the C ABI's s4g_comm_* / s4g_gather_topk (sift4g_amd/csrc/s4g_gather.hip: RCCL
+all-gather + pack / unpack / K-way merge kernels on the rank's device), which is what a C++ host calls (tools/gather_demo.cpp).
+gather_query_shards / gather_db_shards take `comm=`; without one they go through torch.distributed (gloo in the CPU tests,
+where the K-way merge runs in the C ABI's host twin of the merge kernel, s4g_merge_topk_host).
 """
+import ctypes
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from ._lib import check, lib
+
+S4G_GATHER_QUERY_SHARD, S4G_GATHER_DB_SHARD = 0, 1
+
+
+class Comm:
+    """One rank of an RCCL communicator owned by libs4g_hip (s4g_comm_create).  `uid`: the 128 bytes of Comm.unique_id(), made by
+    one rank and handed to the others; from_process_group() does that over an existing torch.distributed group."""
+
+    def __init__(self, device, rank, world, uid):
+        self._h = ctypes.c_void_p()
+        self.device, self.rank, self.world = int(device), int(rank), int(world)
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        check(lib.s4g_comm_create(ctypes.byref(self._h), self.device, self.rank, self.world, buf), "s4g_comm_create")
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * 128)()
+        check(lib.s4g_comm_unique_id(buf), "s4g_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+        if on_dev:
+            t = t.to(torch.device("cuda", device))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(device, rank, world, bytes(t.cpu().numpy().tobytes()))
+
+    def info(self):
+        r, w, d, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib.s4g_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d), ctypes.byref(v)), "s4g_comm_info")
+        return dict(rank=r.value, world=w.value, device=d.value, rccl_version=v.value)
+
+    def _gather(self, mode, n_queries, ids, scores, counts, id_base, id_map, k_out, stream):
+        dev = torch.device("cuda", self.device)
+        k = ids.shape[1]
+        out_ids = torch.empty((n_queries, k_out), dtype=torch.int32, device=dev)
+        out_sc = torch.empty((n_queries, k_out), dtype=torch.int32, device=dev)
+        out_cnt = torch.empty((n_queries,), dtype=torch.int32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        ids, scores, counts = ids.contiguous(), scores.contiguous(), counts.contiguous()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else None)
+        check(lib.s4g_gather_topk(self._h, mode, n_queries, k, ptr(ids), ptr(scores), ptr(counts), int(id_base), ptr(id_map), k_out,
+                                  ptr(out_ids), ptr(out_sc), ptr(out_cnt), ctypes.c_void_p(stream.cuda_stream)), "s4g_gather_topk")
+        return out_ids, out_sc, out_cnt
+
+    def gather_query_shards(self, ids, scores, counts, n_queries_total, stream=None):
+        return self._gather(S4G_GATHER_QUERY_SHARD, n_queries_total, ids, scores, counts, 0, None, ids.shape[1], stream)
+
+    def gather_db_shards(self, local_ids, scores, counts, global_ids, k, stream=None):
+        if isinstance(global_ids, int):
+            return self._gather(S4G_GATHER_DB_SHARD, local_ids.shape[0], local_ids, scores, counts, global_ids, None, k, stream)
+        id_map = torch.as_tensor(global_ids).to(torch.device("cuda", self.device)).to(torch.int32).contiguous()
+        return self._gather(S4G_GATHER_DB_SHARD, local_ids.shape[0], local_ids, scores, counts, 0, id_map, k, stream)
+
+    def close(self):
+        if self._h:
+            lib.s4g_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_lists(ids, scores, k):
+    """K-way merge of ORDERED lists on the host -- s4g_merge_topk_host, the host twin of the device merge kernel of
+    s4g_gather_topk: ids / scores [lists, Q, M] CPU int32 tensors (global ids, -1 = unused and only at a row's end) -> best k per
+    query under (score desc, id asc): (ids [Q, k], scores [Q, k], counts [Q])."""
+    lists, q, m = ids.shape
+    i_np = np.ascontiguousarray(ids.numpy().astype(np.int32)).view(np.uint32)
+    s_np = np.ascontiguousarray(scores.numpy().astype(np.int32))
+    o_ids = np.empty((q, k), dtype=np.uint32)
+    o_sc = np.empty((q, k), dtype=np.int32)
+    o_cnt = np.empty((q,), dtype=np.uint32)
+    u32p, i32p = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)
+    check(lib.s4g_merge_topk_host(lists, q, m, i_np.ctypes.data_as(u32p), s_np.ctypes.data_as(i32p), k, o_ids.ctypes.data_as(u32p),
+                                  o_sc.ctypes.data_as(i32p), o_cnt.ctypes.data_as(u32p)), "s4g_merge_topk_host")
+    return (torch.from_numpy(o_ids.view(np.int32).copy()), torch.from_numpy(o_sc), torch.from_numpy(o_cnt.astype(np.int32)))
 
 
 def shard_bounds(n, world):
@@ -41,9 +137,12 @@ def _all_gather(out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def gather_query_shards(ids, scores, counts, n_queries_total, group=None):
+def gather_query_shards(ids, scores, counts, n_queries_total, group=None, comm=None):
     """query-shard mode: rank r holds the hit lists of queries [b_r, b_{r+1}).  Returns the full
-    (ids [Q,K], scores [Q,K], counts [Q]) on every rank.  One all-gather of (2K+1) int32 per query."""
+    (ids [Q,K], scores [Q,K], counts [Q]) on every rank.  One all-gather of (2K+1) int32 per query.
+    comm: a Comm -- the gather then runs below Python (s4g_gather_topk)."""
+    if comm is not None:
+        return comm.gather_query_shards(ids, scores, counts, n_queries_total)
     world = _world(group)
     if world == 1 and not dist.is_initialized():
         return ids, scores, counts
@@ -79,11 +178,14 @@ def merge_topk(ids, scores, k):
     return out_ids, out_scores, ok.sum(dim=1).to(torch.int32)
 
 
-def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None):
+def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None, comm=None, ordered=True):
     """DB-shard mode: every rank holds, for ALL queries, its local top-k (ids index the rank's own shard).
-    global_ids: int tensor mapping local target id -> global id for this rank, or a plain int = the global id of the
+    global_ids: int tensor mapping local target id -> global id for this rank (ascending), or a plain int = the global id of the
     rank's local target 0 (contiguous shards).  Returns the merged global top-k on every rank.  One all-gather of 2K int32
-    per query per rank, then a K-way merge."""
+    per query per rank, then a K-way merge.  comm: a Comm -- gather and merge then run below Python (s4g_gather_topk).
+    ordered=False: the rows are NOT in (score desc, id asc) order (the prefilter's lists are in id order): sort-based merge."""
+    if comm is not None and ordered:
+        return comm.gather_db_shards(local_ids, scores, counts, global_ids, k)
     world = _world(group)
     valid = local_ids >= 0
     if isinstance(global_ids, int):
@@ -98,6 +200,8 @@ def gather_db_shards(local_ids, scores, counts, global_ids, k, group=None):
     out = torch.empty((world * q, 2 * kk), dtype=torch.int32, device=gid.device)        # concatenated along dim 0
     _all_gather(out, packed, group)
     out = out.view(world, q, 2 * kk)
+    if not out.is_cuda and ordered:                  # host lists (the gloo tests): the C ABI's host twin of the device merge kernel
+        return merge_topk_lists(out[:, :, :kk], out[:, :, kk:], k)
     all_ids = out[:, :, :kk].permute(1, 0, 2).reshape(q, world * kk)
     all_sc = out[:, :, kk:].permute(1, 0, 2).reshape(q, world * kk)
     return merge_topk(all_ids, all_sc, k)
@@ -149,7 +253,7 @@ def merge_candidate_shards(ids, counts, scores, global_ids, max_candidates, grou
     local = torch.where(valid, ids.to(torch.int64), torch.full((q, m), -1, dtype=torch.int64, device=ids.device)).to(torch.int32)
     bits = torch.as_tensor(scores).to(ids.device).contiguous().view(torch.int32)        # positive floats order as their bit patterns
     bits = torch.where(valid, bits, torch.zeros_like(bits))
-    g_ids, _, g_counts = gather_db_shards(local, bits, None, global_ids, max_candidates, group)
+    g_ids, _, g_counts = gather_db_shards(local, bits, None, global_ids, max_candidates, group, ordered=False)
     key = torch.where(g_ids >= 0, g_ids.to(torch.int64), torch.full_like(g_ids, 1 << 40, dtype=torch.int64))
     out = torch.sort(key, dim=1).values
     return torch.where(out < (1 << 40), out, torch.full_like(out, -1)).to(torch.int32), g_counts

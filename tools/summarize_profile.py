@@ -11,7 +11,11 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sift4g_amd.srchash import kernel_source_sha          # the sources the profiled build was made from (run this on the same tree)
+
 prefix, name, label = sys.argv[1:4]
+src_sha = kernel_source_sha()
 sha = sys.argv[4] if len(sys.argv) > 4 else None
 cells = 12076509042144          # BASELINE configs[1]: sum Lq * sum Lt of the synthetic workload
 key = label.split("<")[0]        # kernel symbol to pick out of the traces ("sw_scan_pkd", "sw_scan_i32", ...)
@@ -32,7 +36,7 @@ fetch_kb, write_kb = out["fetch"]["FETCH_SIZE"]["sum"], out["write"]["WRITE_SIZE
 avg_ns = [float(r["AverageNs"]) for r in csv.DictReader(open(f"{dst}/kernel_stats.csv")) if key + "<" in r["Name"]][0]
 t = avg_ns / 1e9
 sq = out["sq"]
-s = dict(kernel=label, workload_cells=cells, git_sha=sha, **meta,
+s = dict(kernel=label, workload_cells=cells, git_sha=sha, kernel_source_sha=src_sha, **meta,
          command="tools/profile_bench.sh: rocprofv3 --pmc <COUNTER SET> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-selfcheck --no-tiers (one pass per counter set: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES "
                  "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES); rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
@@ -52,11 +56,11 @@ s["derived"] = dict(
 json.dump(s, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 if label.startswith("sw_scan_pkd"):        # the default kernel: what bench.py copies into roofline.traffic
     json.dump(dict(kernel=label, workload_cells=cells, hbm_bytes_per_launch=s["hbm_bytes_per_launch"], source=f"{dst}/pmc_summary.json",
-                   git_sha=sha), open("profiles/hbm_traffic.json", "w"), indent=1)
+                   git_sha=sha, kernel_source_sha=src_sha), open("profiles/hbm_traffic.json", "w"), indent=1)
 # executed vector lane-ops per cell of every profiled scan kernel: what bench.py's roofline.frac_executed is priced with
 ve_path = "profiles/valu_executed.json"
 ve = json.load(open(ve_path)) if os.path.exists(ve_path) else {}
 ve[label] = dict(lane_ops_per_cell=s["derived"]["valu_lane_ops_per_cell"], workload_cells=cells, SQ_INSTS_VALU=sq["SQ_INSTS_VALU"]["sum"],
-                 source=f"{dst}/pmc_summary.json", git_sha=sha)
+                 source=f"{dst}/pmc_summary.json", git_sha=sha, kernel_source_sha=src_sha)
 json.dump(ve, open(ve_path, "w"), indent=1)
 print(json.dumps(s["derived"], indent=1))
