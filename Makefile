@@ -15,11 +15,16 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Iinclude
 SWSRC   := $(CSRC)/swsharp/core.cpp $(CSRC)/swsharp/evalue.cpp $(CSRC)/swsharp/align.cpp $(CSRC)/swsharp/output.cpp
 REF     ?= /root/reference
 
-all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so build/shotgun_demo oracle
+all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so build/shotgun_demo build/gather_demo oracle
 
 build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	@mkdir -p build
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+# the one-process-per-GPU layout in plain C++ over the C ABI: N ranks (child processes), scan + s4g_gather_topk (RCCL), self-checking
+build/gather_demo: tools/gather_demo.cpp include/s4g_hip.h $(LIBDIR)/libs4g_hip.so
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ tools/gather_demo.cpp -L$(LIBDIR) -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 # libs4g_hip.so: one object per translation unit (make -j builds them side by side), every unit depends on every header
 HIPSRC  := $(CSRC)/s4g_core.hip $(CSRC)/s4g_scan.hip $(CSRC)/s4g_pairs.hip $(CSRC)/s4g_trace.hip $(CSRC)/s4g_diag.hip $(CSRC)/s4g_lists.hip $(CSRC)/s4g_prefilter.hip $(CSRC)/s4g_chains.hip $(CSRC)/s4g_stream.hip $(CSRC)/s4g_gather.hip

@@ -281,6 +281,12 @@ def main():
             ones = torch.ones(1, dtype=torch.int32)
         dist.all_reduce(ones)                       # how many ranks really joined the collective
         rccl_ranks = int(ones.item())
+    # the gather of the hit lists runs BELOW Python when the ranks are on RCCL: s4g_gather_topk of the C ABI (its own communicator, made
+    # from an id rank 0 creates and the process group hands round; pack / all-gather / unpack or K-way merge on the step's stream).
+    # S4G_BENCH_TORCH_GATHER=1 keeps the torch.distributed form of sift4g_amd/shard.py; gloo (emulated) runs always use it.
+    gather_comm = None
+    if use_dist and backend == "nccl" and os.environ.get("S4G_BENCH_TORCH_GATHER") != "1":
+        gather_comm = shard.Comm.from_process_group(dev_index)
 
     db_shard = args.mode == "db-shard"
     flags = dict(force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)
@@ -388,7 +394,7 @@ def main():
             ids, sc, cnt = s4g.scan_topk(db, allq, scorer, TOPK, 1, **fl)             # streaming scan + tile top-k + merge
             if i is not None:
                 ev[i][1].record(); ev[i][2].record()                                  # (the top-k is inside the streaming scan)
-            return (ids, sc, cnt), gathered(lambda: shard.gather_db_shards(ids, sc, cnt, rank * n_per, TOPK, gather_group))   # all-gather + K-way merge
+            return (ids, sc, cnt), gathered(lambda: shard.gather_db_shards(ids, sc, cnt, rank * n_per, TOPK, gather_group, comm=gather_comm))   # all-gather + K-way merge
         if q_count:
             s4g.scan(db, allq, scorer, scores, q_begin=q_begin, q_count=q_count, **fl)
         if i is not None:
@@ -401,7 +407,7 @@ def main():
             cnt = torch.zeros((0,), dtype=torch.int32, device=dev)
         if i is not None:
             ev[i][2].record()
-        return (ids, sc, cnt), gathered(lambda: shard.gather_query_shards(ids, sc, cnt, allq.n, gather_group))        # all-gather of the hit lists (N > 1)
+        return (ids, sc, cnt), gathered(lambda: shard.gather_query_shards(ids, sc, cnt, allq.n, gather_group, comm=gather_comm))        # all-gather of the hit lists (N > 1)
 
     def fence():
         if use_dist:
@@ -490,6 +496,8 @@ def main():
             "scaling": "weak" if db_shard else "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "rccl_ranks": rccl_ranks, "backend": ("RCCL (nccl)" if backend == "nccl" else backend), "emulated": bool(share and n_dev < world),
+            "gather": ("s4g_gather_topk (C ABI: RCCL all-gather + merge kernels below Python)" if gather_comm is not None else
+                       ("torch.distributed (sift4g_amd/shard.py)" if use_dist else None)),
             "config": {
                 "workload": (f"{wl_label}: {nq} synthetic queries per step len U[{qlen[0]},{qlen[1]}] x {n_per} device-generated targets per GPU "
                              f"({n_targets_total} in total) lognormal(5.68,0.55) clip[30,3000], BLOSUM62 gap 10/1, streaming scan + running top-{TOPK}"
@@ -655,6 +663,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and cfg is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, n_cpu)
         line = json.dumps(out)
+    if gather_comm is not None:
+        torch.cuda.synchronize()
+        gather_comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -546,12 +546,20 @@ static int finish_fused(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, f
     uint32_t* counts = A.take<uint32_t>(p->nq);
     uint32_t m = 2;
     while (m < p->max_c) m <<= 1;
+    const bool prof = getenv("S4G_PROFILE") != nullptr;
+    const auto t0 = Clock::now();
     hipLaunchKernelGGL(s4g::pf_finish_rows, dim3(p->nq), dim3(512), (size_t)m * 8, p->stream, p->d_list_key, p->d_list_cnt, p->max_c, ids, scores, counts);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_counts, counts, (uint64_t)p->nq * 4, hipMemcpyDeviceToHost, p->stream));
+    if (prof) HIP_TRY(hipStreamSynchronize(p->stream));
+    const auto t1 = Clock::now();
     S4G_TRY(rows_to_host(p, ids, h_ids, slots * 4));
+    const auto t2 = Clock::now();
     if (h_scores) S4G_TRY(rows_to_host(p, scores, h_scores, slots * 4));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (prof)
+        fprintf(stderr, "[s4g profile] prefilter finish: rows sorted by id on the device %.0f us (everything queued before it included), ids to the host %.0f us, scores %.0f us "
+                "(%llu bytes each, through pinned staging)\n", us(t0, t1), us(t1, t2), us(t2, Clock::now()), (unsigned long long)(slots * 4));
     return S4G_OK;
 }
 

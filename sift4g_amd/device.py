@@ -409,14 +409,17 @@ class Prefilter:
         check(lib.s4g_prefilter_add_device(self._h, codes.data_ptr(), offsets.data_ptr(), n, first), "s4g_prefilter_add_device")
         self.next_id = first + n
 
-    def finish(self):
+    def finish(self, scores=True, out=None):
+        """-> (ids [nq, max_candidates] uint32, counts [nq], scores float32 or None).  scores=False: ids only, as searchDatabase
+        returns them (database_search.cpp:166-178) and the drop-in asks for them; out: a (ids, scores) pair of arrays to fill (a caller
+        that keeps its buffers pays their first-touch page faults once)."""
         shape = (max(self.nq, 1), self.max_candidates)
-        ids = np.zeros(shape, dtype=np.uint32)
-        scores = np.zeros(shape, dtype=np.float32)
+        ids = out[0] if out is not None else np.zeros(shape, dtype=np.uint32)
+        sc = (out[1] if out is not None else np.zeros(shape, dtype=np.float32)) if scores else None
         counts = np.zeros(max(self.nq, 1), dtype=np.uint32)
-        check(lib.s4g_prefilter_finish(self._h, _ptr(ids, c_u32p), _ptr(counts, c_u32p), _ptr(scores, ctypes.POINTER(ctypes.c_float))),
-              "s4g_prefilter_finish")
-        return ids[: self.nq], counts[: self.nq], scores[: self.nq]
+        check(lib.s4g_prefilter_finish(self._h, _ptr(ids, c_u32p), _ptr(counts, c_u32p),
+                                       _ptr(sc, ctypes.POINTER(ctypes.c_float)) if scores else None), "s4g_prefilter_finish")
+        return ids[: self.nq], counts[: self.nq], (sc[: self.nq] if scores else None)
 
     def stats(self):
         out = np.zeros(7, dtype=np.uint64)

@@ -90,3 +90,55 @@ def test_two_ranks_one_gpu_equal_single_process():
         for got in (a, b):
             gi = np.where(got[0] < 0, 0xFFFFFFFF, got[0]).astype(np.int64)
             assert np.array_equal(gi, want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2].astype(np.int64), want[2])
+
+
+@pytest.mark.parametrize("lists,k_in,k_out", [(2, 40, 40), (8, 400, 400), (8, 25, 60), (5, 4096, 4096)])
+def test_device_merge_kernel_equals_its_host_twin(lists, k_in, k_out):
+    """s4g_merge_topk (the kernel s4g_gather_topk runs behind the RCCL all-gather) on `lists` ordered lists per query in device memory
+    against s4g_merge_topk_host on the same lists."""
+    import ctypes
+    from test_shard import _random_ordered_lists
+    from sift4g_amd import shard
+    from sift4g_amd._lib import check, lib
+    rng = np.random.default_rng(7 * lists + k_in)
+    nq = 9
+    ids, sc = _random_ordered_lists(rng, lists, nq, k_in, n_ids=3 * k_in * lists // 2 + 50)
+    want = shard.merge_topk_lists(torch.from_numpy(ids), torch.from_numpy(sc), k_out)
+    d_ids, d_sc = torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda()
+    o_ids = torch.empty((nq, k_out), dtype=torch.int32, device="cuda")
+    o_sc = torch.empty((nq, k_out), dtype=torch.int32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib.s4g_merge_topk(0, lists, nq, k_in, p(d_ids), p(d_sc), k_out, p(o_ids), p(o_sc), p(o_cnt),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s4g_merge_topk")
+    torch.cuda.synchronize()
+    assert torch.equal(o_ids.cpu(), want[0]) and torch.equal(o_sc.cpu(), want[1]) and torch.equal(o_cnt.cpu(), want[2])
+
+
+def test_one_rank_rccl_communicator_below_python():
+    """s4g_comm_create + s4g_gather_topk with ONE rank on the box's GPU (RCCL really runs: ncclCommInitRank, ncclAllGather on the
+    caller's stream): both modes must hand back what went in -- query-shard the same lists, DB-shard the lists with global ids
+    (base offset and id map) -- and agree with the torch.distributed-free path of shard.py."""
+    import sift4g_amd as s4g
+    from sift4g_amd import shard, synth
+    cfg = synth.make_config(2, n_queries=9, n_targets=1200, homologs_per_query=12)
+    k = 40
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    queries = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    ids, sc, cnt = s4g.scan_topk(db, queries, scorer, k)
+    comm = shard.Comm(0, 0, 1, shard.Comm.unique_id())
+    info = comm.info()
+    assert (info["rank"], info["world"], info["device"]) == (0, 1, 0) and info["rccl_version"] > 20000
+    a = comm.gather_query_shards(ids, sc, cnt, queries.n)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], ids) and torch.equal(a[1], sc) and torch.equal(a[2], cnt)
+    b = comm.gather_db_shards(ids, sc, cnt, 1000, k)
+    torch.cuda.synchronize()
+    assert torch.equal(b[0], torch.where(ids >= 0, ids + 1000, ids)) and torch.equal(b[1], sc) and torch.equal(b[2], cnt)
+    id_map = torch.arange(db.n, dtype=torch.int64) * 3 + 7
+    c = comm.gather_db_shards(ids, sc, cnt, id_map, 25)                      # a shorter output list: the best 25 of the 40
+    w = shard.gather_db_shards(ids, sc, cnt, id_map, 25)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(c, w))
+    comm.close()

@@ -163,3 +163,36 @@ def test_prefilter_lists_merge_world2(contiguous):
         for i in range(len(queries)):
             assert ids[i, :counts[i]].tolist() == w_ids[i, :w_counts[i]].tolist(), (r, i)
             assert (ids[i, counts[i]:] == -1).all()
+
+
+def _random_ordered_lists(rng, lists, nq, k_in, n_ids=5000, max_score=40):
+    """`lists` disjoint shards of a pool of ids with random scores, each shard's per-query list ordered (score desc, id asc), cut at
+    k_in, ragged (some lists short, some empty); many score ties"""
+    ids = np.full((lists, nq, k_in), -1, dtype=np.int32)
+    sc = np.zeros((lists, nq, k_in), dtype=np.int32)
+    owner = rng.integers(0, lists, n_ids)
+    for q in range(nq):
+        s = rng.integers(1, max_score, n_ids)
+        for r in range(lists):
+            mine = np.nonzero(owner == r)[0]
+            if rng.random() < 0.15:
+                mine = mine[: rng.integers(0, 4)]
+            order = sorted(mine.tolist(), key=lambda j: (-s[j], j))[:k_in]
+            ids[r, q, :len(order)] = order
+            sc[r, q, :len(order)] = s[order]
+    return ids, sc
+
+
+@pytest.mark.parametrize("lists,k_in,k_out", [(1, 7, 7), (2, 40, 40), (8, 25, 60), (8, 400, 400), (3, 5, 2)])
+def test_host_twin_of_the_merge_kernel(lists, k_in, k_out):
+    """s4g_merge_topk_host (the host twin of the device merge kernel behind s4g_gather_topk) against the sort-based merge on random
+    ordered lists with ties, short and empty rows: ids, scores and counts equal."""
+    from sift4g_amd import shard
+    rng = np.random.default_rng(lists * 1000 + k_in)
+    ids, sc = _random_ordered_lists(rng, lists, 11, k_in)
+    got = shard.merge_topk_lists(torch.from_numpy(ids), torch.from_numpy(sc), k_out)
+    flat_i = torch.from_numpy(ids).permute(1, 0, 2).reshape(11, lists * k_in)
+    flat_s = torch.from_numpy(sc).permute(1, 0, 2).reshape(11, lists * k_in)
+    want = shard.merge_topk(flat_i, flat_s, k_out)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
