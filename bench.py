@@ -126,19 +126,23 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
     residues = int(t_off[-1])
     d_codes = torch.from_numpy(cfg["t_codes"][:max(residues, 1)]).cuda(dev_index)
     d_off = torch.from_numpy(np.asarray(t_off).astype(np.int64)).cuda(dev_index)
-    best = dict(index=1e9, add=1e9, finish=1e9, call=1e9)
+    best = dict(index=1e9, add=1e9, finish=1e9, call=1e9, finish_ids=1e9)
     stats = None
+    # the caller's result arrays are allocated once, as the drop-in's are (a std::vector sized before the call): a fresh, never
+    # touched 40 MB pays 3 ms of page faults inside the call (tools/prefilter_finish_probe.py: 4.4 ms fresh, 1.3 ms reused)
+    out_bufs = (np.zeros((max(nq, 1), 5000), np.uint32), np.zeros((max(nq, 1), 5000), np.float32))
     for _ in range(reps + 1):                          # the first round grows the buffers
         torch.cuda.synchronize()
         t0 = time.perf_counter(); p = s4gd.Prefilter(queries, 5, 5000, device=dev_index); t1 = time.perf_counter()
         p.add_device(d_codes, d_off, first_id=0)
         torch.cuda.synchronize()                       # (the merge of a chunk's candidates into the lists runs on behind the call: count it)
         t2 = time.perf_counter()
-        p.finish(); t3 = time.perf_counter()
+        p.finish(out=out_bufs); t3 = time.perf_counter()
+        p.finish(scores=False, out=out_bufs); t4 = time.perf_counter()      # ids only: what searchDatabase returns and the drop-in asks for
         stats = p.stats()
         p.close()
         best = dict(index=min(best["index"], t1 - t0), add=min(best["add"], t2 - t1), finish=min(best["finish"], t3 - t2),
-                    call=min(best["call"], t3 - t0))
+                    call=min(best["call"], t3 - t0), finish_ids=min(best["finish_ids"], t4 - t3))
     m = min(check_targets, nt)
     sample = [cfg["t_codes"][int(t_off[i]):int(t_off[i + 1])] for i in range(m)]
     t0 = time.perf_counter()
@@ -176,6 +180,7 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
             "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues, "roofline": roof,
             "path": "fused" if stats.get("fused") else "general", "general_path_targets": stats.get("general_path_targets"),
             "index_ms": round(best["index"] * 1e3, 3), "add_ms": round(best["add"] * 1e3, 3), "finish_ms": round(best["finish"] * 1e3, 3),
+            "finish_ids_only_ms": round(best["finish_ids"] * 1e3, 3),
             "call_ms": round(best["call"] * 1e3, 3), "residues_per_s": round(residues / best["call"], 1),
             "residues_per_s_basis": "database residues / (index + add + finish) of the fastest whole call",
             "add_residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],

@@ -273,7 +273,8 @@ int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
  * speculative launches marked and the exact int32 pass recomputed, out[6] = (query, target) pairs given to the
  * one-wave-per-pair kernels, out[7] = pairs scored by the packed list kernel (s4g_score_pairs_host / s4g_score_lists_host).  cap >= 8;
  * with cap >= 10 also out[8] / out[9] = pairs of the last pair submission / the last traceback call that ran on the cooperative
- * kernels (four waves per pair: the pairs whose own latency would have dominated the launch). */
+ * kernels (four waves per pair: the pairs whose own latency would have dominated the launch); with cap >= 11 also out[10] = pairs of
+ * the last pair submission scored by the packed one-wave-per-pair kernels (sw_pair_scan_pk: two rows per register). */
 int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
 
 /* Shader clock and duration of the scan launches of the last s4g_scan* / s4g_scan_topk* call on `device`, sampled INSIDE those

@@ -127,6 +127,8 @@ struct DeviceCtx {
     uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_band = 0, grid_pair_trace_band = 0, grid_pair_recheck = 0;
     uint32_t grid_pair_coop[3] = {0, 0, 0}, grid_pair_trace_coop[3] = {0, 0, 0};     // sw_pair_scan_coop / sw_pair_trace_coop<2, 3, 4>
+    uint32_t grid_pair_pk[3] = {0, 0, 0};   // sw_pair_scan_pk<1, 2, 3> (sw_pair_pk.hip.h: two rows per register)
+    uint64_t stat_pair_pk = 0;              // pairs of the last pair submission that ran there
     char* h_trace_pin = nullptr;        // pinned staging of traceback_pairs: items up, results back
     uint64_t trace_pin_bytes = 0;
     hipStream_t coop_stream = nullptr;  // they run next to the one-wave-per-pair launches of the same submission, not behind them

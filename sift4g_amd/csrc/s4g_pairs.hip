@@ -3,6 +3,7 @@
 // (/root/reference/sift4g/src/database_alignment.cpp:70-92).
 #include "s4g_internal.hpp"
 #include "sw_pair_coop.hip.h"
+#include "sw_pair_pk.hip.h"
 
 // ---------------------------------------------------------------------------
 // Pair lists (the latency path, sw_pair.hip.h): explicit (query, target) pairs, one wave per pair.
@@ -48,6 +49,8 @@ int ensure_band_ws(DeviceCtx* cx, uint32_t max_lt, uint32_t n_items, uint32_t fu
     return S4G_OK;
 }
 
+constexpr int kPairPkCounter = 32;              // DeviceCtx::d_counter words: work queues of the packed pair classes (3)
+constexpr int kPairPkClasses = 3;               // sw_pair_scan_pk<1, 2, 3>: the scan classes 0 .. 2 (queries of up to 128 / 256 / 384 residues)
 constexpr int kCoopScanCounter = 50;            // DeviceCtx::d_counter words: work queues of the cooperative scan classes (3) ...
 constexpr int kPairTraceCounter = 53;           // ... and of the traceback launches of a batch, one per class (kAllClasses = 10)
 constexpr uint64_t kCoopWsBudget = 1ull << 30;
@@ -153,6 +156,46 @@ int launch_pairs(DeviceCtx* cx, PairArgs a, uint32_t* grid_cache, hipStream_t st
     return S4G_OK;
 }
 
+template <int M>
+int launch_pairs_pk(DeviceCtx* cx, PairArgs a, uint32_t bias, uint32_t* grid_cache, hipStream_t stream) {
+    if (*grid_cache == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_pair_scan_pk<M>, 64, 0));
+        *grid_cache = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(*grid_cache, a.n_pairs));
+    PairPkArgs b;
+    b.p = a; b.bias = bias;
+    hipLaunchKernelGGL(sw_pair_scan_pk<M>, dim3(grid), dim3(64), 0, stream, b);
+    HIP_TRY(hipGetLastError());
+    return S4G_OK;
+}
+
+// Which pairs of a submission may run on the packed kernels (sw_pair_pk.hip.h): per scan class c < 3 the longest target whose
+// drifting frame still fits the int16 window for EVERY query of the submission --
+//     bound + B + (M + columns + 2 * 64 + 8) * ext <= 0x7BFF,   M = c + 1 registers per lane --
+// 0 = none (a scorer with penalties beyond 16 bits, S4G_PAIR_PK=0, or no room at all).  Items of a class are ordered by target length
+// (buckets of 32 residues, longest first), so the pairs beyond the cap are a prefix of the class: they stay on sw_pair_scan.
+struct PairPkRule {
+    uint32_t cap[kPairPkClasses] = {0, 0, 0};
+    uint32_t bias = 0;
+    PairPkRule() {}
+    PairPkRule(const s4g_scorer* sc, uint64_t max_bound) {
+        static const bool on = !(getenv("S4G_PAIR_PK") && atoi(getenv("S4G_PAIR_PK")) == 0);
+        if (!on || sc->open >= 32768 || sc->ext >= 32768) return;
+        bias = (uint32_t)std::max(std::max(-kPadScore, -sc->min_score), std::max(sc->open, 2 * sc->ext));
+        const uint64_t window = 0x7BFF, step = (uint64_t)std::max(0, sc->max_score) + 2 * (uint64_t)sc->ext;
+        for (int c = 0; c < kPairPkClasses; ++c) {
+            const uint64_t fixed = max_bound + bias + step + (uint64_t)(c + 1 + 2 * 64 + 8) * (uint64_t)sc->ext;
+            if (fixed >= window) continue;
+            const uint64_t cols = sc->ext ? (window - fixed) / (uint64_t)sc->ext : 0xFFFFFFFFull;
+            cap[c] = (uint32_t)std::min<uint64_t>(cols, 0x7FFFFFFFull);
+        }
+    }
+    // conservative at the granularity the items are ordered by: a target in the cap's own bucket of 32 residues counts as too long
+    bool takes(int c, uint32_t lt) const { return c < kPairPkClasses && (lt >> 5) < (cap[c] >> 5); }
+};
+
 int warm_pair_kernels(DeviceCtx* cx) {
     int rc = device_props(cx);
     if (rc) return rc;
@@ -166,6 +209,7 @@ int warm_pair_kernels(DeviceCtx* cx) {
     // the classes a 300-400 residue query uses for scores and traceback (the others load with the same code object)
     rc = occ((const void*)sw_pair_scan<6>, &cx->grid_pair[2]);
     if (!rc) rc = occ((const void*)sw_pair_scan<8>, &cx->grid_pair[3]);
+    if (!rc) rc = occ((const void*)sw_pair_scan_pk<3>, &cx->grid_pair_pk[2]);
     if (!rc) rc = occ((const void*)sw_pair_trace<6>, &cx->grid_pair_trace[2]);
     if (!rc) rc = occ((const void*)sw_pair_trace<8>, &cx->grid_pair_trace[3]);
     if (!rc && cx->grid_pair_coop[0] == 0) {
@@ -220,8 +264,11 @@ int pair_stage(DeviceCtx* cx, uint64_t n, PairItem** out) {
 
 // uploads the staged items (class-major: cls_begin[c] .. cls_begin[c+1]) and launches one kernel per class
 // (cls_begin has kAllClasses + 1 entries; max_lt_coop = longest target among the cooperative classes)
+// pk_first (optional): per packed class, the first item of the class that the packed kernel takes (items before it are too long for
+// its window and run on sw_pair_scan); pk_bias its bias.  NULL: no packed launches.
 int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n, const uint32_t* cls_begin,
-                int32_t* d_scores, hipStream_t stream, uint32_t max_lt_band, uint32_t max_lt_coop = 0) {
+                int32_t* d_scores, hipStream_t stream, uint32_t max_lt_band, uint32_t max_lt_coop = 0, const uint32_t* pk_first = nullptr,
+                uint32_t pk_bias = 0) {
     DeviceCtx* cx = device_ctx(db->device);
     int rc = device_props(cx);
     if (rc) return rc;
@@ -236,6 +283,8 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
     HIP_TRY(hipMemcpyAsync(cx->d_items, cx->h_items, (size_t)n * sizeof(PairItem), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->items_done, stream));
     HIP_TRY(hipMemsetAsync(cx->d_counter + 24, 0, kScanClasses * 4, stream));
+    if (pk_first) HIP_TRY(hipMemsetAsync(cx->d_counter + kPairPkCounter, 0, kPairPkClasses * 4, stream));
+    cx->stat_pair_pk = 0;
     if (cls_begin[kAllClasses] != cls_begin[kScanClasses]) HIP_TRY(hipMemsetAsync(cx->d_counter + kCoopScanCounter, 0, kCoopClasses * 4, stream));
     // the cooperative classes first, on their own stream: they are the submission's longest pairs
     CoopFork coop_fork(cx, stream);
@@ -258,6 +307,21 @@ int pair_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer
             }
             if (rc) return rc;
             continue;
+        }
+        if (pk_first && c < kPairPkClasses && pk_first[c] < e) {
+            // the packed kernel takes the class from pk_first[c] on (two rows per register: half the steps' instructions); what is too
+            // long for its int16 window -- the head of the class -- stays on the int32 kernel below
+            PairArgs pa = a;
+            pa.items = cx->d_items + pk_first[c]; pa.n_pairs = e - pk_first[c]; pa.counter = cx->d_counter + kPairPkCounter + c;
+            switch (c) {
+                case 0: rc = launch_pairs_pk<1>(cx, pa, pk_bias, &cx->grid_pair_pk[0], stream); break;
+                case 1: rc = launch_pairs_pk<2>(cx, pa, pk_bias, &cx->grid_pair_pk[1], stream); break;
+                default: rc = launch_pairs_pk<3>(cx, pa, pk_bias, &cx->grid_pair_pk[2], stream); break;
+            }
+            if (rc) return rc;
+            cx->stat_pair_pk += pa.n_pairs;
+            a.n_pairs = pk_first[c] - b;
+            if (a.n_pairs == 0) continue;
         }
         if (c == kPairClasses) {        // banded kernel: per-wave boundary workspace sized by the launch's longest target
             if (cx->grid_pair_band == 0) {
@@ -338,6 +402,14 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
     double cells_total = 0;
     for (uint32_t i = 0; i < n; ++i) cells_total += (double)q->len[pair_q[sel[i]]] * db->len[pair_t[sel[i]]];
     const CoopRule coop(cells_total, false);
+    ensure_bounds(q, scorer);
+    uint64_t max_bound = 0;
+    {   // the largest score bound among the submission's queries (a per-query call has one)
+        uint32_t last_q = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < n; ++i) { const uint32_t qi = pair_q[sel[i]]; if (qi != last_q) { max_bound = std::max(max_bound, q->score_bound[qi]); last_q = qi; } }
+    }
+    const PairPkRule pk(scorer, max_bound);
+    uint32_t pk_unfit[kPairPkClasses] = {0, 0, 0};
     auto class_of = [&](uint32_t pi) {
         const int cc = coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]);
         return cc >= 0 ? cc : pair_class(q->len[pair_q[pi]]);
@@ -351,10 +423,21 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
         const int c = class_of(sel[i]);
         if (c == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[sel[i]]]);
         if (c >= kScanClasses) max_lt_coop = std::max(max_lt_coop, db->len[pair_t[sel[i]]]);
+        if (c < kPairPkClasses && !pk.takes(c, db->len[pair_t[sel[i]]])) ++pk_unfit[c];
     }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
     uint32_t cls_begin[kAllClasses + 1];
     for (int c = 0; c <= kAllClasses; ++c) cls_begin[c] = count[(size_t)c * kBuckets];
+    // The packed kernels win where a call waits for its longest pair: a wave walks a pair in ~150 clocks per step instead of ~260.  Their
+    // two tables per wave (48 KB of LDS at three registers per lane) leave room for 3 waves per CU against the int32 kernel's 8, so
+    // once there is work for every resident wave several times over the int32 kernel is ahead again (16 queries x 3645 candidates:
+    // 4.0 ms against 2.9; one query x 3645: 0.30 ms against 0.41; profiles/r04_pair_pk/).  Crossover by the two rates: ~8000 pairs.
+    static const uint32_t pk_max_pairs = getenv("S4G_PAIR_PK_MAX") ? (uint32_t)strtoul(getenv("S4G_PAIR_PK_MAX"), nullptr, 10) : 8192u;
+    uint32_t pk_first[kPairPkClasses];
+    for (int c = 0; c < kPairPkClasses; ++c) {
+        pk_first[c] = cls_begin[c] + pk_unfit[c];                   // (the too-long ones are the head of the class)
+        if (cls_begin[c + 1] - cls_begin[c] > pk_max_pairs) pk_first[c] = cls_begin[c + 1];
+    }
     where->resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t pi = sel[i];
@@ -364,7 +447,7 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
     }
     cx->stat_coop_scan = cls_begin[kAllClasses] - cls_begin[kScanClasses];
     *d_sc_out = reinterpret_cast<int32_t*>(cx->d_items + cx->items_cap);
-    return pair_submit(db, q, scorer, n, cls_begin, *d_sc_out, stream, max_lt_band, max_lt_coop);
+    return pair_submit(db, q, scorer, n, cls_begin, *d_sc_out, stream, max_lt_band, max_lt_coop, pk.bias ? pk_first : nullptr, pk.bias);
 }
 
 // Explicit list -> host scores (synchronous).

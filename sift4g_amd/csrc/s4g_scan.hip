@@ -432,6 +432,7 @@ S4G_API int s4g_scan_stats(int device, uint64_t* out, uint32_t cap) {
     for (int k = 0; k < 4; ++k) out[k] = cx->stat_tier[k];
     out[4] = cx->stat_spec_queries; out[5] = rechecked; out[6] = cx->stat_pair_items; out[7] = cx->stat_list_pairs;
     if (cap >= 10) { out[8] = cx->stat_coop_scan; out[9] = cx->stat_coop_trace; }
+    if (cap >= 11) out[10] = cx->stat_pair_pk;
     return S4G_OK;
 }
 

@@ -137,7 +137,10 @@ SW_API ChainDatabase* chainDatabaseCreate(Chain** database, int databaseStart, i
     if (cards && cardsLen > 0) db->cards.assign(cards, cards + cardsLen); else db->cards.assign(1, 0);
     db->replicas.assign(db->cards.size(), (s4g_db*)NULL);
     db->residues = 0;
+    // (a per-query candidate database is a few thousand chains scattered over the heap: every first touch of a Chain is a cache miss,
+    // and they are independent -- ask for the objects a few iterations ahead)
     for (int i = 0; i < databaseLen; ++i) {
+        if (i + 16 < databaseLen) __builtin_prefetch(db->chains[i + 16]);
         SW_ASSERT(db->chains[i] != NULL, "NULL chain at index %d", i);
         db->residues += chainGetLength(db->chains[i]);
     }
@@ -263,6 +266,8 @@ s4g_db* cached_replica(ChainDatabase* db) {
     std::vector<uint32_t> lens(n);
     std::vector<uint64_t> tags(n), addrs(n);
     for (size_t i = 0; i < n; ++i) {
+        if (i + 16 < n) __builtin_prefetch(db->chains[i + 16]);
+        if (i + 8 < n) __builtin_prefetch(db->chains[i + 8]->data);        // chainGetCodes reads through the chain's data block
         Chain* c = db->chains[i];
         seqs[i] = reinterpret_cast<const uint8_t*>(chainGetCodes(c));
         lens[i] = (uint32_t)chainGetLength(c);

@@ -224,11 +224,11 @@ def scan_plan(db, queries, scorer):
 
 def scan_stats(device=0):
     """what the last scan call on `device` did (s4g_scan_stats): queries per tier, speculative routing, rechecked entries, pairs"""
-    out = np.zeros(10, dtype=np.uint64)
-    check(lib.s4g_scan_stats(device, _ptr(out, c_u64p), 10), "s4g_scan_stats")
+    out = np.zeros(11, dtype=np.uint64)
+    check(lib.s4g_scan_stats(device, _ptr(out, c_u64p), 11), "s4g_scan_stats")
     return dict(tier_drift=int(out[0]), tier_m3=int(out[1]), tier_i16=int(out[2]), tier_i32=int(out[3]),
                 speculative=int(out[4]), rechecked=int(out[5]), pair_items=int(out[6]), list_pairs=int(out[7]),
-                coop_scan=int(out[8]), coop_trace=int(out[9]))
+                coop_scan=int(out[8]), coop_trace=int(out[9]), pair_pk=int(out[10]))
 
 
 def chain_cache_info(device=0):

@@ -754,6 +754,37 @@ def test_pairs_empty_sequences_and_other_scorers(s4g, oracle_mod, blosum62, scor
         s4g.score_pairs(s4g.Database(ts), s4g.QuerySet(qs), scorer, [3], [0])
 
 
+def test_packed_pair_kernel_takes_what_its_window_admits(s4g, oracle_mod, blosum62):
+    """sw_pair_scan_pk (two rows per register, the upper halves one column behind; sw_pair_pk.hip.h) serves the pairs of queries of up to
+    384 residues whose drifting frame fits the int16 window; the rest of the same call -- longer queries, targets beyond the window's
+    reach -- stays on the int32 kernel.  Query lengths on both sides of its three classes (128 / 256 / 384 rows), targets of one
+    residue to several LDS windows, exact copies (the highest scores a pair can have), a scorer whose extension penalty of 4 cuts
+    the reach to a few thousand columns (so that one class is split between the two kernels), and one whose penalties admit nothing:
+    every score against the oracle, and the routing statistics say who ran where."""
+    from sift4g_amd import device as s4gd
+    rng = np.random.default_rng(91)
+    qlens = [1, 2, 7, 64, 127, 128, 129, 200, 255, 256, 257, 300, 350, 383, 384, 385, 400, 512]
+    tlens = [1, 2, 3, 5, 63, 64, 65, 127, 128, 129, 130, 340, 1000, 2047, 2048, 2049, 2175, 2176, 2177, 4500, 7000, 9000, 20000, 29000, 33000]
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in qlens]
+    ts = [rand_seqs(rng, 1, l, l)[0] for l in tlens]
+    ts += [q.copy() for q in qs]                                            # self-scores: the top of the window
+    ts.append(np.concatenate([rand_seqs(rng, 1, 2040, 2040)[0], qs[12], rand_seqs(rng, 1, 300, 300)[0]]))      # a hit across a window boundary
+    pq, pt = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    pq, pt = pq.ravel(), pt.ravel()
+    n_pk_queries = sum(1 for l in qlens if l <= 384)
+    for (go, ge), expect in (((10, 1), "most"), ((12, 4), "split"), ((40000, 1), "none")):
+        sc = s4g.Scorer("BLOSUM_62", go, ge)
+        _pairs_check(s4g, oracle_mod, blosum62, qs, ts, pq, pt, sc, go, ge, routes=("wave",))
+        st = s4gd.scan_stats(0)
+        assert st["pair_items"] == len(pq)
+        if expect == "most":          # everything of the short queries but the 33 000-residue target (frame beyond 0x7BFF)
+            assert n_pk_queries * (len(ts) - 2) <= st["pair_pk"] <= n_pk_queries * (len(ts) - 1), st
+        elif expect == "split":       # reach of a few thousand columns: the long targets of every class stay behind
+            assert n_pk_queries * 20 <= st["pair_pk"] <= n_pk_queries * (len(ts) - 3), st
+        else:
+            assert st["pair_pk"] == 0, st
+
+
 def test_pair_traceback_row_block_classes_windows_and_mixed_routes(s4g, oracle_mod, blosum62, scorer):
     """sw_pair_trace over every rows-per-lane class, targets beyond one LDS window, gap-rich alignments; queries beyond
     1024 residues in the same call run band by band (sw_pair_trace_band)."""
