@@ -283,6 +283,22 @@ def test_device_prefilter_build_gives_the_reference_flows_outputs(tmp_path):
     assert dropin_synth.run(DEVSEARCH, str(parts), env=dict(os.environ, S4G_PREFILTER_CHUNK_BYTES="30000", S4G_CHUNK_BYTES="30000")) == want
 
 
+@pytest.mark.skipif(not (os.path.exists(DEVSEARCH) and os.path.exists(BATCHED)), reason="drop-in builds missing (need /root/reference at build time)")
+def test_selection_ties_by_name_is_the_same_on_flat_and_chain_databases(tmp_path):
+    """S4G_SELECTION_TIES=name orders equal (value, score) survivors by chain name: the one-pass device-prefilter build keeps
+    the database flat (placeholder chains whose names are the records' header text, chainDatabaseCreateFlat) and must order exactly as
+    the builds that hold real chains do -- same bytes in alignments.txt, on the synthetic set, whole and in parts."""
+    import dropin_synth
+    env = dict(os.environ, S4G_SELECTION_TIES="name")
+    outs = []
+    for k, (exe, extra) in enumerate(((BATCHED, {}), (DEVSEARCH, {}), (DEVSEARCH, {"S4G_PREFILTER_CHUNK_BYTES": "30000", "S4G_CHUNK_BYTES": "30000"}), (DROPIN, {}))):
+        d = tmp_path / f"run{k}"
+        d.mkdir()
+        outs.append(dropin_synth.run(exe, str(d), env=dict(env, **extra)))
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert len(outs[0]) > 1000
+
+
 FULLSCAN = os.path.join(ROOT, "build", "dropin", "sift4g_fullscan")
 
 
