@@ -291,7 +291,19 @@ def main():
     # S4G_BENCH_TORCH_GATHER=1 keeps the torch.distributed form of sift4g_amd/shard.py; gloo (emulated) runs always use it.
     gather_comm = None
     if use_dist and backend == "nccl" and os.environ.get("S4G_BENCH_TORCH_GATHER") != "1":
-        gather_comm = shard.Comm.from_process_group(dev_index)
+        # every rank must end up on the same form: the ranks agree (an all-reduce of "I have a communicator") before anybody uses
+        # it, and all of them fall back to the torch.distributed gather if any of them could not make one
+        try:
+            gather_comm = shard.Comm.from_process_group(dev_index)
+            ok = 1
+        except Exception as exc:          # librccl not loadable, ncclCommInitRank refused ...
+            log(f"rank {rank}: no C-ABI communicator ({exc}); falling back to the torch.distributed gather")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and gather_comm is not None:
+            gather_comm.close()
+            gather_comm = None
 
     db_shard = args.mode == "db-shard"
     flags = dict(force_i32=args.force_i32, no_f16=args.no_f16, no_drift=args.no_drift, no_spec=args.no_spec)

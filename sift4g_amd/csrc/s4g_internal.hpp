@@ -278,7 +278,8 @@ int ensure_seq_tables(const s4g_db* db);
 // stages and submits the pairs sel[] to the one-wave-per-pair kernels on `stream` (asynchronous; caller holds cx->mu): the score
 // of pair sel[i] will be at (*d_sc_out)[(*where)[i]]
 int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
-                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream);
+                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream,
+                  bool pk_allowed = true);       // pk_allowed: the packed pair kernels may take what their window admits (not beside the list kernel)
 // s4g_lists.hip
 int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used);

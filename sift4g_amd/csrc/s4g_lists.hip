@@ -325,7 +325,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
         if (wave_sel.empty()) return S4G_OK;
         HIP_TRY(hipStreamWaitEvent(cx->side_stream, cx->side_fork, 0));
         scope.forked = true;
-        const int rcw = pairs_enqueue(db, q, scorer, wave_sel, pair_q, pair_t, &wave_where, &d_wave_sc, cx->side_stream);
+        const int rcw = pairs_enqueue(db, q, scorer, wave_sel, pair_q, pair_t, &wave_where, &d_wave_sc, cx->side_stream, /*pk_allowed=*/false);
         if (rcw) return rcw;
         HIP_TRY(hipEventRecord(cx->side_join, cx->side_stream));
         return S4G_OK;

@@ -389,7 +389,8 @@ int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sco
 // Order inside a class: longest target first at 32-residue granularity (counting sort; a launch cannot end before its
 // longest pair does, so that one must not start last).
 int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
-                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream) {
+                  const uint32_t* pair_q, const uint32_t* pair_t, std::vector<uint32_t>* where, int32_t** d_sc_out, hipStream_t stream,
+                  bool pk_allowed) {
     DeviceCtx* cx = device_ctx(db->device);
     const uint32_t n = (uint32_t)sel.size();
     PairItem* items = nullptr;
@@ -409,7 +410,8 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
         for (uint32_t i = 0; i < n; ++i) { const uint32_t qi = pair_q[sel[i]]; if (qi != last_q) { max_bound = std::max(max_bound, q->score_bound[qi]); last_q = qi; } }
     }
     const PairPkRule pk(scorer, max_bound);
-    uint32_t pk_unfit[kPairPkClasses] = {0, 0, 0};
+    uint32_t pk_unfit[kPairPkClasses] = {0, 0, 0}, pk_max_lt[kPairPkClasses] = {0, 0, 0};
+    double pk_cells[kPairPkClasses] = {0, 0, 0};
     auto class_of = [&](uint32_t pi) {
         const int cc = coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]);
         return cc >= 0 ? cc : pair_class(q->len[pair_q[pi]]);
@@ -423,7 +425,11 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
         const int c = class_of(sel[i]);
         if (c == kPairClasses) max_lt_band = std::max(max_lt_band, db->len[pair_t[sel[i]]]);
         if (c >= kScanClasses) max_lt_coop = std::max(max_lt_coop, db->len[pair_t[sel[i]]]);
-        if (c < kPairPkClasses && !pk.takes(c, db->len[pair_t[sel[i]]])) ++pk_unfit[c];
+        if (c < kPairPkClasses) {
+            const uint32_t lt = db->len[pair_t[sel[i]]];
+            if (!pk.takes(c, lt)) ++pk_unfit[c];
+            else { pk_cells[c] += (double)q->len[pair_q[sel[i]]] * lt; pk_max_lt[c] = std::max(pk_max_lt[c], lt); }
+        }
     }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
     uint32_t cls_begin[kAllClasses + 1];
@@ -431,12 +437,18 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
     // The packed kernels win where a call waits for its longest pair: a wave walks a pair in ~150 clocks per step instead of ~260.  Their
     // two tables per wave (48 KB of LDS at three registers per lane) leave room for 3 waves per CU against the int32 kernel's 8, so
     // once there is work for every resident wave several times over the int32 kernel is ahead again (16 queries x 3645 candidates:
-    // 4.0 ms against 2.9; one query x 3645: 0.30 ms against 0.41; profiles/r04_pair_pk/).  Crossover by the two rates: ~8000 pairs.
-    static const uint32_t pk_max_pairs = getenv("S4G_PAIR_PK_MAX") ? (uint32_t)strtoul(getenv("S4G_PAIR_PK_MAX"), nullptr, 10) : 8192u;
+    // 4.0 ms against 2.9; one query x 3645: 0.30 ms against 0.41; the 9 000 long-tail pairs of a list call: 1.4 ms against 1.1;
+    // profiles/r04_pair_pk/).  So a class goes there while its cells, at the packed kernels' chip rate (768 waves x 6 rows x 64 lanes per
+    // ~150 clocks), take no longer than ONE int32 wave needs for the class's longest pair -- the time the int32 launch cannot beat:
+    //     cells / 1966 per clock  <=  (longest target + 64) x 260 clocks.          S4G_PAIR_PK_MAX scales the right-hand side (percent).
+    // Pairs that run beside the list kernel (pk_allowed = false) stay on the int32 kernel: the list kernel's blocks hold 108 KB of a
+    // CU's LDS, and one packed wave fits beside them where two int32 waves do.
+    static const double pk_scale = getenv("S4G_PAIR_PK_MAX") ? atof(getenv("S4G_PAIR_PK_MAX")) / 100.0 : 1.0;
     uint32_t pk_first[kPairPkClasses];
     for (int c = 0; c < kPairPkClasses; ++c) {
         pk_first[c] = cls_begin[c] + pk_unfit[c];                   // (the too-long ones are the head of the class)
-        if (cls_begin[c + 1] - cls_begin[c] > pk_max_pairs) pk_first[c] = cls_begin[c + 1];
+        const double budget = ((double)pk_max_lt[c] + 64.0) * 260.0 * 1966.0 * pk_scale;
+        if (!pk_allowed || pk_cells[c] > budget) pk_first[c] = cls_begin[c + 1];
     }
     where->resize(n);
     for (uint32_t i = 0; i < n; ++i) {

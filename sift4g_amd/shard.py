@@ -46,13 +46,21 @@ class Comm:
     def from_process_group(cls, device, group=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         on_dev = dist.get_backend(group) == "nccl"
-        t = torch.zeros(128, dtype=torch.uint8)
+        t = torch.zeros(129, dtype=torch.uint8)                # the id + "rank 0 has one" (rank 0 broadcasts whatever happened to it)
+        err = None
         if rank == 0:
-            t = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+            try:
+                t[:128] = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8)
+                t[128] = 1
+            except Exception as exc:
+                err = exc
         if on_dev:
             t = t.to(torch.device("cuda", device))
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(device, rank, world, bytes(t.cpu().numpy().tobytes()))
+        t = t.cpu()
+        if int(t[128]) != 1:
+            raise RuntimeError(f"rank 0 could not make a communicator id: {err}" if rank == 0 else "rank 0 could not make a communicator id")
+        return cls(device, rank, world, bytes(t[:128].numpy().tobytes()))
 
     def info(self):
         r, w, d, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
