@@ -38,6 +38,12 @@ mkdir -p $B/out/devsearch
 S4G_CHUNK_BYTES=1500 S4G_PREFILTER_CHUNK_BYTES=1200 LD_LIBRARY_PATH=$B/lib $B/sift4g_devsearch -q $F/query.fasta --subst $F/ -d $F/sample_protein_database.fa \
     --cards 0 --out $B/out/devsearch --sub-results -t 4 > $B/out/devsearch/stdout.txt 2>> $B/out/stderr.txt || [ "$MODE" = thread ]
 for f in LACI_ECOLI.SIFTprediction PURR_SALTY.SIFTprediction alignments.txt; do cmp $B/out/devsearch/$f tests/golden/dropin_predictions/$f; done
+# the same build with TWO cards: one host thread per card works on the same flat database (the placeholders' real chains are
+# built on first use from either thread, under the database's lock: ADVICE r3)
+mkdir -p $B/out/cards00
+S4G_CHUNK_BYTES=1500 S4G_PREFILTER_CHUNK_BYTES=1200 LD_LIBRARY_PATH=$B/lib $B/sift4g_devsearch -q $F/query.fasta --subst $F/ -d $F/sample_protein_database.fa \
+    --cards 00 --out $B/out/cards00 --sub-results -t 4 > $B/out/cards00/stdout.txt 2>> $B/out/stderr.txt || [ "$MODE" = thread ]
+for f in LACI_ECOLI.SIFTprediction PURR_SALTY.SIFTprediction alignments.txt; do cmp $B/out/cards00/$f tests/golden/dropin_predictions/$f; done
 for ev in 0 1; do      # the batched entry points: callback selection and e-value driven selection
     LD_LIBRARY_PATH=$B/lib $B/shotgun_demo $F/query.fasta $F/sample_protein_database.fa 400 1e-4 4 $ev > $B/out/shotgun_$ev.txt 2>> $B/out/stderr.txt
 done
