@@ -54,6 +54,15 @@ def _check_common(d, n_gpus, steps, warmup):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 0
     # `peak` is priced at the guide's 2.4 GHz; the clock the timed kernel ran at is sampled inside it and prices the second peak
     assert "2400 MHz" in rf["peak_basis"] and rf["frac_algorithmic"] == rf["frac"] and rf["traffic_measured_in_run"] is False
+    # round 4: what the arithmetic type guarantees is in `dtype`; the two issue models sit side by side; stored counter figures are
+    # keyed on the hash of the kernel sources (and are null whenever that hash is not the profiled build's)
+    assert d["dtype"] == "int32" or d["dtype"].endswith("int32 out")
+    assert rf["frac_every_instruction_a_full_slot"] >= rf["frac"] and "frac_model" in rf
+    from sift4g_amd.srchash import kernel_source_sha
+    assert rf["kernel_source_sha"] == kernel_source_sha()
+    if rf["traffic"] is not None:
+        import json as _json
+        assert _json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernel_source_sha"] == rf["kernel_source_sha"]
     ck = rf["clock_in_kernel"]
     if ck["launches_sampled"]:           # a call that went to the pair waves as a whole launches no scan kernel
         assert 800.0 < ck["min_block"] <= ck["shader_mhz"] <= ck["max_block"] < 2600.0 and ck["blocks"] >= 1
