@@ -186,6 +186,8 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 #define S4G_SCAN_BLOCK_PIPE 64u /* every tile whose queries fit the drifting-frame window runs on the block-cooperative strip pipeline
                                    (sw_scan_lists in scan mode: the four waves of a block on one (group, query pair) item) whatever the
                                    query count; by default calls of 3 to 16 queries (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it */
+#define S4G_SCAN_DIAG_FRAME 128u /* the drifting-frame tier runs sw_scan_pkd (frame grows per anti-diagonal, rounds 1-4) instead of sw_scan_pkc
+                                   (frame grows per column, round 5): the same results, kept as an independent second form */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,

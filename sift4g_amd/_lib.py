@@ -22,6 +22,7 @@ S4G_SCAN_NO_DRIFT = 8
 S4G_SCAN_NO_PAIRS = 16
 S4G_SCAN_NO_SPEC = 32
 S4G_SCAN_BLOCK_PIPE = 64
+S4G_SCAN_DIAG_FRAME = 128
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)

@@ -12,8 +12,10 @@ constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of 
 
 // Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
 // is EXACT for it (score bound = sum_i max(0, max_b M[q_i][b]); see sw_kernels.hip.h for each window):
-//   drift  sw_scan_pkd          bound + B + (rows + tile columns) * ext <= 0x7BFF      6.5 ops / pair of cells
-//          ... or speculatively: only the frame B + (rows + columns) * ext (+ a span) fits; the kernel marks results that
+//   drift  sw_scan_pkc          bound + B + tile columns * ext <= 0x7BFF               6.5 ops / pair of cells, 3 of them double-rate
+//          (column frame, round 5; S4G_SCAN_DIAG_FRAME or S4G_SCAN_FRAME=diag selects sw_scan_pkd, the anti-diagonal frame of
+//          rounds 1-4, whose window is bound + B + (rows + tile columns) * ext)
+//          ... or speculatively: only the frame B + columns * ext (+ a span) fits; the kernel marks results that
 //          came near the window's end and sw_pair_recheck recomputes those in int32 (Plan::speculative)
 //   m3     sw_scan_pk<I16M3>    bound + B <= 0x7BFF   (or ArithF16: bound <= 4096)     7.5
 //          ... or speculatively (I16M3 only) when no drift frame fits: results with best + B beyond 0x7BFF - max score are marked
@@ -38,8 +40,15 @@ struct Plan {
     uint64_t n_by_tier[4] = {0, 0, 0, 0};   // queries per tier, summed over tiles (reporting)
     bool speculative = false;       // some query runs in the drift tier on its frame alone: marked results need sw_pair_recheck
     uint64_t n_spec = 0;            // (query, tile) combinations routed speculatively (reporting)
-    uint32_t spec_base = 0;         // 0x7BFF - bias - (max score + 2 ext)
+    uint32_t spec_base = 0;         // sw_scan_pkd: 0x7BFF - bias - (max score + 2 ext); sw_scan_pkc: 0x7BFF - (max score + ext), in the frame
+    bool rows24 = false;            // EXPERIMENT: sw_scan_pkc<24, 4>
+    bool col_frame = true;          // drift tier = sw_scan_pkc (column frame) rather than sw_scan_pkd (anti-diagonal frame)
 };
+// S4G_SCAN_FRAME=diag|col overrides the flag for a whole process (A/B runs of bench.py and the tests)
+static int frame_env() {
+    static const int v = []() { const char* e = getenv("S4G_SCAN_FRAME"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
+    return v;
+}
 constexpr uint64_t kSpecSpan = 6144;    // scores a speculative query can reach without a recheck, at least
 
 int device_props(DeviceCtx* cx) {
@@ -70,6 +79,8 @@ int warm_scan_kernels(DeviceCtx* cx) {
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pk<ArithI16, kStripRows16>, &cx->grid_i16);
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &cx->grid_f16);
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
+    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkc<kStripRows16>, &cx->grid_col);
+    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkc<24, 4>, &cx->grid_col24);
     return rc;
 }
 
@@ -107,7 +118,13 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     if (rc) return rc;
     rc = grid_for(db, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
     if (rc) return rc;
-    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = cx->grid_drift;
+    rc = grid_for(db, (const void*)sw_scan_pkc<kStripRows16>, &cx->grid_col);
+    if (rc) return rc;
+    rc = grid_for(db, (const void*)sw_scan_pkc<24, 4>, &cx->grid_col24);
+    if (rc) return rc;
+    p->rows24 = getenv("S4G_PKC_ROWS24") != nullptr;
+    p->col_frame = frame_env() ? frame_env() == 2 : !(flags & S4G_SCAN_DIAG_FRAME);
+    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = p->col_frame ? (p->rows24 ? cx->grid_col24 : cx->grid_col) : cx->grid_drift;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
     p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
     // bias of the maximum3-on-bit-patterns tiers: keeps diag+s, h-open, E-ext (and H~(0,-1) = B - ext in the drift frame) >= 0
@@ -132,6 +149,10 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         if (((uint64_t)max_rows + 2 * kStripRows + max_cols) * (uint64_t)sc->ext + max_bound + step >= (1ull << 31)) p->wide_drift = false;
     }
     p->spec_base = (uint32_t)(cap > p->bias + step ? cap - p->bias - step : 0);
+    // column frame: a cell adds at most max score + ext to a stored value, the running maximum ext per column; the kernel compares
+    // IN the frame (sw_scan_pkc), so the bias is not part of the threshold
+    const uint64_t step_c = (uint64_t)std::max(0, sc->max_score) + (uint64_t)sc->ext;
+    if (p->col_frame) p->spec_base = (uint32_t)(cap > step_c ? cap - step_c : 0);
 
     std::vector<uint32_t> ids[4];
     auto add_pairs = [&](std::vector<uint32_t>& v, uint32_t* off, uint32_t* n) {
@@ -151,10 +172,11 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         for (uint32_t i = 0; i < q_count; ++i) {
             const uint32_t id = q_begin + i;
             const uint64_t b = q->score_bound[id];
-            const uint64_t rows = (uint64_t)q->len[id] + 2 * kStripRows16;          // padded rows of the pair's strips
+            const uint64_t rows = p->col_frame ? 0 : (uint64_t)q->len[id] + 2 * kStripRows16;   // anti-diagonal frame: padded rows of the pair's strips
+            const uint64_t fstep = p->col_frame ? step_c : step;
             int tier;
             if (!no_drift && gaps16 && b + p->bias + (rows + cols) * (uint64_t)sc->ext <= cap) tier = 0;
-            else if (!no_drift && !no_spec && gaps16 && p->bias + step + (rows + cols) * (uint64_t)sc->ext + kSpecSpan <= cap) {
+            else if (!no_drift && !no_spec && gaps16 && p->bias + fstep + (rows + cols) * (uint64_t)sc->ext + kSpecSpan <= cap) {
                 tier = 0;               // the frame fits with room to spare: run there, recheck what comes near the end
                 p->speculative = true;
                 p->n_spec++;
@@ -287,7 +309,9 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         a.spec_base = p.speculative ? p.spec_base : 0;
         const uint32_t gd = grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift);
         a.clk = clk_region(gd, 0);
-        hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
+        if (p.col_frame && p.rows24) hipLaunchKernelGGL((sw_scan_pkc<24, 4>), dim3(gd), dim3(kBlock), 0, stream, a);
+        else if (p.col_frame) hipLaunchKernelGGL((sw_scan_pkc<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
+        else hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }
     if (w.n_m3) {
@@ -509,7 +533,7 @@ S4G_API int s4g_scan_plan(const s4g_db* db, const s4g_queries* q, const s4g_scor
     // report the kernel that carries most of the queries
     int top = 0;
     for (int k = 1; k < 4; ++k) if (p.n_by_tier[k] > p.n_by_tier[top]) top = k;
-    const char* names[4] = {"sw_scan_pkd<32>", p.f16_arith ? "sw_scan_pk<ArithF16,32>" : "sw_scan_pk<ArithI16M3,32>", "sw_scan_pk<ArithI16,32>",
+    const char* names[4] = {p.col_frame ? "sw_scan_pkc<32>" : "sw_scan_pkd<32>", p.f16_arith ? "sw_scan_pk<ArithF16,32>" : "sw_scan_pk<ArithI16M3,32>", "sw_scan_pk<ArithI16,32>",
                             p.wide_drift ? "sw_scan_i32d<32>" : "sw_scan_i32<32>"};
     const uint32_t grids[4] = {p.grid_drift, p.grid_m3, p.grid_i16, p.grid_i32};
     if (kernel_name && kernel_name_cap) snprintf(kernel_name, kernel_name_cap, "%s", names[top]);

@@ -923,4 +923,211 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
     clk_leave(a.clk, lane);
 }
 
+// =====================================================================================================
+// sw_scan_pkc: the packed kernel in a COLUMN frame (round 5) -- the same 6.5 vector instructions per pair of cells as
+// sw_scan_pkd, but three of them (not two) are two-VGPR 32-bit adds / subtracts, the class gfx950 issues at double rate
+// when two waves present one together (tools/valu_issue.hip), and nothing in the row loop depends on the row index.
+//
+// Store every DP value with a bias that grows by `ext` per COLUMN only:   X~(i,j) = X(i,j) + B + j*ext,  z_j = B + j*ext.
+//     H~(i,j)   = max3( H~(i-1,j-1) + (s + e),  E~(i,j),  F~(i,j) )               s + e comes from the strip profile
+//     E~(i,j+1) = max3( E~(i,j),  H~(i,j) + (e - o),  z_{j+1} )                   floor E >= 0; z_{j+1} is ONE SGPR per column
+//     F~(i+1,j) = max ( F~(i,j),  H~(i,j) + (e - o) )  -  e                       v_sub_u32 v, v, v: double-rate class
+//     best~     = max3( best~, H~(i,j), H~(i+1,j) )                               the running maximum lives IN the frame:
+//     best~    += e   once per column                                             z_j is uniform over a column's rows
+// sw_scan_pkd's per-row "true H = H~ - z(i,j)" (a packed subtract with an SGPR operand, single rate) is gone; its place in
+// the count is taken by F's "- e".  Per pair of cells: 3 double-rate (diag + s', H~ + (e - o), F - e) + 3.5 single-rate
+// (max3, max3, max, 1/2 max3) against 2 + 4.5.  No per-row frame constants (sw_scan_pkd's r*e SGPRs, some of which spilled to
+// v_readlane reloads), and the exactness window loses its row term:  bound + B + columns * e <= 0x7BFF.
+// Non-negativity (what makes v_pk_maximum3_f16 an integer max3 and the 32-bit adds packed adds): H~ >= z_j >= B because
+// E~ >= z_j; diag + s + e >= z_{j-1} + e + s >= B + min score >= 0; H~ + (e - o) >= B + e - o >= 0; F~ - e >= z_j - o >= 0
+// -- with the same B >= max(64, open, 2 ext, -min score) as sw_scan_pkd.
+//
+// Speculative launches (spec_base != 0; the host guarantees only that the FRAME fits: B + (max score + e) + columns*e + span
+// <= 0x7BFF).  The in-frame running maximum is its own witness: its "+= e" is a SIGNED SATURATING packed add (v_pk_add_i16
+// clamp: one single-rate instruction per column), so as a 16-bit pattern best~ never decreases inside a strip and never passes
+// 0x7FFF -- h is never a negative pattern (E~ >= z_j, finite and positive, is one of its operands, so a wrapped diag + s' loses the
+// max or a NaN pattern 0x7C01.. wins it and then propagates through every later maximum3).  Claim: best~ <= spec_base =
+// 0x7BFF - (max score + e) at the end of every strip  =>  the result is exact.  The first value ever to leave the window is a
+// diag + s' whose diag was exact and > 0x7BFF - (max score + e) -- which best~ took in in the column before and cannot lose -- or
+// best~ itself, above spec_base before the add.  `ovf` collects best~ at the end of each strip (best~ is re-based between strips).
+// =====================================================================================================
+// LDS byte offset of a column's profile slot: (residue code) * 16.  A residue byte holds 0 .. 31, so the byte IS the code and one
+// SDWA shift (v_lshlrev_b32_sdwa ... src1_sel:BYTE_n) does it; pk_taddr's shift + mask are two instructions per column.
+__device__ __forceinline__ unsigned pkc_taddr(uint32_t r4, int cc) { return ((r4 >> (8 * cc)) & 0xFFu) << 4; }
+
+template <int R>
+__device__ __forceinline__ void pkc_rows8(int (&H)[R], int (&E)[R], int row0, const v4i (&sc)[2], int& diag, int& F, int& best,
+                                          int eo, int e2v, int zn) {
+    int hprev = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + i;
+        const int h = pk_maximum3((int)((unsigned)diag + (unsigned)sc[i / 4][i % 4]), E[r], F);
+        if (i & 1) best = pk_maximum3(best, hprev, h); else hprev = h;
+        const int hm = (int)((unsigned)h + (unsigned)eo);
+        E[r] = pk_maximum3(E[r], hm, zn);                               // zn = z_{j+1}, an SGPR that is constant over the column
+        F = (int)((unsigned)as_i(pk_max(as_s(F), as_s(hm))) - (unsigned)e2v);
+        diag = H[r];
+        H[r] = h;
+    }
+}
+
+template <int R, int RR, bool FIRST>
+__device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+                                          bool last, int& best, int eo, int e2v, int e2, int B2) {
+    constexpr bool first = FIRST;
+    constexpr int NB = RR / 8;
+    // res_u, wsH, wsF are UNIFORM bases; a lane adds its own 32-bit byte offset, so every access is "SGPR base + VGPR offset" and the
+    // chunk's address arithmetic runs on the scalar unit (sw_scan_pkd spends five 64-bit vector adds per chunk on it)
+    const unsigned lane4 = (unsigned)lane * 4u, lane16 = (unsigned)lane * 16u;
+    auto ld_res = [&](unsigned c) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(res_u + (uint64_t)c * 64) + lane4); };
+    auto ld_ws = [&](const v4i* w, unsigned c) { return *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(w + (uint64_t)c * 64) + lane16); };
+    auto st_ws = [&](v4i* w, unsigned c, v4i v) { *reinterpret_cast<v4i*>(reinterpret_cast<char*>(w + (uint64_t)c * 64) + lane16) = v; };
+    int H[R];
+    int E[R];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) { H[r] = B2 - e2; E[r] = B2; }          // H~(i,-1) = z_{-1}, E~(i,0) = z_0 for H = E = 0: the same in every row
+    int zj = B2;                            // z_j of the current column (SGPR)
+    int hdiag = B2 - e2;                    // H~(i0-1, -1)
+    uint32_t res_n = ld_res(0);
+    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
+    if (!first && len4) { hb_n = ld_ws(wsH, 0); fb_n = ld_ws(wsF, 0); }
+    v4i sc_n[2];
+    pk_load8(sc_n, prof, pkc_taddr(res_n, 0), 0);
+    for (unsigned c = 0; c < len4; ++c) {
+        const uint32_t r4 = res_n;
+        const v4i hb = hb_n, fb = fb_n;
+        const unsigned cn = (c + 1 < len4) ? c + 1 : c;
+        res_n = ld_res(cn);
+        if (!first) { hb_n = ld_ws(wsH, cn); fb_n = ld_ws(wsF, cn); }
+        v4i ho, fo;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const unsigned taddr = pkc_taddr(r4, cc);
+            const unsigned taddr_next = cc < 3 ? pkc_taddr(r4, cc + 1) : pkc_taddr(res_n, 0);
+            int diag = hdiag;
+            int F = first ? zj : fb[cc];             // first strip: F~(0,j) = z_j (F = 0)
+            const int zn = zj + e2;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                v4i sc[2] = {sc_n[0], sc_n[1]};
+                if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
+                pkc_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, e2v, zn);
+            }
+            hdiag = first ? zj : hb[cc];             // first strip: H~(-1, j) = z_j (H = 0)
+            zj = zn;
+            ho[cc] = H[RR - 1];
+            fo[cc] = F;
+            best = as_i(__builtin_elementwise_add_sat(as_s(best), as_s(e2)));   // best~ moves to column j+1's frame; saturating: see "speculative launches" above
+            asm volatile("" : "+v"(best));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last) { st_ws(wsH, c, ho); st_ws(wsF, c, fo); }
+    }
+}
+
+template <int R, int WPS = 3>
+__global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
+    static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
+    __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    signed char* lmat = reinterpret_cast<signed char*>(lds);
+    char* prof = lds + 1024 + wave * (R * 128);
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        reinterpret_cast<int*>(lds)[i] = reinterpret_cast<const int*>(a.mat)[i];
+    __syncthreads();
+    clk_enter(a.clk);
+
+    const unsigned slot = blockIdx.x * kWavesPerBlock + wave;
+    v4i* wsH = reinterpret_cast<v4i*>(a.ws + (uint64_t)slot * a.ws_slot);
+    const unsigned n_items = a.n_groups * a.n_pairs;
+    const int e2 = (int)(a.ext | (a.ext << 16));
+    int e2v = e2;                                                        // the same pair in a VGPR: operand of the double-rate subtract / add
+    int eo = ((int)a.ext - (int)a.open) * 65537;                         // the pair (e - o, e - o) as the integer hi * 65536 + lo, in a VGPR
+    asm volatile("" : "+v"(eo), "+v"(e2v));
+    const int B2 = (int)a.floor_bits;                                   // packed bias B
+    const int one_e = (int)a.ext;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const unsigned g = item / a.n_pairs;
+        const unsigned pi = item - g * a.n_pairs;
+        const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
+        const bool hasB = qB != 0xFFFFFFFFu;
+        const unsigned len4 = a.grp_len4[g];
+        const uint32_t* res = a.db_res + a.grp_off[g];       // uniform; pkc_strip adds the lane
+        const uint8_t* qcA = a.q_codes + a.q_off[qA];
+        const uint8_t* qcB = a.q_codes + a.q_off[hasB ? qB : qA];
+        const unsigned lA = a.q_len[qA], lB = hasB ? a.q_len[qB] : 0u;
+        const unsigned capA = (lA + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;
+        const unsigned capB = hasB ? (lB + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign : 0u;
+        const unsigned lq = lA > lB ? lA : lB;
+        const unsigned nstrips = (lq + R - 1) / R;
+        v4i* wsF = wsH + (uint64_t)len4 * 64;
+        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);   // see sw_scan_pk
+        const int zend = B2 + (int)(len4 * 4u) * e2;                   // z of the column after the last: where best~ stands when a strip ends
+        int best = 0;                                                   // true running maximum (both halves), between strips
+        int ovf = 0;
+
+        for (unsigned s = 0; s < nstrips; ++s) {
+            const unsigned rows_left = lq - s * R;
+            const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
+            // ---- strip profile: packed (sA + e, sB + e) ----
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e0 = 0; e0 < 8 * R; e0 += 64) {
+                const int e = e0 + lane;
+                const int kk = e >> 5, t = e & 31;
+                const unsigned row0 = s * R + 4 * kk;
+                const unsigned cA = row0 < capA ? *reinterpret_cast<const unsigned*>(qcA + row0) : 0x1F1F1F1Fu;
+                const unsigned cB = row0 < capB ? *reinterpret_cast<const unsigned*>(qcB + row0) : 0x1F1F1F1Fu;
+                v4i out;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int sA = lmat[((cA >> (8 * d)) & 31u) * 32 + t] + one_e;
+                    const int sB = lmat[((cB >> (8 * d)) & 31u) * 32 + t] + one_e;
+                    out[d] = (int)(((unsigned)sB << 16) + (unsigned)sA);        // integer-sum pair: a negative sA borrows from sB in advance
+                }
+                *reinterpret_cast<v4i*>(prof + e * 16) = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            const bool first = (s == 0), last = (s + 1 == nstrips);
+            int bf = (int)((unsigned)best + (unsigned)B2);              // best~ in column 0's frame
+            bool done = false;
+#define S4G_LAST_STRIP(RR_)                                                                                  \
+            if constexpr (R > RR_) {                                                                         \
+                if (!done && rr == RR_) {                                                                    \
+                    if (first) pkc_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2); \
+                    else pkc_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);    \
+                    done = true;                                                                             \
+                }                                                                                            \
+            }
+            S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
+#undef S4G_LAST_STRIP
+            if (!done) {
+                if (first) pkc_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);
+                else pkc_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);
+            }
+            ovf = as_i(__builtin_elementwise_max(as_u(ovf), as_u(bf)));
+            best = (int)((unsigned)bf - (unsigned)zend);                // back to the true maximum (no borrow: bf >= zend in both halves)
+        }
+        int outA = (int)as_s(best)[0], outB = (int)as_s(best)[1];
+        if (a.spec_base) {
+            if (((unsigned)ovf & 0xFFFFu) > a.spec_base) outA = outB = kScoreUnsure;   // (kept from sw_scan_pkd: a marked lower half marks the upper one)
+            if (((unsigned)ovf >> 16) > a.spec_base) outB = kScoreUnsure;
+        }
+        const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
+        if (p != 0xFFFFFFFFu) {
+            a.scores[(uint64_t)(qA - a.q_begin) * a.score_stride + p] = outA;
+            if (hasB) a.scores[(uint64_t)(qB - a.q_begin) * a.score_stride + p] = outB;
+        }
+    }
+    clk_leave(a.clk, lane);
+}
+
 }  // namespace s4g

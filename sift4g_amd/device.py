@@ -254,14 +254,14 @@ def clock_probe(device=0):
     return dict(shader_mhz=out[0], pk_add_T_lane_ops=out[1], cus=int(out[2]), nominal_mhz=out[3], probe_ms=out[4])
 
 
-def _flags(force_i32=False, no_f16=False, f16_arith=False, no_drift=False, no_pairs=False, no_spec=False, block_pipe=False):
-    return ((_lib.S4G_SCAN_FORCE_I32 if force_i32 else 0) | (_lib.S4G_SCAN_NO_F16 if no_f16 else 0) | (_lib.S4G_SCAN_BLOCK_PIPE if block_pipe else 0) |
+def _flags(force_i32=False, no_f16=False, f16_arith=False, no_drift=False, no_pairs=False, no_spec=False, block_pipe=False, diag_frame=False):
+    return ((_lib.S4G_SCAN_DIAG_FRAME if diag_frame else 0) | (_lib.S4G_SCAN_FORCE_I32 if force_i32 else 0) | (_lib.S4G_SCAN_NO_F16 if no_f16 else 0) | (_lib.S4G_SCAN_BLOCK_PIPE if block_pipe else 0) |
             (_lib.S4G_SCAN_F16_ARITH if f16_arith else 0) | (_lib.S4G_SCAN_NO_DRIFT if no_drift else 0) |
             (_lib.S4G_SCAN_NO_PAIRS if no_pairs else 0) | (_lib.S4G_SCAN_NO_SPEC if no_spec else 0))
 
 
 def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False,
-         no_pairs=False, no_spec=False, block_pipe=False):
+         no_pairs=False, no_spec=False, block_pipe=False, diag_frame=False):
     """Asynchronous scan into a device tensor `out` (torch int32 [q_count, n_seqs], on db.device).
 
     stream: a torch.cuda.Stream (default: torch's current stream on that device)."""
@@ -272,17 +272,17 @@ def scan(db, queries, scorer, out, q_begin=0, q_count=None, stream=None, force_i
     if stream is None:
         stream = torch.cuda.current_stream(out.device)
     check(lib.s4g_scan_flags(db._h, queries._h, q_begin, q_count, scorer._h, ctypes.c_void_p(out.data_ptr()),
-                             ctypes.c_void_p(stream.cuda_stream), _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec, block_pipe)), "s4g_scan_flags")
+                             ctypes.c_void_p(stream.cuda_stream), _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec, block_pipe, diag_frame)), "s4g_scan_flags")
     return out
 
 
 def scan_host(db, queries, scorer, q_begin=0, q_count=None, force_i32=False, no_f16=False, f16_arith=False, no_drift=False,
-              no_pairs=False, no_spec=False, block_pipe=False):
+              no_pairs=False, no_spec=False, block_pipe=False, diag_frame=False):
     """Synchronous scan -> numpy int32 [q_count, n_seqs]."""
     q_count = queries.n - q_begin if q_count is None else q_count
     out = np.zeros((q_count, db.n), dtype=np.int32)
     check(lib.s4g_scan_host_flags(db._h, queries._h, q_begin, q_count, scorer._h, _ptr(out, c_i32p),
-                                  _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec, block_pipe)), "s4g_scan_host_flags")
+                                  _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec, block_pipe, diag_frame)), "s4g_scan_host_flags")
     return out
 
 
@@ -310,7 +310,7 @@ def score_pairs(db, queries, scorer, pair_q, pair_t, route=None):
 
 
 def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stream=None, force_i32=False, no_f16=False,
-              f16_arith=False, no_drift=False, no_pairs=False, no_spec=False):
+              f16_arith=False, no_drift=False, no_pairs=False, no_spec=False, diag_frame=False):
     """Streaming scan + running top-k (no score matrix): -> device tensors (ids int32 [q,k] (-1 unused), scores [q,k], counts [q])."""
     import torch
     q_count = queries.n - q_begin if q_count is None else q_count
@@ -322,7 +322,7 @@ def scan_topk(db, queries, scorer, k, min_score=1, q_begin=0, q_count=None, stre
         stream = torch.cuda.current_stream(device)
     check(lib.s4g_scan_topk(db._h, queries._h, q_begin, q_count, scorer._h, k, int(min_score), ctypes.c_void_p(ids.data_ptr()),
                             ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(stream.cuda_stream),
-                            _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec)), "s4g_scan_topk")
+                            _flags(force_i32, no_f16, f16_arith, no_drift, no_pairs, no_spec, diag_frame=diag_frame)), "s4g_scan_topk")
     return ids, sc, cnt
 
 

@@ -30,7 +30,8 @@ def _check(s4g, oracle_mod, M, queries, targets, scorer, go=10, ge=1, threads=8)
     # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
     # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
     # block_pipe: the block-cooperative strip pipeline (sw_scan_lists in scan mode) wherever the queries fit its window
-    for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
+    # diag_frame: the drifting-frame tier in its anti-diagonal form (sw_scan_pkd, rounds 1-4) instead of the column frame (sw_scan_pkc)
+    for mode in (dict(), dict(no_pairs=True), dict(diag_frame=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
                  dict(force_i32=True), dict(force_i32=True, no_drift=True)):
         got = s4g.scan_host(db, qs, scorer, **mode)
         bad = np.argwhere(got != exp)
@@ -194,6 +195,39 @@ def test_drift_frame_window_routing(s4g, oracle_mod, blosum62):
     db = s4g.Database(ts, tile_seqs=64)                        # the 13000-residue target gets a tile of its own
     exp = oracle_mod.scan(qs, ts, blosum62, 12, 3, threads=8)
     assert np.array_equal(s4g.scan_host(db, s4g.QuerySet(qs), s4g.Scorer("BLOSUM_62", 12, 3)), exp)
+
+
+def test_column_frame_window_edge(s4g, oracle_mod, blosum62, scorer):
+    """sw_scan_pkc stores X + B + j*ext and keeps its running maximum in that frame: exact while bound + B + columns*ext <= 0x7BFF,
+    whatever the query's length adds in rows.  A poly-W query of 2600 against a poly-W target of 3068: bound 28 600 + 64 + 3076
+    columns = 31 740 <= 31 743 routes by bound into the drift tier and the in-frame maximum really climbs to 31 732, twelve below the
+    first f16 infinity pattern; one more W in the query (28 611) is beyond the window and runs elsewhere (speculatively in the
+    same kernel by default -- marked and rechecked --, in the maximum3 tier with routing by bound).  Both frames, every mode."""
+    from sift4g_amd import device as s4gd
+    W = ord("W") - 65
+    rng = np.random.default_rng(35)
+    qs = [np.full(2600, W, dtype=np.uint8), np.full(2601, W, dtype=np.uint8)] + rand_seqs(rng, 4, 100, 400)
+    ts = [np.full(3068, W, dtype=np.uint8), np.full(2600, W, dtype=np.uint8)] + rand_seqs(rng, 100, 30, 700)
+    got = _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
+    assert got[0, 0] == 28600 and got[1, 0] == 28611 and got[1, 1] == 28600
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    # (a tier with little work is folded into the next slower one when one launch beats two, so the routing is read off calls
+    # whose queries all belong to one tier)
+    inside = s4g.QuerySet([qs[0]] + qs[2:])
+    assert np.array_equal(s4g.scan_host(db, inside, scorer, no_pairs=True, no_spec=True), exp[[0, 2, 3, 4, 5]])
+    st = s4gd.scan_stats(0)
+    assert st["tier_drift"] == 5 and st["tier_m3"] == 0 and st["speculative"] == 0 and st["rechecked"] == 0, st
+    assert np.array_equal(s4g.scan_host(db, s4g.QuerySet([qs[1]]), scorer, no_pairs=True, no_spec=True), exp[1:2])
+    st = s4gd.scan_stats(0)
+    assert st["tier_drift"] == 0 and st["tier_m3"] == 1, st
+    assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), exp)
+    st = s4gd.scan_stats(0)
+    assert st["tier_drift"] == 6 and st["speculative"] == 1 and 1 <= st["rechecked"] <= 4, st
+    # the anti-diagonal frame's window also counts the rows: the 2600-residue query is outside it (28 600 + 64 + 2664 + 3076)
+    assert np.array_equal(s4g.scan_host(db, s4g.QuerySet([qs[0]]), scorer, diag_frame=True, no_spec=True), exp[0:1])
+    st = s4gd.scan_stats(0)
+    assert st["tier_drift"] == 0 and st["tier_m3"] == 1, st
 
 
 def test_odd_query_counts_and_unequal_pairs(s4g, oracle_mod, blosum62, scorer):
@@ -417,7 +451,8 @@ def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
         # (small inputs are latency-bound: by default they take the one-wave-per-pair route, no_pairs keeps them on the scan kernels)
     # (int32 alone runs the drifting-frame int32 kernel where the scorer's shifted scores fit its int8 profile; + no_drift: the fixed frame)
     # block_pipe: the block-cooperative strip pipeline (sw_scan_lists in scan mode) wherever the queries fit its window
-    for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
+    # diag_frame: the drifting-frame tier in its anti-diagonal form (sw_scan_pkd, rounds 1-4) instead of the column frame (sw_scan_pkc)
+    for mode in (dict(), dict(no_pairs=True), dict(diag_frame=True), dict(block_pipe=True), dict(no_drift=True), dict(f16_arith=True), dict(no_f16=True),
                  dict(force_i32=True), dict(force_i32=True, no_drift=True)):
             assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp)
 
@@ -1095,7 +1130,7 @@ def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
         assert exp.max() > 32767 and np.sort(exp[3])[-3] > 12000
         for tile_seqs in (0, 64):
             db = s4g.Database(ts, tile_seqs=tile_seqs)
-            for mode in (dict(no_pairs=True), dict(no_spec=True), dict()):
+            for mode in (dict(no_pairs=True), dict(diag_frame=True), dict(no_spec=True), dict(no_spec=True, diag_frame=True), dict()):
                 got = s4g.scan_host(db, q, sc, **mode)
                 bad = np.argwhere(got != exp)
                 assert bad.size == 0, (go, ge, tile_seqs, mode, bad[:5].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
@@ -1119,11 +1154,19 @@ def test_speculative_launch_really_marks_results(s4g, oracle_mod, blosum62):
     sc = s4g.Scorer("BLOSUM_62", 10, 1)
     db, q = s4g.Database(ts), s4g.QuerySet(qs)
     exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    got = s4g.scan_host(db, q, sc, diag_frame=True)
+    st = s4gd.scan_stats(0)
+    assert np.array_equal(got, exp)
+    # anti-diagonal frame (sw_scan_pkd): self hits of the 5000- and 4200-residue queries (29k, 24k) lie beyond the limit
+    # (31 666 - the largest frame value of the pair: rows + columns); 2600 / 2500 (15k, 14k) do not
+    assert st["speculative"] >= 2 and 2 <= st["rechecked"] <= 8 and st["tier_i32"] == 0, st
     got = s4g.scan_host(db, q, sc, no_pairs=True)
     st = s4gd.scan_stats(0)
     assert np.array_equal(got, exp)
-    # self hits of the 5000- and 4200-residue queries (29k, 24k) lie beyond the limit (31 666 - frame); 2600 / 2500 (15k, 14k) do not
-    assert st["speculative"] >= 2 and 2 <= st["rechecked"] <= 8 and st["tier_i32"] == 0, st
+    # column frame (sw_scan_pkc): its window has no row term, so only the 5000-residue query (bound 28k + 64 + 5008 columns) is
+    # beyond it; the mark is taken IN the frame, score + B + column, against 0x7BFF - 12: the 29k self hit ends at column 5000
+    # (34k: marked, and its partner's result at that target with it)
+    assert st["speculative"] >= 1 and 1 <= st["rechecked"] <= 4 and st["tier_i32"] == 0, st
     got = s4g.scan_host(db, q, sc, no_pairs=True, no_spec=True)
     st = s4gd.scan_stats(0)
     assert np.array_equal(got, exp) and st["speculative"] == 0 and st["rechecked"] == 0, st

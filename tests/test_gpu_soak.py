@@ -63,7 +63,7 @@ def soak(budget, seed):
         exp = oracle.scan(qs, ts, M, go, ge, threads=8)
         cells += sum(len(x) for x in qs) * sum(len(x) for x in ts)
         ctx = (it, go, ge, nq, nt, qmax, tmax)
-        for mode in (dict(), dict(no_pairs=True), dict(block_pipe=True), dict(force_i32=True), dict(force_i32=True, no_drift=True), dict(no_spec=True)):
+        for mode in (dict(), dict(no_pairs=True), dict(diag_frame=True), dict(block_pipe=True), dict(force_i32=True), dict(force_i32=True, no_drift=True), dict(no_spec=True)):
             assert np.array_equal(s4g.scan_host(db, q, sc, **mode), exp), ("scan", mode, ctx)
         k = int(rng.integers(1, min(nt, 40) + 1))               # streaming top-k: tiles (alternating when >= 3), segments, both routings
         for mode in (dict(no_pairs=True), dict()):
