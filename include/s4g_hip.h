@@ -345,7 +345,11 @@ int s4g_prefilter_destroy(s4g_prefilter* p);
  *                        MPI, torch.distributed ...).  Opens librccl on first use (S4G_ERR_NO_DEVICE if there is none).
  *   s4g_comm_create      collective: every rank of `world` calls it with the same id, its own rank and the device it scans on.
  *   s4g_gather_topk      collective, asynchronous on `stream`; all pointers are DEVICE pointers in the layout s4g_topk /
- *                        s4g_scan_topk write (ids 0xFFFFFFFF = unused, lists ordered by score descending then id ascending).
+ *                        s4g_scan_topk write (ids 0xFFFFFFFF = unused, lists ordered by score descending then id ascending:
+ *                        the merge relies on that order and on distinct global ids, it does not check them).  A communicator
+ *                        stages through one buffer pair: a gather waits (on the device) for the previous gather of the same
+ *                        communicator whatever stream that ran on, and every rank must issue its gathers in the same order.
+ *                        S4G_RCCL_LIBRARY names the RCCL library to open instead of librccl.so.1.
  *     S4G_GATHER_QUERY_SHARD  database replicated; this rank holds the lists of queries [n*rank/world, n*(rank+1)/world) of the
  *                        n_queries in total (d_ids / d_scores [own queries][k], d_counts [own queries]; may be NULL for a rank
  *                        without queries).  Out: all n_queries lists in query order, on every rank.  k_out must equal k;

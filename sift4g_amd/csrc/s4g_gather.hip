@@ -45,10 +45,15 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // S4G_RCCL_LIBRARY names the one library to open instead (a vendor build elsewhere; the CPU test of this error path)
+        const char* forced = getenv("S4G_RCCL_LIBRARY");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names)
-            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.handle) { r.error = dlerror() ? dlerror() : "dlopen failed"; return; }
+        if (forced && *forced) r.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else
+            for (const char* n : names)
+                if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        // (dlerror() clears the message it returns: ask once)
+        if (!r.handle) { const char* m = dlerror(); r.error = m ? m : "dlopen failed"; return; }
         auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + s; return p; };
         r.GetUniqueId = (int (*)(RcclId*))sym("ncclGetUniqueId");
         r.CommInitRank = (int (*)(RcclComm*, int, RcclId, int))sym("ncclCommInitRank");
@@ -167,6 +172,9 @@ struct s4g_comm {
     int32_t* d_send = nullptr;
     int32_t* d_recv = nullptr;
     uint64_t send_bytes = 0, recv_bytes = 0;
+    hipEvent_t done = nullptr;      // recorded behind the last kernel of a gather: the next gather (on whatever stream) waits for it before
+                                    // it packs into the one d_send / d_recv pair, and the buffers are not regrown underneath a gather in flight
+    std::mutex mu;                  // calls on one communicator are serialised on the host (RCCL wants its collectives issued in one order anyway)
 };
 
 S4G_API int s4g_comm_unique_id(uint8_t* id128) {
@@ -214,13 +222,18 @@ S4G_API int s4g_comm_destroy(s4g_comm* c) {
     (void)hipDeviceSynchronize();
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->comm) (void)rccl()->CommDestroy(c->comm);
     delete c;
     return S4G_OK;
 }
 
-static int comm_buffers(s4g_comm* c, uint64_t send_bytes) {
+// makes `stream` wait for the previous gather on this communicator (any stream) and sizes the staging pair
+static int comm_buffers(s4g_comm* c, uint64_t send_bytes, hipStream_t stream) {
     const uint64_t recv_bytes = send_bytes * (uint64_t)c->world;
+    if (!c->done) HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    else if (c->send_bytes < send_bytes || c->recv_bytes < recv_bytes) HIP_TRY(hipEventSynchronize(c->done));   // about to free what it may still read
+    else HIP_TRY(hipStreamWaitEvent(stream, c->done, 0));
     if (c->send_bytes < send_bytes) {
         if (c->d_send) HIP_TRY(hipFree(c->d_send));
         c->d_send = nullptr; c->send_bytes = 0;
@@ -244,6 +257,7 @@ S4G_API int s4g_gather_topk(s4g_comm* c, int mode, uint32_t n_queries, uint32_t 
     if (n_queries == 0) return S4G_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lk(c->mu);
     const uint32_t world = (uint32_t)c->world;
     if (mode == S4G_GATHER_QUERY_SHARD) {
         if (k_out != k) return fail(S4G_ERR_INVALID, "query-shard gather: k_out must equal k");
@@ -254,19 +268,20 @@ S4G_API int s4g_gather_topk(s4g_comm* c, int mode, uint32_t n_queries, uint32_t 
         for (uint32_t r = 0; r < world; ++r)
             per = std::max(per, (uint32_t)((uint64_t)n_queries * (r + 1) / world) - (uint32_t)((uint64_t)n_queries * r / world));
         const uint64_t row = 2ull * k + 1;
-        int rc = comm_buffers(c, (uint64_t)per * row * 4);
+        int rc = comm_buffers(c, (uint64_t)per * row * 4, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(pack_query_rows, dim3(per), dim3(128), 0, stream, d_ids, d_scores, d_counts, q_local, per, k, c->d_send);
         HIP_TRY(hipGetLastError());
         RCCL_TRY(rccl()->AllGather(c->d_send, c->d_recv, (size_t)per * row, kRcclInt32, c->comm, stream));
         hipLaunchKernelGGL(unpack_query_rows, dim3(n_queries), dim3(128), 0, stream, c->d_recv, n_queries, world, per, k, d_out_ids, d_out_scores, d_out_counts);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->done, stream));
         return S4G_OK;
     }
     if (mode == S4G_GATHER_DB_SHARD) {
         if (!d_ids || !d_scores || !d_counts) return fail(S4G_ERR_INVALID, "NULL argument");
         if (k_out == 0 || k_out > 4096) return fail(S4G_ERR_INVALID, "k_out must be in 1..4096 (got %u)", k_out);
-        int rc = comm_buffers(c, (uint64_t)n_queries * 2 * k * 4);
+        int rc = comm_buffers(c, (uint64_t)n_queries * 2 * k * 4, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(pack_shard_rows, dim3(n_queries), dim3(128), 0, stream, d_ids, d_scores, d_counts, k, id_base, d_id_map, c->d_send);
         HIP_TRY(hipGetLastError());
@@ -274,6 +289,7 @@ S4G_API int s4g_gather_topk(s4g_comm* c, int mode, uint32_t n_queries, uint32_t 
         hipLaunchKernelGGL(merge_shard_rows, dim3(n_queries), dim3(256), 0, stream, c->d_recv, c->d_recv + k, (uint64_t)n_queries * 2 * k, (uint64_t)2 * k,
                            world, k, k_out, d_out_ids, d_out_scores, d_out_counts);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->done, stream));
         return S4G_OK;
     }
     return fail(S4G_ERR_INVALID, "mode %d is neither S4G_GATHER_QUERY_SHARD nor S4G_GATHER_DB_SHARD", mode);

@@ -77,8 +77,13 @@ S4G_API int s4g_db_open_streamed(s4g_db** out, int device, const char* path) {
         TileHeaderS h;
         if (fread(&h, sizeof h, 1, f) != 1) return bad("tile header");
         // the header's numbers against each other (what s4g_db_save guarantees): device pointers are derived from them
+        // (every product is bounded before it is formed: crafted fields must not wrap a uint64 into a plausible size)
+        const uint64_t fsize = (uint64_t)st.st_size;
+        if (h.dwords > fsize / 4 || h.n_seqs > fsize / 4 || h.padded_residues > fsize || h.n_groups > fsize / 8)
+            return bad("a tile header names more data than the file holds");
+        unsigned __int128 lanes = (unsigned __int128)h.n_groups * 64u * h.max_len4;
         if (h.n_groups != (h.n_seqs + 63) / 64 || h.dwords * 4 != h.padded_residues || h.residues > h.padded_residues ||
-            h.dwords > (uint64_t)h.n_groups * 64 * h.max_len4 || h.pos0 != seqs_seen)
+            (unsigned __int128)h.dwords > lanes || h.pos0 != seqs_seen)
             return bad("inconsistent tile header");
         seqs_seen += h.n_seqs; padded_seen += h.padded_residues; residues_seen += h.residues;
         db->tiles.emplace_back();
@@ -90,7 +95,7 @@ S4G_API int s4g_db_open_streamed(s4g_db** out, int device, const char* path) {
         s->bytes.push_back(b);
         s->slot_bytes = std::max(s->slot_bytes, b);
         db->max_tile_seqs = std::max(db->max_tile_seqs, t.n_seqs);
-        if (s->file_off.back() + b > (uint64_t)st.st_size) return bad("file shorter than its tiles (truncated?)");     // every tile, not only the last
+        if (b > fsize || s->file_off.back() > fsize - b) return bad("file shorter than its tiles (truncated?)");     // every tile, not only the last
         if (fseeko(f, (off_t)b, SEEK_CUR) != 0) return bad("tile payload");
     }
     if (seqs_seen != db->n_seqs || padded_seen != db->padded_residues || residues_seen != db->residues) return bad("tile headers do not add up to the file header");
@@ -130,6 +135,16 @@ int db_stream_load(const s4g_db* db, size_t ti) {
         for (uint32_t g = 0; g < m.n_groups; ++g)
             if (glen[g] > m.max_len4 || goff[g] > dwords || (uint64_t)glen[g] * 64 > dwords - goff[g])
                 return fail(S4G_ERR_INVALID, "tile %zu of the packed database is corrupt (group %u lies outside the tile)", ti, g);
+        // the two permutations are WRITE indices of the scan kernels (global: a row of the score matrix, n_seqs wide; local: a row of
+        // the tile buffer, the tile's n_seqs wide); 0xFFFFFFFF marks an empty lane
+        const uint32_t* pglob = glen + m.n_groups;
+        const uint32_t* ploc = pglob + (uint64_t)m.n_groups * 64;
+        const uint32_t* cols = ploc + (uint64_t)m.n_groups * 64;
+        for (uint64_t i = 0, n = (uint64_t)m.n_groups * 64; i < n; ++i)
+            if ((pglob[i] != 0xFFFFFFFFu && pglob[i] >= db->n_seqs) || (ploc[i] != 0xFFFFFFFFu && ploc[i] >= m.n_seqs))
+                return fail(S4G_ERR_INVALID, "tile %zu of the packed database is corrupt (lane %llu maps outside the score row)", ti, (unsigned long long)i);
+        for (uint32_t i = 0; i < m.n_seqs; ++i)
+            if (cols[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "tile %zu of the packed database is corrupt (column %u names sequence %u of %u)", ti, i, cols[i], db->n_seqs);
     }
     HIP_TRY(hipMemcpyAsync(s->d_slot[k], s->h_pin[k], s->bytes[ti], hipMemcpyHostToDevice, s->copy_stream));
     HIP_TRY(hipEventRecord(s->uploaded[k], s->copy_stream));

@@ -35,6 +35,9 @@
 #include <vector>
 
 #include "impl.hpp"
+#include <mutex>
+#include <set>
+#include <string>
 #include "../matrices.h"
 
 namespace {
@@ -197,6 +200,38 @@ SW_API EValueParams* createEValueParams(long long length, Scorer* scorer) {
     }
     const GumbelRow& g = tab->rows[row];
     const GumbelRow& u = tab->rows[0];
+    // Say once which reading is in force when the two readings disagree and nobody chose.  The default looks
+    // the scorer's penalties up as they are -- what upstream swsharp does as far as anyone here recalls (main.cpp:71-76,210 hand
+    // them over unconverted) --, while the published rows are indexed by BLAST's (existence, extension) with a gap of k costing
+    // existence + k * extension, i.e. existence = open - extend for this scorer (main.cpp:297-303).  tests/test_gumbel_mc.py
+    // shows the converted row is the one this scorer's scores actually follow.
+    if (!blast && have_table && !(getenv("S4G_EVALUE_CONVENTION") && *getenv("S4G_EVALUE_CONVENTION"))) {
+        int other = -1;
+        for (int i = 1; i < tab->n; ++i)
+            if (tab->rows[i].open == scorerGetGapOpen(scorer) - extension && tab->rows[i].extension == extension) other = i;
+        if (other >= 0 && other != row) {
+            static std::mutex mu;
+            static std::set<std::string> said;
+            char key[96];
+            snprintf(key, sizeof key, "%s/%d/%d", tab->matrix, scorerGetGapOpen(scorer), extension);
+            std::lock_guard<std::mutex> lk(mu);
+            if (said.insert(key).second) {
+                const GumbelRow& o = tab->rows[other];
+                // how far apart the two readings are where sift4g cuts (main.cpp:75: --evalue 1e-4 by default): the score S at
+                // which this row says E = 1e-4 for a 350 x 350 pair in this database, and what the other row says there
+                const double mn = 350.0 * 350.0 * ((double)p->length / 350.0);
+                const double S = (log(g.K * mn) - log(1e-4)) / g.lambda;
+                const double e_other = o.K * mn * exp(-o.lambda * S);
+                fprintf(stderr, "[NOTE]: e-values for gap penalties %d/%d with matrix '%s' use the published row %d/%d%s (lambda %.3f, K %.3f): the "
+                                "penalties are looked up as they are (the 'swsharp' convention, the default).  Read as BLAST's existence/extension "
+                                "(existence = open - extend) they select row %d/%d (lambda %.3f, K %.3f), under which a hit this row gives E = 1e-04 "
+                                "has E ~ %.0e; set S4G_EVALUE_CONVENTION=blast for that reading, =swsharp to keep this one without this note "
+                                "(INTEGRATION.md section 5).\n",
+                        scorerGetGapOpen(scorer), extension, tab->matrix, g.open, g.extension, p->gapped_row_found ? "" : " (no row for them: the matrix's default)",
+                        g.lambda, g.K, o.open, o.extension, o.lambda, o.K, e_other);
+            }
+        }
+    }
     if (getenv("S4G_PROFILE"))      // which published row this scorer's statistics come from (the lookup convention is a switch, see above)
         fprintf(stderr, "[s4g profile] e-value statistics: matrix %s, gap penalties %d/%d looked up %s (%s convention) -> row %d/%d%s: lambda %.4f K %.4f H %.3f alpha %.2f\n",
                 tab->matrix, scorerGetGapOpen(scorer), extension, blast ? "as existence = open - extend" : "as they are", blast ? "blast" : "swsharp",

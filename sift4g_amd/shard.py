@@ -73,9 +73,27 @@ class Comm:
         out_ids = torch.empty((n_queries, k_out), dtype=torch.int32, device=dev)
         out_sc = torch.empty((n_queries, k_out), dtype=torch.int32, device=dev)
         out_cnt = torch.empty((n_queries,), dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream(dev)
         if stream is None:
-            stream = torch.cuda.current_stream(dev)
+            stream = cur
+        if counts is None:                       # legal on the torch path: a list's length is its number of used slots
+            counts = (ids >= 0).sum(dim=1).to(torch.int32)
+        for name, t in (("ids", ids), ("scores", scores), ("counts", counts), ("id_map", id_map)):
+            if t is None:
+                continue
+            if not t.is_cuda or t.device.index != self.device:
+                raise ValueError(f"{name} must be a tensor on cuda:{self.device} (got {t.device}); CPU tensors go through gather_db_shards / "
+                                 "gather_query_shards of sift4g_amd.shard, which merge on the host")
+            if t.dtype != torch.int32:
+                raise ValueError(f"{name} must be int32 (got {t.dtype})")
         ids, scores, counts = ids.contiguous(), scores.contiguous(), counts.contiguous()
+        if stream != cur:
+            # inputs (and the temporaries above) were produced on the current stream and are read by kernels on `stream`:
+            # order the two, and keep the caching allocator from recycling the blocks while `stream` still reads them
+            stream.wait_stream(cur)
+            for t in (ids, scores, counts, id_map, out_ids, out_sc, out_cnt):
+                if t is not None:
+                    t.record_stream(stream)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else None)
         check(lib.s4g_gather_topk(self._h, mode, n_queries, k, ptr(ids), ptr(scores), ptr(counts), int(id_base), ptr(id_map), k_out,
                                   ptr(out_ids), ptr(out_sc), ptr(out_cnt), ctypes.c_void_p(stream.cuda_stream)), "s4g_gather_topk")
@@ -109,6 +127,14 @@ def merge_topk_lists(ids, scores, k):
     lists, q, m = ids.shape
     i_np = np.ascontiguousarray(ids.numpy().astype(np.int32)).view(np.uint32)
     s_np = np.ascontiguousarray(scores.numpy().astype(np.int32))
+    if m > 1:
+        # the merge ranks by counting and trusts the order of every row: refuse rows that are not in it instead of returning a wrong list
+        # (key = score descending, then id ascending; unused slots -- id -1 -- sort last)
+        key = (s_np.astype(np.int64) << 32) | (0xFFFFFFFF - i_np.astype(np.int64))
+        key[i_np == 0xFFFFFFFF] = -(1 << 62)
+        if not (key[..., :-1] >= key[..., 1:]).all():
+            raise ValueError("merge_topk_lists: a row is not ordered by (score descending, id ascending) with its unused slots at the end; "
+                             "lists in another order (the prefilter's are in id order) must be merged with gather_db_shards(..., ordered=False) / merge_topk")
     o_ids = np.empty((q, k), dtype=np.uint32)
     o_sc = np.empty((q, k), dtype=np.int32)
     o_cnt = np.empty((q,), dtype=np.uint32)

@@ -99,6 +99,20 @@ def test_the_cpu_stand_in_cannot_be_loaded_as_the_product_library():
     assert not hasattr(raw, "s4g_is_shim")
 
 
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """with no librccl to open, s4g_comm_unique_id must return S4G_ERR_NO_DEVICE with the loader's message --
+    round 4 asked dlerror() twice, got NULL the second time and built a std::string from it (SIGSEGV inside call_once).
+    S4G_RCCL_LIBRARY points the loader at a file that does not exist; a child process, since the loader state is per process."""
+    import subprocess, sys
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.s4g_last_error.restype = ctypes.c_char_p; "
+            "buf = (ctypes.c_uint8 * 128)(); rc = L.s4g_comm_unique_id(buf); print(rc, L.s4g_last_error().decode())")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "sift4g_amd", "lib", "libs4g_hip.so")], capture_output=True, text=True,
+                       timeout=120, env=dict(os.environ, S4G_RCCL_LIBRARY="/nonexistent/librccl.so.1"))
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == -1 and "RCCL is not available" in msg and "/nonexistent/librccl.so.1" in msg, r.stdout
+
+
 def test_libswsharp_exports_only_its_c_api():
     """the host library exports the swsharp-compatible C API (version script libswsharp.map) and no C++ runtime instantiations
     (round 1 leaked std::thread state objects and vector bases into the dynamic symbol table)."""

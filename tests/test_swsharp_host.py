@@ -409,6 +409,43 @@ def test_evalue_row_convention_and_missing_rows(capfd):
     L.chainDelete(q); L.chainDelete(t)
 
 
+def test_evalue_convention_note_on_stderr():
+    """when the default ('swsharp') lookup and the 'blast' lookup would pick DIFFERENT published rows and nobody set
+    S4G_EVALUE_CONVENTION, createEValueParams says so once per (matrix, penalties) on stderr -- both rows, the factor at E = 1e-4, the
+    switch -- without S4G_PROFILE.  Run in a child process: the note is once per process."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(%r, "tests"))
+import swsharp_ctypes as sw
+from swsharp_ctypes import L
+def make(go, ge, name="BLOSUM_62"):
+    s = sw.scorer(go, ge, name); p = L.createEValueParams(34548336, s); L.deleteEValueParams(p); L.scorerDelete(s)
+step = sys.argv[1]
+if step == "default":
+    make(10, 1); sys.stderr.write("--second--\n"); sys.stderr.flush(); make(10, 1); make(11, 2); make(6, 2)
+else:
+    make(10, 1)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("S4G_EVALUE_CONVENTION", "S4G_PROFILE")}
+    r = subprocess.run([sys.executable, "-c", code, "default"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    first, second = r.stderr.split("--second--")
+    note = [l for l in first.splitlines() if l.startswith("[NOTE]")]
+    assert len(note) == 1, first
+    assert "10/1" in note[0] and "9/1" in note[0] and "BLOSUM_62" in note[0] and "S4G_EVALUE_CONVENTION=blast" in note[0]
+    assert "lambda 0.243" in note[0] and "lambda 0.206" in note[0]
+    factor = float(note[0].split("has E ~ ")[1].split(";")[0])
+    assert 1e-3 < factor < 1e-2                      # one to two orders above the 1e-4 the default row reports (DESIGN.md 3 item 9)
+    # second call with the same penalties: silent; 11/2 -> the other reading is 9/2 (a row): its own note; 6/2 -> 4/2 is no row: silent
+    lines = [l for l in second.splitlines() if l.startswith("[NOTE]")]
+    assert len(lines) == 1 and "11/2" in lines[0] and "9/2" in lines[0], second
+    for conv in ("swsharp", "blast"):               # somebody chose: no note
+        r = subprocess.run([sys.executable, "-c", code, "chosen"], env=dict(env, S4G_EVALUE_CONVENTION=conv), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "[NOTE]" not in r.stderr, r.stderr[-1000:]
+
+
 def test_evalue_reaches_the_textbook_limit_for_long_sequences():
     """Far from the finite-size regime the corrected e-value must reduce to the classic Karlin-Altschul form E = K m n exp(-lambda S)
     (= m n 2^-S' with the bit score S' = (lambda S - ln K) / ln 2): both the library and the restatement, for query and target of

@@ -195,6 +195,17 @@ int main(int argc, char** argv) {
     if (rank >= 0) return run_rank(rank, ranks, id_file, mode, nq, nt, k);
 
     // ---- the parent: no GPU call in this process, ever ----
+    // ... which a profiler's preloaded library breaks: under `rocprofv3 -- build/gather_demo --ranks N` the tool initialises the GPU before
+    // main(), and the fork + execv below becomes an exec from a process that holds the GPU (refused on this pool: it takes the machine
+    // down).  Profile ONE rank directly instead:  rocprofv3 ... -- build/gather_demo --ranks N --rank r --id-file F  (start the others by hand).
+    {
+        const char* pre = getenv("LD_PRELOAD");
+        if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && (strstr(pre, "rocprofiler") || strstr(pre, "roctracer")))) {
+            fprintf(stderr, "gather_demo: a profiler library is preloaded; the launcher will not fork + exec rank processes under it.\n"
+                            "Profile one rank directly: -- %s --ranks %d --rank <r> --id-file <path> --mode %s\n", argv[0], ranks, mode.c_str());
+            return 2;
+        }
+    }
     char tmpl[] = "/tmp/s4g_gather_demo_XXXXXX";
     const int fd = mkstemp(tmpl);
     if (fd < 0) { perror("mkstemp"); return 3; }
