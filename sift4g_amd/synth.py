@@ -101,18 +101,35 @@ def mutate_batch(seed, src, identity, indel):
     return res, cnt.sum(axis=1)
 
 
+# The length tail of a real Swiss-Prot that SURVEY.md 8d's generator clips away at 3000 (database_alignment.cpp:36-47 streams
+# whatever the FASTA holds): the body's lognormal runs on unclipped, a thin second component fills the 2 000 .. 10 000 range
+# (0.3 % of the sequences, lognormal(7.6, 0.5): median 2 000), and a handful of giants are planted: just below and just above
+# the 12 288 residues beyond which s4g_db_create gives sequences a tile of their own, up to titin's 35 213.
+SWISSPROT_TAIL = dict(hi=36000, frac=0.003, mu=7.6, sigma=0.5,
+                      giants=(10200, 12288, 12289, 14507, 18141, 22152, 27118, 35213))
+
+
 def make_config(cfg=2, n_queries=1000, n_targets=100000, homologs_per_query=50, q_len=(300, 400),
-                t_len=dict(mu=5.68, sigma=0.55, lo=30, hi=3000)):
+                t_len=dict(mu=5.68, sigma=0.55, lo=30, hi=3000), tail=None):
     """Synthetic workload of BASELINE.json configs 2/3/5.
 
     cfg 2: 1k queries U[300,400] x 100k targets; cfg 3: same generator at 570k targets;
     cfg 5: long queries (pass q_len=(2000, 5000), n_queries=64).
+    tail: a dict like SWISSPROT_TAIL -- the same set with a realistic length tail instead of the clip at 3000 (the sequences
+    that are not in the tail keep the lengths and residues' seeds of the clipped set); `giants` lists the planted ids.
     Returns dict(q_codes, q_off, t_codes, t_off, planted) with planted = list of (query, target) ids.
     """
     seed = SEED_BASE + cfg
     ql = query_lengths(seed + 0x100, n_queries, *q_len)
     q_codes, q_off = random_set(seed + 0x200, ql)
+    giants = []
+    if tail:
+        t_len = dict(t_len, hi=tail["hi"])
     tl = target_lengths(seed + 0x300, n_targets, **t_len)
+    if tail:
+        pick = _uniform(seed + 0x700, n_targets) < tail["frac"]
+        heavy = target_lengths(seed + 0x800, n_targets, mu=tail["mu"], sigma=tail["sigma"], lo=t_len["lo"], hi=tail["hi"])
+        tl = np.where(pick, heavy, tl)
     planted = []
     n_h = min(homologs_per_query, n_targets // max(n_queries, 1)) if n_queries else 0
     hom = {}
@@ -130,10 +147,30 @@ def make_config(cfg=2, n_queries=1000, n_targets=100000, homologs_per_query=50, 
                 hom[t] = seqs[ends[h] - lens[h]:ends[h]]
                 tl[t] = lens[h]
                 planted.append((q, t))
+    if tail:
+        # the giants sit at fixed, spread-out ids, moved on past any id a planted homolog uses
+        step = max(1, n_targets // (len(tail["giants"]) + 1))
+        for k, length in enumerate(tail["giants"]):
+            t = min(n_targets - 1, (k + 1) * step)
+            while t in hom or t in giants:
+                t += 1
+            if t < n_targets:
+                tl[t] = length
+                giants.append(int(t))
     t_codes, t_off = random_set(seed + 0x600, tl)
     for t, seq in hom.items():
         t_codes[int(t_off[t]):int(t_off[t + 1])] = seq
-    return dict(q_codes=q_codes, q_off=q_off, t_codes=t_codes, t_off=t_off, planted=planted)
+    # a giant that is all noise would never be looked at: each carries a copy of one query somewhere inside it
+    for k, t in enumerate(giants):
+        if n_queries == 0:
+            break
+        q = (k * 37) % n_queries
+        src = q_codes[int(q_off[q]):int(q_off[q + 1])]
+        at = int(t_off[t]) + int(tl[t]) * (k + 1) // (len(giants) + 2)
+        if at + len(src) <= int(t_off[t + 1]):
+            t_codes[at:at + len(src)] = src
+            planted.append((q, t))
+    return dict(q_codes=q_codes, q_off=q_off, t_codes=t_codes, t_off=t_off, planted=planted, giants=giants)
 
 
 def device_database(n_targets, seed, device, mu=5.68, sigma=0.55, lo=30, hi=3000, chunk=1 << 28):

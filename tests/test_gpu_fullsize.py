@@ -108,6 +108,53 @@ def test_configs2_swissprot_scale_scan(s4g, oracle_mod):
     assert torch.equal(ids, sids) and torch.equal(sc, ssc) and torch.equal(cnt, scnt)
 
 
+def test_configs2_with_an_unclipped_length_tail(s4g, oracle_mod):
+    """configs[2]'s 570 000 targets WITHOUT SURVEY 8d's clip at 3000 (synth.SWISSPROT_TAIL: the lognormal
+    unclipped, 0.3 % of the sequences from a 2-10 k component, eight planted giants of 10 200 .. 35 213 residues, each holding a copy
+    of a query) -- what database_alignment.cpp:36-47 would stream out of a real Swiss-Prot.  256 queries (1.8e13 cells): the sequences
+    beyond 12 288 residues get a tile of their own, scored beside the main tile.  The oracle on every giant x 24 queries, on every
+    planted (query, giant) pair, on 300 pairs with targets of 3000 .. 10 000 residues and 2000 random ones; properties over the
+    whole matrix; the scan kernels alone (no_pairs) and the streaming top-400 agree with the default routing."""
+    from sift4g_amd import synth
+    from sift4g_amd import device as s4gd
+    cfg = synth.make_config(3, n_queries=256, n_targets=570000, tail=synth.SWISSPROT_TAIL)
+    lens = np.diff(cfg["t_off"].astype(np.int64))
+    giants = cfg["giants"]
+    assert len(giants) == 8 and int(lens.max()) == 35213 and int((lens > 12288).sum()) >= 6 and int((lens > 3000).sum()) > 200
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet(codes=cfg["q_codes"], offsets=cfg["q_off"])
+    assert len(db.tiles()) >= 2                                   # the long sequences sit in a tile of their own
+    scorer = s4g.Scorer("BLOSUM_62", 10, 1)
+    got = torch.empty((q.n, db.n), dtype=torch.int32, device="cuda:0")
+    s4g.scan(db, q, scorer, got)
+    st = s4gd.scan_stats(0)
+    _properties(got, q.lengths, db.lengths, cfg["planted"][::40])
+    rng = np.random.default_rng(47)
+    mid = np.nonzero((lens > 3000) & (lens <= 10000))[0]
+    pq = np.concatenate([np.repeat(np.arange(24), len(giants)), [a for a, b in cfg["planted"] if b in giants],
+                         rng.integers(0, q.n, 300), rng.integers(0, q.n, 2000)]).astype(np.uint32)
+    pt = np.concatenate([np.tile(giants, 24), [b for a, b in cfg["planted"] if b in giants],
+                         rng.choice(mid, 300), rng.integers(0, db.n, 2000)]).astype(np.uint32)
+    exp = oracle_mod.pairs_flat(cfg["q_codes"], cfg["q_off"], cfg["t_codes"], cfg["t_off"], pq, pt, oracle_mod.blosum62(), 10, 1,
+                                threads=os.cpu_count() or 8)
+    have = got[torch.from_numpy(pq.astype(np.int64)).cuda(), torch.from_numpy(pt.astype(np.int64)).cuda()].cpu().numpy()
+    assert np.array_equal(have, exp)
+    M = s4gd.matrix_by_name("BLOSUM_62")
+    for a, b in cfg["planted"]:
+        if b in giants:                                           # the copy of the query inside the giant scores the query's self-score
+            qc = cfg["q_codes"][int(cfg["q_off"][a]):int(cfg["q_off"][a + 1])]
+            assert int(got[a, b]) >= int(M[qc, qc].sum())
+    alone = torch.empty_like(got)
+    s4g.scan(db, q, scorer, alone, no_pairs=True)                 # every tile on the scan kernels
+    assert torch.equal(alone, got)
+    del alone
+    ids, sc, cnt = s4g.topk_device(db, got, 400, 1)
+    del got
+    sids, ssc, scnt = s4g.scan_topk(db, q, scorer, 400, 1)
+    assert torch.equal(ids, sids) and torch.equal(sc, ssc) and torch.equal(cnt, scnt)
+    assert st["tier_drift"] > 0, st
+
+
 def test_configs3_streaming_scan_of_one_gpus_share(s4g, oracle_mod):
     """BASELINE configs[3], one GPU's share: 20 M targets generated on the device (6.8e9 residues: every offset beyond 32 bits),
     packed where they lie, streaming scan + running top-400 for 16 queries (3.8e13 cells, 20 tiles).  A planted copy of every query
