@@ -85,36 +85,83 @@ def self_launch(args):
     sys.exit(0)
 
 
+def _cpu_topology():
+    """physical cores among the CPUs this process may run on (sysfs thread_siblings_list), or None"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        cores = set()
+        for c in cpus:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                cores.add(f.read().strip())
+        return len(cpus), len(cores)
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, n_threads, target_seconds=12.0):
     """The CPU port of the same recurrence timed on this host's cores on a bounded sample of the same workload
-    (kind "port": a restatement, NOT swsharp's own SSE code, which is an absent submodule).  Uses the AVX2
-    inter-sequence port (oracle/sw_simd.c, 16 targets per vector -- the class of code the reference's CPU scorer is) and
-    falls back to the scalar oracle on CPUs without AVX2."""
+    (kind "port": a restatement, NOT swsharp's own SSE code, which is an absent submodule).  Uses the AVX2 inter-sequence port
+    (oracle/sw_simd.c) in the precision ladder the reference's class of CPU scorer uses (swimd / OPAL): 32 targets
+    per register in unsigned 8-bit lanes, int16 for the pairs that reach the 8-bit saturation mark, scalar beyond int16; falls
+    back to the scalar oracle on CPUs without AVX2.  The thread count is swept first (a pod's CPU quota can make every hardware
+    thread the affinity mask shows slower than a fraction of them): `cores` = the count the reported figure was taken at."""
     import oracle
     M = oracle.blosum62()
     q_off, t_off = cfg["q_off"], cfg["t_off"]
     simd = oracle.simd_available()
-    scan = oracle.scan_simd_flat if simd else oracle.scan_flat
     nq = min(128 if simd else 16, len(q_off) - 1)
     qo = q_off[:nq + 1].copy()
     n_t = len(t_off) - 1
-    chunk = max(256, min(n_t, 64 * n_threads))
-    cells, dt, nt = 0.0, 0.0, 0
+
+    def run(scan, lo, hi, threads):
+        to = (t_off[lo:hi + 1] - t_off[lo]).copy()
+        tc = np.ascontiguousarray(cfg["t_codes"][int(t_off[lo]):int(t_off[hi])])
+        t0 = time.perf_counter()
+        r = scan(cfg["q_codes"], qo, tc, to, M, 10, 1, threads)
+        return time.perf_counter() - t0, float(qo[nq]) * float(to[-1]), r
+
+    if not simd:
+        scan = lambda *a: (oracle.scan_flat(*a), 0)
+        sweep, best_threads = {}, n_threads
+    else:
+        scan = oracle.scan_simd_ladder_flat
+        # thread sweep on a short sample each: all hardware threads, the physical cores, halves of that
+        topo = _cpu_topology()
+        counts = sorted({n_threads, topo[1] if topo else n_threads, max(1, n_threads // 2), max(1, n_threads // 4), max(1, n_threads // 8)}, reverse=True)
+        sweep = {}
+        m = min(n_t, 8192)
+        for c in counts:
+            dt, cells, _ = run(scan, 0, m, c)
+            sweep[c] = round(cells / dt / 1e9, 2)
+        best_threads = max(sweep, key=sweep.get)
+    chunk = max(256, min(n_t, 64 * best_threads))
+    cells, dt, nt, escalated = 0.0, 0.0, 0, 0
     while nt < n_t and dt < target_seconds:           # time-boxed: whole chunks of targets until ~target_seconds
         hi = min(n_t, nt + chunk)
-        to = (t_off[nt:hi + 1] - t_off[nt]).copy()
-        tc = cfg["t_codes"][int(t_off[nt]):int(t_off[hi])]
-        t0 = time.perf_counter()
-        scan(cfg["q_codes"], qo, np.ascontiguousarray(tc), to, M, 10, 1, n_threads)
-        dt += time.perf_counter() - t0
-        cells += float(qo[nq]) * float(to[-1])
+        d, c, r = run(scan, nt, hi, best_threads)
+        dt += d; cells += c; escalated += r[1]
         nt = hi
         chunk = min(chunk * 2, 1 << 18)
-    impl = ("AVX2 inter-sequence port (oracle/sw_simd.c, 16 int16 lanes, scalar recheck on saturation)" if simd
-            else "scalar C oracle (oracle/sw_oracle.c)")
-    return dict(value=round(cells / dt / 1e9, 3), unit="GCUPS", cores=n_threads, kind="port",
-                sample=f"first {nq} queries x first {nt} targets of the same workload, {cells:.3e} cells in {dt:.1f} s, "
-                       f"{impl}, {n_threads} pthreads")
+    out = dict(value=round(cells / dt / 1e9, 3), unit="GCUPS", cores=best_threads, kind="port")
+    if simd:
+        # what the tiers are worth on ONE thread, and the int16 tier alone (rounds 1-4's baseline) at the same thread count
+        m1 = min(n_t, 1024)
+        d8, c8, _ = run(scan, 0, m1, 1)
+        d16, c16, _ = run(oracle.scan_simd16_flat, 0, m1, 1)
+        m16 = min(n_t, 16 * best_threads * 8)
+        dA, cA, _ = run(oracle.scan_simd16_flat, 0, m16, best_threads)
+        topo = _cpu_topology()
+        out.update(per_thread_gcups=round(cells / dt / 1e9 / best_threads, 3),
+                   one_thread_gcups={"ladder_8bit_first": round(c8 / d8 / 1e9, 2), "int16_only": round(c16 / d16 / 1e9, 2)},
+                   int16_only_gcups=round(cA / dA / 1e9, 2),
+                   thread_sweep_gcups={str(k): v for k, v in sweep.items()},
+                   host=dict(hardware_threads=topo[0], physical_cores=topo[1], smt_siblings_used=bool(best_threads > topo[1])) if topo else None,
+                   tiers=dict(pairs=int(nq) * int(nt), escalated_to_int16=int(escalated)))
+    impl = ("AVX2 inter-sequence port (oracle/sw_simd.c): 32 unsigned 8-bit lanes first, int16 lanes for the pairs that reach the 8-bit saturation "
+            "mark, scalar beyond int16 (the swimd / OPAL ladder)" if simd else "scalar C oracle (oracle/sw_oracle.c)")
+    out["sample"] = (f"first {nq} queries x first {nt} targets of the same workload, {cells:.3e} cells in {dt:.1f} s, {impl}, "
+                     f"{best_threads} pthreads (best of the sweep over {sorted(sweep) if sweep else [best_threads]})")
+    return out
 
 
 def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):

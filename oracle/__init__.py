@@ -50,6 +50,10 @@ def lib():
         L.s4g_oracle_scan_simd.argtypes = [_u8p, _u64p, ctypes.c_uint32, _u8p, _u64p, ctypes.c_uint32,
                                            _i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p]
         L.s4g_oracle_scan_simd.restype = ctypes.c_int
+        L.s4g_oracle_scan_simd16.argtypes = L.s4g_oracle_scan_simd.argtypes
+        L.s4g_oracle_scan_simd16.restype = ctypes.c_int
+        L.s4g_oracle_scan_simd8.argtypes = list(L.s4g_oracle_scan_simd.argtypes) + [_u64p]
+        L.s4g_oracle_scan_simd8.restype = ctypes.c_int
         _f32p = ctypes.POINTER(ctypes.c_float)
         L.s4g_oracle_prefilter_create.argtypes = [_u8p, _u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         L.s4g_oracle_prefilter_create.restype = ctypes.c_void_p
@@ -125,13 +129,35 @@ def simd_available():
 
 
 def scan_simd_flat(qcodes, qoff, tcodes, toff, M, gap_open=10, gap_extend=1, threads=1):
-    """AVX2 inter-sequence port (oracle/sw_simd.c): the timed CPU baseline.  Returns None without AVX2."""
+    """AVX2 inter-sequence port (oracle/sw_simd.c), the whole precision ladder (8-bit lanes, int16 for what reached the 8-bit
+    saturation mark, scalar beyond int16): the timed CPU baseline.  Returns None without AVX2."""
     nq, nt = len(qoff) - 1, len(toff) - 1
     out = np.zeros((nq, nt), dtype=np.int32)
     M = np.ascontiguousarray(M, dtype=np.int32)
     rc = lib().s4g_oracle_scan_simd(_p(qcodes, _u8p), _p(qoff, _u64p), nq, _p(tcodes, _u8p), _p(toff, _u64p), nt,
                                     _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p))
     return out if rc == 0 else None
+
+
+def scan_simd16_flat(qcodes, qoff, tcodes, toff, M, gap_open=10, gap_extend=1, threads=1):
+    """the int16 tier of the AVX2 port alone (16 targets per register; rounds 1-4's baseline).  Returns None without AVX2."""
+    nq, nt = len(qoff) - 1, len(toff) - 1
+    out = np.zeros((nq, nt), dtype=np.int32)
+    M = np.ascontiguousarray(M, dtype=np.int32)
+    rc = lib().s4g_oracle_scan_simd16(_p(qcodes, _u8p), _p(qoff, _u64p), nq, _p(tcodes, _u8p), _p(toff, _u64p), nt,
+                                      _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p))
+    return out if rc == 0 else None
+
+
+def scan_simd_ladder_flat(qcodes, qoff, tcodes, toff, M, gap_open=10, gap_extend=1, threads=1):
+    """the AVX2 port's precision ladder (8-bit lanes -> int16 -> scalar) -> (scores, pairs the 8-bit tier escalated) or None"""
+    nq, nt = len(qoff) - 1, len(toff) - 1
+    out = np.zeros((nq, nt), dtype=np.int32)
+    esc = np.zeros(1, dtype=np.uint64)
+    M = np.ascontiguousarray(M, dtype=np.int32)
+    rc = lib().s4g_oracle_scan_simd8(_p(qcodes, _u8p), _p(qoff, _u64p), nq, _p(tcodes, _u8p), _p(toff, _u64p), nt,
+                                     _p(M, _i32p), gap_open, gap_extend, threads, _p(out, _i32p), _p(esc, _u64p))
+    return (out, int(esc[0])) if rc == 0 else None
 
 
 def scan(queries, targets, M, gap_open=10, gap_extend=1, threads=1):

@@ -114,15 +114,14 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     const uint64_t bias = (uint64_t)std::max(std::max(-kPadScore, -scorer->min_score), std::max(scorer->open, 2 * scorer->ext));
 
     // ---- which pairs may go to the list kernel at all: the drifting-frame window per query (as make_plan's drift tier) ----
-    // bound + bias + (rows + columns) * ext <= 0x7BFF with rows = lq + 2R, columns = 4 * len4 + 8
+    // bound + bias + columns * ext <= 0x7BFF with columns = 4 * len4 + 8 (sw_scan_lists runs the column frame of sw_scan_pkc)
     std::vector<uint32_t> lt_cap(q->n, 0);              // longest target query i may meet in the list kernel (0: none)
     for (uint32_t i = 0; i < q->n; ++i) {
         const uint64_t fixed = q->score_bound[i] + bias;
         if (fixed > cap) continue;
-        const uint64_t rows = (uint64_t)q->len[i] + 2 * kListRows + kListPairSlack;        // (an item runs to the longer of its two queries)
         uint64_t cols = scorer->ext ? (cap - fixed) / (uint64_t)scorer->ext : 0xFFFFFFFFull;
-        if (scorer->ext && cols < rows + 16) continue;
-        if (scorer->ext) cols -= rows + 12;              // 8 + rounding of the length to 4
+        if (scorer->ext && cols < 16) continue;
+        if (scorer->ext) cols -= 12;                     // 8 + rounding of the length to 4 (column frame: the rows do not count)
         lt_cap[i] = (uint32_t)std::min<uint64_t>(cols, 0x7FFFFFFFu);
     }
     // ---- the split length: histogram of cells over target length (one pass), estimate for every 64-residue cut ----
@@ -346,6 +345,11 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     }
 
     // ---- host: the item table ----
+    // (Round 5 measured the other way to cut items: every block of 64 candidates of every query of a length class in ONE order by the
+    // length of its longest member, neighbours sharing an item.  Against the true cells of the 729k-pair batch the rank-aligned items
+    // below compute +10.1 %, that form +9.2 %, and blocks of 64 consecutive ranks cannot do better than +8.5 % (the spread of 64 ranks
+    // of a length-sorted list, rows rounded to 8, columns to 4): the kernel got 0.3 % faster and the host 0.6 ms slower.  Dropped;
+    // EXPERIMENTS.md, round 5.)
     // Units: two queries of nearly the same length walk their lists in step, 64 candidates each per item; a query without such a
     // partner is a unit of its own (items of 128).  Items of block k of every unit come before block k + 1 of any: the longest
     // members of every list start first.
@@ -534,7 +538,8 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     for (uint32_t i = 0; i < q_count; ++i) {
         const uint32_t longer = order[i & ~1u];
         if (q->len[order[i]] == 0) return S4G_OK;
-        if (q->score_bound[order[i]] + bias + ((uint64_t)q->len[longer] + 2 * kListRows + cols) * (uint64_t)scorer->ext > cap) return S4G_OK;
+        (void)longer;
+        if (q->score_bound[order[i]] + bias + cols * (uint64_t)scorer->ext > cap) return S4G_OK;
     }
     const uint32_t n_pairs = (q_count + 1) / 2;
     const uint64_t n_items64 = (uint64_t)t.n_groups * n_pairs;

@@ -17,9 +17,10 @@
 //   * list_gather copies the 128 targets of every item out of the resident database into a lane-transposed block of
 //     their own (dword (c*2 + half)*64 + lane = columns 4c .. 4c+3), padded to the item's longest member -- the scan then
 //     reads 2 x 256 contiguous bytes per wave and 4 columns, exactly like a database group;
-//   * sw_scan_lists is sw_scan_pkd (drifting frame, v_pk_maximum3_f16 on integer bit patterns, same exactness window)
+//   * sw_scan_lists is sw_scan_pkc (round 5: the COLUMN frame X + B + j*e, v_pk_maximum3_f16 on integer bit patterns, same
+//     exactness window bound + B + columns * e <= 0x7BFF; rounds 2-4 ran sw_scan_pkd's anti-diagonal frame)
 //     with ONE difference: a lane looks its two residues up separately.  The strip profile is two tables of 32-bit words --
-//     PA[4-row block][residue][4 rows] = s + 2e (sign-extended) for the lower half, PB = (s + 2e) << 16 for the upper --
+//     PA[4-row block][residue][4 rows] = s + e (sign-extended) for the lower half, PB = (s + e) << 16 for the upper --
 //     and ONE v_add3_u32 per row adds both to the diagonal: on the register pair read as the integer hi * 65536 + lo that
 //     IS the packed add (no half leaves 0 .. 0xFFFF, a negative lower score borrows from the upper half exactly as the
 //     integer sum says).  6.5 vector ops per pair of cells, as the scan kernel (round 2 paired 16-bit scores with a
@@ -125,22 +126,20 @@ __global__ __launch_bounds__(256) void list_gather(const ListItem* __restrict__ 
     }
 }
 
-// rows row0 .. row0+3 of one column for both halves: xa = the 4 scores s + 2e of the lower half's residue, xb = those of the upper
-// half's residue << 16
+// rows row0 .. row0+3 of one column for both halves: xa = the 4 scores s + e of the lower half's residue, xb = those of the upper
+// half's residue << 16.  Column frame (sw_scan_pkc, round 5): the running maximum lives in the frame, F carries the "- e".
 template <int R>
 __device__ __forceinline__ void lst_rows4(int (&H)[R], int (&E)[R], int row0, const v4i& xa, const v4i& xb, int& diag, int& F, int& best,
-                                          int eo, int& zcur, int e2) {
-    int tprev = 0;
+                                          int eo, int e2v, int zn) {
+    int hprev = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + i;
         const int h = pk_maximum3((int)((unsigned)diag + (unsigned)xa[i] + (unsigned)xb[i]), E[r], F);       // v_add3_u32
-        const int t = as_i(as_s(h) - as_s(zcur));
-        if (i & 1) best = pk_maximum3(best, tprev, t); else tprev = t;
-        zcur += e2;
+        if (i & 1) best = pk_maximum3(best, hprev, h); else hprev = h;
         const int hm = (int)((unsigned)h + (unsigned)eo);               // eo: the pair (e - o, e - o) as an integer, in a VGPR
-        E[r] = pk_maximum3(E[r], hm, zcur);
-        F = as_i(pk_max(as_s(F), as_s(hm)));
+        E[r] = pk_maximum3(E[r], hm, zn);                               // zn = z_{j+1}: one SGPR per column
+        F = (int)((unsigned)as_i(pk_max(as_s(F), as_s(hm))) - (unsigned)e2v);
         diag = H[r];
         H[r] = h;
     }
@@ -188,7 +187,7 @@ __device__ __forceinline__ unsigned lds_load32(const unsigned* p) {
 // prod: progress word of the wave that owns the strip above (FIRST: unused), need_tag = that strip's tag; mine / my_tag: this wave's.
 template <int R, int RR, bool FIRST, bool SCAN>
 __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
-                                          bool last, int& best, int eo, int e2, int zrow0,
+                                          bool last, int& best, int eo, int e2v, int e2, int B2,
                                           const unsigned long long* prod, unsigned long long need_tag,
                                           unsigned long long* mine, unsigned long long my_tag) {
     constexpr bool first = FIRST;
@@ -197,9 +196,9 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
     int H[R];
     int E[R];
 #pragma unroll
-    for (int r = 0; r < RR; ++r) { H[r] = zrow0 + (r - 1) * e2; E[r] = zrow0 + r * e2; }
-    int zcol = zrow0;
-    int hdiag = zrow0 - 2 * e2;
+    for (int r = 0; r < RR; ++r) { H[r] = B2 - e2; E[r] = B2; }         // H~(i,-1) = z_{-1}, E~(i,0) = z_0: the same in every row
+    int zj = B2;                         // z_j of the current column (SGPR)
+    int hdiag = B2 - e2;
     unsigned avail = 0;                  // boundary chunks the strip above is known to have finished
     auto wait_for = [&](unsigned chunks) {
         if constexpr (!first) {
@@ -233,21 +232,21 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
             const unsigned ta_next = cc < 3 ? pk_taddr(ra, cc + 1) : pk_taddr(ra_n, 0);
             const unsigned tb_next = cc < 3 ? pk_taddr(rb, cc + 1) : pk_taddr(rb_n, 0);
             int diag = hdiag;
-            int F = first ? zcol : fb[cc];
-            int zcur = zcol;
-            const int e2c = e2;
+            int F = first ? zj : fb[cc];
+            const int zn = zj + e2;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const v4i xa = xa_n, xb = xb_n;
                 xa_n = xa_m; xb_n = xb_m;
                 if (b + 2 < NB) { xa_m = lst_load(prof, ta, b + 2); xb_m = lst_load(profb, tb, b + 2); }
                 else { xa_m = lst_load(prof, ta_next, b + 2 - NB); xb_m = lst_load(profb, tb_next, b + 2 - NB); }
-                lst_rows4<R>(H, E, 4 * b, xa, xb, diag, F, best, eo, zcur, e2c);
+                lst_rows4<R>(H, E, 4 * b, xa, xb, diag, F, best, eo, e2v, zn);
             }
-            hdiag = first ? zcol - e2 : hb[cc];
-            zcol += e2;
+            hdiag = first ? zj : hb[cc];
+            zj = zn;
             ho[cc] = H[RR - 1];
             fo[cc] = F;
+            best = (int)((unsigned)best + (unsigned)e2v);               // best~ moves to column j+1's frame (no speculative launches here: plain add)
             asm volatile("" : "+v"(best));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -287,9 +286,10 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     v4i* const ws_block = reinterpret_cast<v4i*>(a.ws + (uint64_t)blockIdx.x * kListBufs * a.ws_slot);
     const int e2 = (int)(a.ext | (a.ext << 16));
     int eo = ((int)a.ext - (int)a.open) * 65537;       // the pair (e - o, e - o) as the integer hi * 65536 + lo ...
-    asm volatile("" : "+v"(eo));                       // ... in a VGPR: the two-VGPR v_add_u32 issues a little faster (tools/valu_issue.hip)
+    int e2v = e2;
+    asm volatile("" : "+v"(eo), "+v"(e2v));            // ... in VGPRs: two-VGPR v_add_u32 / v_sub_u32 are the double-rate class (tools/valu_issue.hip)
     const int B2 = (int)a.floor_bits;
-    const int two_e = 2 * (int)a.ext;
+    const int one_e = (int)a.ext;
     const int prev_wave = (wave + W - 1) % W;
 
     // item k of this block's stream (fetched from the global queue by whichever wave needs it first); n == 0: end of the queue
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
 
         const unsigned rows_left = lq - s * R;
         const unsigned rr = rows_left >= (unsigned)R ? (unsigned)R : (rows_left + 7) / 8 * 8;
-        // ---- strip profile: PA[blk][t] = 4 rows of query A's (score + 2e), PB[blk][t] = query B's << 16 ----
+        // ---- strip profile: PA[blk][t] = 4 rows of query A's (score + e), PB[blk][t] = query B's << 16 ----
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int e0 = 0; e0 < 8 * R; e0 += 64) {
@@ -379,8 +379,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
             v4i lo, hi;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                lo[d] = lmat[((ca >> (8 * d)) & 31u) * 32 + t] + two_e;
-                hi[d] = (int)((unsigned)(lmat[((cb >> (8 * d)) & 31u) * 32 + t] + two_e) << 16);
+                lo[d] = lmat[((ca >> (8 * d)) & 31u) * 32 + t] + one_e;
+                hi[d] = (int)((unsigned)(lmat[((cb >> (8 * d)) & 31u) * 32 + t] + one_e) << 16);
             }
             *reinterpret_cast<v4i*>(prof + e * 16) = lo;
             *reinterpret_cast<v4i*>(prof + R * 128 + e * 16) = hi;
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         const bool first = (s == 0), last = (s + 1 == nstrips);
-        const int zrow0 = B2 + (int)(s * R) * e2;
-        int best = 0;
+        const int zend = B2 + (int)(len4 * 4u) * e2;     // z of the column after the last: where the in-frame maximum stands at the strip's end
+        int best = B2;                                   // in-frame running maximum of THIS strip (true 0)
         const unsigned long long* prod = &sy.prog[prev_wave];
         unsigned long long* mine = &sy.prog[wave];
         const unsigned long long need_tag = (unsigned long long)g;            // tag of strip g - 1
@@ -397,17 +397,18 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
 #define S4G_LAST_STRIP(RR_)                                                                                  \
         if constexpr (R > RR_) {                                                                             \
             if (!done && rr == RR_) {                                                                        \
-                if (first) lst_strip<R, RR_, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag); \
-                else lst_strip<R, RR_, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);    \
+                if (first) lst_strip<R, RR_, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag); \
+                else lst_strip<R, RR_, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);    \
                 done = true;                                                                                 \
             }                                                                                                \
         }
         S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
 #undef S4G_LAST_STRIP
         if (!done) {
-            if (first) lst_strip<R, R, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
-            else lst_strip<R, R, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2, zrow0, prod, need_tag, mine, my_tag);
+            if (first) lst_strip<R, R, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
+            else lst_strip<R, R, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
         }
+        best = (int)((unsigned)best - (unsigned)zend);   // the true maximum of the strip (no borrow: best~ >= z in both halves)
         // merge this strip's maximum into the item's, THEN publish the strip as finished: the wave that ends the item's last strip
         // has seen every strip above finished (each waited for its predecessor's last chunk), so the row is complete for it
         if (!(first && last)) {

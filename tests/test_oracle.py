@@ -229,9 +229,42 @@ def test_simd_port_equals_scalar_oracle(oracle_mod, blosum62):
     qc, qo = _flat(qs); tc, to = _flat(ts)
     for go, ge in ((10, 1), (5, 5), (14, 0)):
         a = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, go, ge, threads=4)
-        b = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, go, ge, threads=3)
+        b = oracle_mod.scan_simd_flat(qc, qo, tc, to, blosum62, go, ge, threads=3)          # the ladder: 8-bit -> int16 -> scalar
         assert np.array_equal(a, b), (go, ge, np.argwhere(a != b)[:5])
+        c = oracle_mod.scan_simd16_flat(qc, qo, tc, to, blosum62, go, ge, threads=3)        # the int16 tier alone
+        assert np.array_equal(a, c), (go, ge, np.argwhere(a != c)[:5])
     assert a[7, 83] == 3100 * 11          # > 32767: went through the scalar recheck
+
+
+def test_simd_8bit_tier_and_its_escalation(oracle_mod, blosum62):
+    """the AVX2 port's 8-bit tier (32 unsigned lanes, scores biased by -min score, the swimd / OPAL scheme).
+    A lane is exact while its maximum stays below 255 - bias and is recomputed in int16 otherwise: poly-W runs whose scores sit
+    on both sides of that mark (BLOSUM62: bias 4, mark 251 = 22.8 W), planted homologs far beyond it, a target count that is not
+    a multiple of 32, every built-in matrix (PAM_30: bias 17), and penalties a byte cannot hold (the tier steps aside)."""
+    if not oracle_mod.simd_available():
+        pytest.skip("no AVX2 on this CPU")
+    from oracle import _flat
+    from sift4g_amd.device import matrix_by_name
+    rng = np.random.default_rng(52)
+    W = ord("W") - 65
+    qs = rand_seqs(rng, 6, 1, 260, 26) + [np.full(n, W, dtype=np.uint8) for n in (22, 23, 24, 60)]
+    ts = rand_seqs(rng, 77, 0, 330, 26) + [np.full(n, W, dtype=np.uint8) for n in (22, 23, 40)] + [qs[0].copy(), qs[1][3:].copy()]
+    qc, qo = _flat(qs); tc, to = _flat(ts)
+    exp = oracle_mod.scan_flat(qc, qo, tc, to, blosum62, 10, 1, threads=4)
+    got, esc = oracle_mod.scan_simd_ladder_flat(qc, qo, tc, to, blosum62, 10, 1, threads=3)
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
+    assert exp[6, 77] == 242 and exp[7, 78] == 253 and exp[8, 79] == 264          # 22 / 23 / 24 W: below, above, above the mark
+    assert esc == int((exp >= 251).sum()) and esc >= 5                              # exactly the pairs at or beyond the mark escalate
+    for name, go, ge in (("BLOSUM_45", 14, 2), ("BLOSUM_80", 10, 1), ("PAM_30", 9, 1), ("PAM_250", 14, 2), ("BLOSUM_50", 3, 3),
+                         ("BLOSUM_90", 12, 0), ("PAM_70", 1, 1), ("BLOSUM_62", 127, 127), ("BLOSUM_62", 128, 1), ("BLOSUM_62", 300, 200)):
+        M = matrix_by_name(name)
+        exp = oracle_mod.scan_flat(qc, qo, tc, to, M, go, ge, threads=4)
+        got, esc = oracle_mod.scan_simd_ladder_flat(qc, qo, tc, to, M, go, ge, threads=3)
+        assert np.array_equal(got, exp), (name, go, ge, np.argwhere(got != exp)[:5])
+        if go > 127:
+            assert esc == 0                                                          # the 8-bit tier stepped aside: int16 for everything
+        else:
+            assert esc == int((exp >= 255 + int(M.min())).sum()), (name, go, ge)
 
 
 # ---- the k-mer prefilter (SURVEY.md 8f-3): oracle/kmer_prefilter.c against what the reference's own code printed ----
