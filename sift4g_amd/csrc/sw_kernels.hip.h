@@ -86,6 +86,7 @@ __device__ __forceinline__ unsigned umax_s(unsigned a, unsigned b) {  // both < 
 }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
 // One DP column of an R-row strip.  H[r] holds H(row r, previous column) on
 // entry and H(row r, this column) on exit; E[r] holds E(row r, this column)
@@ -976,16 +977,30 @@ __device__ __forceinline__ void pkc_rows8(int (&H)[R], int (&E)[R], int row0, co
 }
 
 template <int R, int RR, bool FIRST>
-__device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+__device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, const char* prof, v4i* ws, int lane,
                                           bool last, int& best, int eo, int e2v, int e2, int B2) {
     constexpr bool first = FIRST;
     constexpr int NB = RR / 8;
-    // res_u, wsH, wsF are UNIFORM bases; a lane adds its own 32-bit byte offset, so every access is "SGPR base + VGPR offset" and the
-    // chunk's address arithmetic runs on the scalar unit (sw_scan_pkd spends five 64-bit vector adds per chunk on it)
-    const unsigned lane4 = (unsigned)lane * 4u, lane16 = (unsigned)lane * 16u;
-    auto ld_res = [&](unsigned c) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(res_u + (uint64_t)c * 64) + lane4); };
-    auto ld_ws = [&](const v4i* w, unsigned c) { return *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(w + (uint64_t)c * 64) + lane16); };
-    auto st_ws = [&](v4i* w, unsigned c, v4i v) { *reinterpret_cast<v4i*>(reinterpret_cast<char*>(w + (uint64_t)c * 64) + lane16) = v; };
+    // res_u and ws are UNIFORM bases: every access is a buffer instruction -- descriptor and chunk offset in SGPRs, the lane's own
+    // 32-bit byte offset the only VGPR -- so the chunk's address arithmetic runs on the scalar unit (sw_scan_pkd spends five 64-bit
+    // vector adds per chunk on it).
+    // Strip-boundary workspace of this kernel: dword [chunk c][H | F][column cc][lane] -- one 256-byte line per (chunk, row kind,
+    // column).  A boundary value is loaded for the NEXT chunk into the register it was just read from, and stored as soon as its
+    // column is done: no second set of registers for a chunk in flight and no copies between the sets (sw_scan_pkd moves 16-byte
+    // vectors per lane and pays six v_mov per chunk for the hand-over), and the loads still lead their use by four columns.
+    const unsigned lane4 = (unsigned)lane * 4u;
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_u), 0, (int)(len4 * 256u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ws = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(len4 * 2048u), 0x00020000);
+    auto ld_res = [&](unsigned c) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_res, (int)lane4, (int)(c * 256u), 0); };
+    auto ld_ws = [&](bool f, unsigned c, int cc) {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(r_ws, (int)lane4, (int)(c * 2048u + (f ? 1024u : 0u) + (unsigned)cc * 256u), 0);
+    };
+    // (the last strip hands no boundary row on: its stores go through a descriptor of zero records, which the hardware drops --
+    // no branch in the column loop)
+    const __amdgpu_buffer_rsrc_t r_wst = __builtin_amdgcn_make_buffer_rsrc(ws, 0, last ? 0 : (int)(len4 * 2048u), 0x00020000);
+    auto st_ws = [&](bool f, unsigned c, int cc, int v) {
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r_wst, (int)lane4, (int)(c * 2048u + (f ? 1024u : 0u) + (unsigned)cc * 256u), 0);
+    };
     int H[R];
     int E[R];
 #pragma unroll
@@ -993,23 +1008,25 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
     int zj = B2;                            // z_j of the current column (SGPR)
     int hdiag = B2 - e2;                    // H~(i0-1, -1)
     uint32_t res_n = ld_res(0);
-    v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
-    if (!first && len4) { hb_n = ld_ws(wsH, 0); fb_n = ld_ws(wsF, 0); }
+    int hbv[4] = {0, 0, 0, 0}, fbv[4] = {0, 0, 0, 0};
+    if (!first && len4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { if (cc < 3) hbv[cc] = ld_ws(false, 0, cc); fbv[cc] = ld_ws(true, 0, cc); }   // (hbv[3]: after column 0, below)
+    }
     v4i sc_n[2];
-    pk_load8(sc_n, prof, pkc_taddr(res_n, 0), 0);
+    unsigned taddr_first = pkc_taddr(res_n, 0);
+    pk_load8(sc_n, prof, taddr_first, 0);
     for (unsigned c = 0; c < len4; ++c) {
         const uint32_t r4 = res_n;
-        const v4i hb = hb_n, fb = fb_n;
         const unsigned cn = (c + 1 < len4) ? c + 1 : c;
         res_n = ld_res(cn);
-        if (!first) { hb_n = ld_ws(wsH, cn); fb_n = ld_ws(wsF, cn); }
-        v4i ho, fo;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const unsigned taddr = pkc_taddr(r4, cc);
+            const unsigned taddr = cc == 0 ? taddr_first : pkc_taddr(r4, cc);
             const unsigned taddr_next = cc < 3 ? pkc_taddr(r4, cc + 1) : pkc_taddr(res_n, 0);
+            if (cc == 3) taddr_first = taddr_next;
             int diag = hdiag;
-            int F = first ? zj : fb[cc];             // first strip: F~(0,j) = z_j (F = 0)
+            int F = first ? zj : fbv[cc];            // first strip: F~(0,j) = z_j (F = 0)
             const int zn = zj + e2;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -1017,15 +1034,21 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
                 if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
                 pkc_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, e2v, zn);
             }
-            hdiag = first ? zj : hb[cc];             // first strip: H~(-1, j) = z_j (H = 0)
+            hdiag = first ? zj : hbv[cc];            // first strip: H~(-1, j) = z_j (H = 0)
             zj = zn;
-            ho[cc] = H[RR - 1];
-            fo[cc] = F;
+            st_ws(false, c, cc, H[RR - 1]); st_ws(true, c, cc, F);
+            if (!first) {
+                // reload what has been consumed, into the registers it was consumed from: F of this column (its chain is over) for the
+                // next chunk, and H of the column BEFORE (its value went into the first row of this one; for column 0 that is column 3
+                // of the chunk before, whose successor is this chunk's).  Three columns of lead.
+                fbv[cc] = ld_ws(true, cn, cc);
+                const int pc = (cc + 3) & 3;
+                hbv[pc] = ld_ws(false, cc == 0 ? c : cn, pc);
+            }
             best = as_i(__builtin_elementwise_add_sat(as_s(best), as_s(e2)));   // best~ moves to column j+1's frame; saturating: see "speculative launches" above
             asm volatile("" : "+v"(best));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!last) { st_ws(wsH, c, ho); st_ws(wsF, c, fo); }
     }
 }
 
@@ -1062,7 +1085,10 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
         const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
         const bool hasB = qB != 0xFFFFFFFFu;
         const unsigned len4 = a.grp_len4[g];
-        const uint32_t* res = a.db_res + a.grp_off[g];       // uniform; pkc_strip adds the lane
+        // (uniform, and told so: the buffer descriptor pkc_strip makes of it must sit in SGPRs, not behind a waterfall loop)
+        const uint64_t res_bits = reinterpret_cast<uint64_t>(a.db_res + a.grp_off[g]);
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(res_bits >> 32)) << 32) |
+                                                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)res_bits));
         const uint8_t* qcA = a.q_codes + a.q_off[qA];
         const uint8_t* qcB = a.q_codes + a.q_off[hasB ? qB : qA];
         const unsigned lA = a.q_len[qA], lB = hasB ? a.q_len[qB] : 0u;
@@ -1070,7 +1096,6 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
         const unsigned capB = hasB ? (lB + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign : 0u;
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
-        v4i* wsF = wsH + (uint64_t)len4 * 64;
         if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);   // see sw_scan_pk
         const int zend = B2 + (int)(len4 * 4u) * e2;                   // z of the column after the last: where best~ stands when a strip ends
         int best = 0;                                                   // true running maximum (both halves), between strips
@@ -1105,16 +1130,16 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
 #define S4G_LAST_STRIP(RR_)                                                                                  \
             if constexpr (R > RR_) {                                                                         \
                 if (!done && rr == RR_) {                                                                    \
-                    if (first) pkc_strip<R, RR_, true>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2); \
-                    else pkc_strip<R, RR_, false>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);    \
+                    if (first) pkc_strip<R, RR_, true>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2); \
+                    else pkc_strip<R, RR_, false>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);    \
                     done = true;                                                                             \
                 }                                                                                            \
             }
             S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
 #undef S4G_LAST_STRIP
             if (!done) {
-                if (first) pkc_strip<R, R, true>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);
-                else pkc_strip<R, R, false>(res, len4, prof, wsH, wsF, lane, last, bf, eo, e2v, e2, B2);
+                if (first) pkc_strip<R, R, true>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
+                else pkc_strip<R, R, false>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
             }
             ovf = as_i(__builtin_elementwise_max(as_u(ovf), as_u(bf)));
             best = (int)((unsigned)bf - (unsigned)zend);                // back to the true maximum (no borrow: bf >= zend in both halves)
