@@ -129,8 +129,8 @@ def cpu_baseline(cfg, n_threads, target_seconds=12.0):
         topo = _cpu_topology()
         counts = sorted({n_threads, topo[1] if topo else n_threads, max(1, n_threads // 2), max(1, n_threads // 4), max(1, n_threads // 8)}, reverse=True)
         sweep = {}
-        m = min(n_t, 8192)
         for c in counts:
+            m = min(n_t, max(8192, 256 * c))      # >= 8 batches of 32 targets per thread: the queue balances unequal batches
             dt, cells, _ = run(scan, 0, m, c)
             sweep[c] = round(cells / dt / 1e9, 2)
         best_threads = max(sweep, key=sweep.get)

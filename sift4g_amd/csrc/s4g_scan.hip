@@ -135,19 +135,18 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     const bool no_m3 = (flags & (S4G_SCAN_FORCE_I32 | S4G_SCAN_NO_F16)) != 0;
     const bool no_drift = no_m3 || p->f16_arith || (flags & S4G_SCAN_NO_DRIFT) != 0;
     const bool no_spec = (flags & S4G_SCAN_NO_SPEC) != 0;
-    // int32 tier in the drifting frame (a column frame since round 5): s + e must fit the int8 profile; the frame itself, columns * ext, and the scores
+    // int32 tier in the drifting frame: s + 2e must fit the int8 profile; the frame itself (rows + columns) * ext and the scores
     // are far inside int32 for anything a database holds (S4G_SCAN_NO_DRIFT selects the fixed-frame kernel, as for the packed tier)
-    p->wide_drift = !(flags & S4G_SCAN_NO_DRIFT) && std::max(0, sc->max_score) + sc->ext <= 127 && sc->ext <= 4096 && sc->open <= (1 << 20);
+    p->wide_drift = !(flags & S4G_SCAN_NO_DRIFT) && std::max(0, sc->max_score) + 2 * sc->ext <= 127 && sc->ext <= 4096 && sc->open <= (1 << 20);
     const uint64_t step = (uint64_t)std::max(0, sc->max_score) + 2 * (uint64_t)sc->ext;      // the most one cell adds to a stored value
     if (p->wide_drift) {
-        // ... and every stored value, score + columns * ext, must stay inside int32 for the longest query against the longest
+        // ... and every stored value, score + (rows + columns) * ext, must stay inside int32 for the longest query against the longest
         // tile of THIS call (half a million residues at ext = 4096): otherwise the fixed-frame kernel
         uint64_t max_cols = 0, max_bound = 0;
         for (const Tile& t : db->tiles) max_cols = std::max<uint64_t>(max_cols, (uint64_t)t.max_len4 * 4 + 8);
         uint32_t max_rows = 0;
         for (uint32_t i = 0; i < q_count; ++i) { max_bound = std::max<uint64_t>(max_bound, q->score_bound[q_begin + i]); max_rows = std::max(max_rows, q->len[q_begin + i]); }
-        (void)max_rows;
-        if (max_cols * (uint64_t)sc->ext + max_bound + step >= (1ull << 31)) p->wide_drift = false;
+        if (((uint64_t)max_rows + 2 * kStripRows + max_cols) * (uint64_t)sc->ext + max_bound + step >= (1ull << 31)) p->wide_drift = false;
     }
     p->spec_base = (uint32_t)(cap > p->bias + step ? cap - p->bias - step : 0);
     // column frame: a cell adds at most max score + ext to a stored value, the running maximum ext per column; the kernel compares

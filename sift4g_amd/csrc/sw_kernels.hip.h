@@ -226,28 +226,33 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
 
 
 // =====================================================================================================
-// sw_scan_i32d: the int32 kernel in a DRIFTING FRAME.  Round 5: the COLUMN frame of sw_scan_pkc (see there for the algebra; rounds
-// 2-4 used sw_scan_pkd's anti-diagonal frame): every stored value carries j * ext, z_j = j * ext,
-//     H~ = max3(diag~ + (s + e), E~, F~);   E~' = max3(E~, H~ + (e - o), z_{j+1});   F~' = max(F~, H~ + (e - o)) - e;
-//     best~ = max3(best~, H~(i), H~(i+1))  [two rows per instruction, in the frame];   best~ += e once per column
-// = 6.5 vector ops per cell against sw_scan_i32's 7.5, two of them (H~ + (e - o), F~ - e) two-VGPR adds of the double-rate class
-// -- the anti-diagonal frame had one, its per-row "true H = H~ - z(i,j)" being a subtract with an SGPR operand -- and no per-row
-// frame constants.  int32 has room for any frame (no bias, no window, no tiers): exact for every scorer whose shifted scores
-// s + e still fit the int8 strip profile (max score + ext <= 127); the host falls back to sw_scan_i32 otherwise.
+// sw_scan_i32d: the int32 kernel in a DRIFTING FRAME (see sw_scan_pkd below for the algebra): every stored value carries
+// (i + j) * ext, which removes the two saturating "- ext" of the gap recurrences and lets them share one add:
+//     H~ = max3(diag~ + (s + 2e), E~, F~);   E~' = max3(E~, H~ + (e - o), z');   F~' = max(F~, H~ + (e - o));
+//     best = max3(best, H~ - z  [two rows per instruction])
+// = 6.5 vector ops per cell against sw_scan_i32's 7.5.  int32 has room for any frame (no bias, no window, no tiers): exact
+// for every scorer whose shifted scores s + 2e still fit the int8 strip profile (max score + 2 ext <= 127); the host falls
+// back to sw_scan_i32 otherwise.  z(i, j) is uniform over the wave and lives in SGPRs.
+// (Round 5 measured this kernel in sw_scan_pkc's COLUMN frame as well -- F carries the "- e" as a two-VGPR subtract, the running
+// maximum lives in the frame: the same 6.5 instructions with two of the double-rate class instead of one -- and it is 2.2 % SLOWER,
+// 5 631 against 5 756 GCUPS A/B on one device: the column frame puts a fourth instruction on the dependent chain down a column
+// (max3 -> add -> max -> sub), and this kernel, unlike sw_scan_pkd, had no spilled per-row frame constants to win back.)
 // =====================================================================================================
 template <int R>
 __device__ __forceinline__ void sw_column_d(int (&H)[R], int (&E)[R], const v4i (&sc)[R / 16], int diag, int F, int& best,
-                                            int eo, int zn, int ev, int& h_last, int& f_last) {
-    int hprev = 0;
+                                            int eo, int zcur, int e, int& h_last, int& f_last) {
+    int tprev = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int w = sc[r / 16][(r % 16) / 4];
         const int s = (int)(signed char)(w >> (8 * (r % 4)));
         const int h = imax(imax(diag + s, E[r]), F);
-        if (r & 1) best = imax(imax(best, hprev), h); else hprev = h;
+        const int t = h - zcur;                                   // true H
+        if (r & 1) best = imax(imax(best, tprev), t); else tprev = t;
+        zcur += e;                                                // scalar: z(i+1, j) = z(i, j+1)
         const int hm = h + eo;
-        E[r] = imax(imax(E[r], hm), zn);                          // zn = z_{j+1}: one SGPR for the whole column
-        F = imax(F, hm) - ev;
+        E[r] = imax(imax(E[r], hm), zcur);
+        F = imax(F, hm);
         diag = H[r];
         H[r] = h;
     }
@@ -258,18 +263,20 @@ __device__ __forceinline__ void sw_column_d(int (&H)[R], int (&E)[R], const v4i 
 // rows row0 .. row0+7 of one column (the tail strip of sw_scan_i32d walks a column in blocks of eight rows)
 template <int R>
 __device__ __forceinline__ void sw_rows8_d(int (&H)[R], int (&E)[R], int row0, const v4i (&sc)[R / 16], int& diag, int& F, int& best,
-                                           int eo, int zn, int ev) {
-    int hprev = 0;
+                                           int eo, int& zcur, int e) {
+    int tprev = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = row0 + i;
         const int w = sc[r / 16][(r % 16) / 4];
         const int s = (int)(signed char)(w >> (8 * (r % 4)));
         const int h = imax(imax(diag + s, E[r]), F);
-        if (i & 1) best = imax(imax(best, hprev), h); else hprev = h;
+        const int t = h - zcur;
+        if (i & 1) best = imax(imax(best, tprev), t); else tprev = t;
+        zcur += e;
         const int hm = h + eo;
-        E[r] = imax(imax(E[r], hm), zn);
-        F = imax(F, hm) - ev;
+        E[r] = imax(imax(E[r], hm), zcur);
+        F = imax(F, hm);
         diag = H[r];
         H[r] = h;
     }
@@ -278,17 +285,17 @@ __device__ __forceinline__ void sw_rows8_d(int (&H)[R], int (&E)[R], int row0, c
 // The LAST strip of a query when it needs fewer than R rows: nb = ceil(rows / 8) blocks of eight rows per column, the others are
 // skipped by a uniform branch (the last strip hands no boundary row on, so nothing reads the rows that were not computed).  A
 // query of 300-400 residues pads to a multiple of 8 instead of 32: 1 % of rows that score nothing instead of 4.4 %.  One extra
-// instantiation of the column loop, kept out of the full strips' code.  `best` is the in-frame maximum (frame of column 0 on
-// entry, of the column after the last on exit).
+// instantiation of the column loop, kept out of the full strips' code: their registers and per-diagonal SGPR constants are untouched
+// (round 2's attempts specialised the strip height at compile time and paid for the second set of constants with SGPR spills).
 template <int R>
 __device__ __forceinline__ void i32d_tail_strip(const uint32_t* res, unsigned len4, const char* prof, const v4i* wsH, const v4i* wsF, int lane,
-                                                bool first, unsigned nb_, int& best, int eo, int e, int ev) {
+                                                bool first, unsigned nb_, int& best, int eo, int e, int zrow0) {
     int H[R];
     int E[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { H[r] = -e; E[r] = 0; }          // H~(i,-1) = z_{-1}, E~(i,0) = z_0 for H = E = 0
-    int zj = 0;
-    int hdiag = -e;
+    for (int r = 0; r < R; ++r) { H[r] = zrow0 + (r - 1) * e; E[r] = zrow0 + r * e; }
+    int zcol = zrow0;
+    int hdiag = zrow0 - 2 * e;
     uint32_t res_n = res[0];
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
     if (!first && len4) { hb_n = wsH[lane]; fb_n = wsF[lane]; }
@@ -309,15 +316,14 @@ __device__ __forceinline__ void i32d_tail_strip(const uint32_t* res, unsigned le
             for (int k = 0; k < R / 16; ++k) sc[k] = sc_n[k];
             if (cc < 3) load_scores<R>(sc_n, prof, r4, cc + 1); else load_scores<R>(sc_n, prof, res_n, 0);
             int diag = hdiag;
-            int F = first ? zj : fb[cc];
-            const int zn = zj + e;
-            sw_rows8_d<R>(H, E, 0, sc, diag, F, best, eo, zn, ev);
+            int F = first ? zcol : fb[cc];
+            int zcur = zcol;
+            sw_rows8_d<R>(H, E, 0, sc, diag, F, best, eo, zcur, e);
 #pragma unroll
             for (int b = 1; b < R / 8; ++b)
-                if (nb > (unsigned)b) sw_rows8_d<R>(H, E, 8 * b, sc, diag, F, best, eo, zn, ev);
-            hdiag = first ? zj : hb[cc];
-            zj = zn;
-            best += ev;
+                if (nb > (unsigned)b) sw_rows8_d<R>(H, E, 8 * b, sc, diag, F, best, eo, zcur, e);
+            hdiag = first ? zcol - e : hb[cc];
+            zcol += e;
             asm volatile("" : "+v"(best));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -343,8 +349,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
     const unsigned n_items = a.n_groups * a.q_count;
     const int e = (int)a.ext;
     int eo = (int)a.ext - (int)a.open;
-    int ev = e;
-    asm volatile("" : "+v"(eo), "+v"(ev));           // in VGPRs: v_add_u32 / v_sub_u32 with two VGPR sources are the double-rate class (tools/valu_issue.hip)
+    asm volatile("" : "+v"(eo));           // in a VGPR: v_add_u32 with two VGPR sources issues a little faster than the SGPR-operand form (tools/valu_issue.hip)
+    const int two_e = 2 * e;
 
     for (;;) {
         unsigned item = 0;
@@ -360,11 +366,10 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
         const unsigned lq = a.q_len[q];
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
-        const int zend = (int)(len4 * 4u) * e;                      // z of the column after the last: where best~ stands when a strip ends
-        int best = 0;                                               // true running maximum, between strips
+        int best = 0;
 
         for (unsigned s = 0; s < nstrips; ++s) {
-            // ---- strip profile: prof[k][t][b] = M[q_{sR+16k+b}][t] + e  (int8) ----
+            // ---- strip profile: prof[k][t][b] = M[q_{sR+16k+b}][t] + 2e  (int8) ----
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int e0 = 0; e0 < 2 * R; e0 += 64) {
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const unsigned code = ((unsigned)q16[d] >> (8 * b)) & 31u;
-                        w |= (unsigned)(unsigned char)(lmat[code * 32 + t] + e) << (8 * b);
+                        w |= (unsigned)(unsigned char)(lmat[code * 32 + t] + two_e) << (8 * b);
                     }
                     out[d] = (int)w;
                 }
@@ -387,18 +392,17 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
             __builtin_amdgcn_wave_barrier();
 
             const bool first = (s == 0), last = (s + 1 == nstrips);
-            int bf = best;                                           // best~ in column 0's frame (z_0 = 0)
+            const int zrow0 = (int)(s * R) * e;                     // z(i0, 0) for the strip's first row i0
             if (last && lq - s * R + 7 < (unsigned)R) {             // a short last strip: only the blocks of eight rows it needs
-                i32d_tail_strip<R>(res, len4, prof, wsH, wsF, lane, first, (lq - s * R + 7) / 8, bf, eo, e, ev);
-                best = bf - zend;
+                i32d_tail_strip<R>(res, len4, prof, wsH, wsF, lane, first, (lq - s * R + 7) / 8, best, eo, e, zrow0);
                 break;
             }
             int H[R];
             int E[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { H[r] = -e; E[r] = 0; }     // H~(i,-1) = z_{-1}, E~(i,0) = z_0 for H = E = 0: the same in every row
-            int zj = 0;                                              // z_j of the current column
-            int hdiag = -e;                                          // H~(i0-1, -1)
+            for (int r = 0; r < R; ++r) { H[r] = zrow0 + (r - 1) * e; E[r] = zrow0 + r * e; }     // H~(i,-1), E~(i,0) for H = E = 0
+            int zcol = zrow0;                                        // z(i0, j) of the current column
+            int hdiag = zrow0 - 2 * e;                               // H~(i0-1, -1)
 
             uint32_t res_n = res[0];
             v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
@@ -419,18 +423,15 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
                     for (int k = 0; k < R / 16; ++k) sc[k] = sc_n[k];
                     if (cc < 3) load_scores<R>(sc_n, prof, r4, cc + 1); else load_scores<R>(sc_n, prof, res_n, 0);
                     int hl, fl;
-                    const int zn = zj + e;
-                    sw_column_d<R>(H, E, sc, hdiag, first ? zj : fb[cc], bf, eo, zn, ev, hl, fl);   // first strip: F~(0,j) = z_j
-                    hdiag = first ? zj : hb[cc];                     // first strip: H~(-1, j) = z_j
-                    zj = zn;
+                    sw_column_d<R>(H, E, sc, hdiag, first ? zcol : fb[cc], best, eo, zcol, e, hl, fl);   // first strip: F~(0,j) = z(0,j)
+                    hdiag = first ? zcol - e : hb[cc];               // first strip: H~(-1, j) = z(0,j) - e
+                    zcol += e;
                     ho[cc] = hl; fo[cc] = fl;
-                    bf += ev;                                        // best~ moves to column j+1's frame
-                    asm volatile("" : "+v"(bf));
+                    asm volatile("" : "+v"(best));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!last) { wsH[(uint64_t)c * 64 + lane] = ho; wsF[(uint64_t)c * 64 + lane] = fo; }
             }
-            best = bf - zend;
         }
         const unsigned p = a.grp_perm[(uint64_t)g * 64 + lane];
         if (p != 0xFFFFFFFFu) a.scores[(uint64_t)(q - a.q_begin) * a.score_stride + p] = best;

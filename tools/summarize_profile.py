@@ -44,7 +44,8 @@ s = dict(kernel=label, workload_cells=cells, git_sha=sha, kernel_source_sha=src_
          FETCH_SIZE_KB=fetch_kb, WRITE_SIZE_KB=write_kb,
          correction="MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128-B request on wide (16 B/lane) coalesced reads -> read "
                     "bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 exact for 16 B/lane stores. Strip-boundary rows are the kernel's only bulk "
-                    "traffic, all 16 B/lane.",
+                    "traffic: 16 B/lane vectors in sw_scan_pkd / sw_scan_i32d, 4 B/lane dwords (one whole 256-byte line per wave instruction, "
+                    "two 128-B requests) in sw_scan_pkc -- the same bytes per chunk either way.",
          hbm_read_bytes_per_launch=fetch_kb * 2048, hbm_write_bytes_per_launch=write_kb * 1024,
          hbm_bytes_per_launch=fetch_kb * 2048 + write_kb * 1024, kernel_ms_rocprof_avg=avg_ns / 1e6, sq=sq)
 s["derived"] = dict(
@@ -54,7 +55,7 @@ s["derived"] = dict(
     cycles_per_valu_wave_instr_per_simd=(sq["GRBM_GUI_ACTIVE"]["sum"] / 8) / (sq["SQ_INSTS_VALU"]["sum"] / 1024),
     lds_bank_conflict_cycles_frac_of_wave_cycles=sq["SQ_LDS_BANK_CONFLICT"]["sum"] / sq["SQ_WAVE_CYCLES"]["sum"])
 json.dump(s, open(f"{dst}/pmc_summary.json", "w"), indent=1)
-if label.startswith("sw_scan_pkd"):        # the default kernel: what bench.py copies into roofline.traffic
+if label.startswith("sw_scan_pkc"):        # the default kernel: what bench.py copies into roofline.traffic
     json.dump(dict(kernel=label, workload_cells=cells, hbm_bytes_per_launch=s["hbm_bytes_per_launch"], source=f"{dst}/pmc_summary.json",
                    git_sha=sha, kernel_source_sha=src_sha), open("profiles/hbm_traffic.json", "w"), indent=1)
 # executed vector lane-ops per cell of every profiled scan kernel: what bench.py's roofline.frac_executed is priced with
