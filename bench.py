@@ -296,7 +296,7 @@ def tail_leg(s4g, s4gd, synth, torch, cfg, allq, scorer, dev, nq, nt, qlen, wl, 
     info["long_tile"] = {"cells": float(cells_rank - cells_a), "cells_frac": round(float(cells_rank - cells_a) / float(cells_rank), 5),
                          "scan_ms_added": round(kern_ms - ms_a, 3), "scan_ms_added_frac": round((kern_ms - ms_a) / kern_ms, 4),
                          "note": "scan time of the timed steps minus the scan time of the same database without its sequences beyond 12 288 residues; "
-                                 "those sit in a tile of their own that runs on a side stream underneath the main tile (DESIGN.md 6.1)"}
+                                 "those sit in a tile of their own that runs on a side stream underneath the main tile (DESIGN.md 5)"}
     # (b) the clipped set: BASELINE configs[2] as SURVEY 8d generates it
     cfg_c = synth.make_config(wl["cfg"], n_queries=nq, n_targets=nt, q_len=qlen)
     db_c = s4g.Database(codes=cfg_c["t_codes"], offsets=cfg_c["t_off"], device=dev.index)

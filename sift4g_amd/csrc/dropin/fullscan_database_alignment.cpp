@@ -8,7 +8,7 @@
 // without an alignment deleted and their slots NULLed (:106-111), the surviving `database` array handed back, banner and
 // progress lines.  Changed: one ChainDatabase per chunk (uploaded once, packed on the device) and ONE
 // shotgunDatabaseEValues call for all queries -- conservative integer score cut and exact top-k' on the device, exact
-// double-precision e-values on the survivors, traceback of the survivors on the device (DESIGN.md 6) -- instead of
+// double-precision e-values on the survivors, traceback of the survivors on the device (DESIGN.md 7) -- instead of
 // createFilteredDatabase + chainDatabaseCreate + alignDatabase per query (:61-95).
 //
 // Results: every hit the prefiltered builds report is reported here with the same score, e-value and path, plus the

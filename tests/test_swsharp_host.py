@@ -437,7 +437,7 @@ else:
     assert "10/1" in note[0] and "9/1" in note[0] and "BLOSUM_62" in note[0] and "S4G_EVALUE_CONVENTION=blast" in note[0]
     assert "lambda 0.243" in note[0] and "lambda 0.206" in note[0]
     factor = float(note[0].split("has E ~ ")[1].split(";")[0])
-    assert 1e-3 < factor < 1e-2                      # one to two orders above the 1e-4 the default row reports
+    assert 1e-3 < factor < 1e-2                      # one to two orders above the 1e-4 the default row reports (EXPERIMENTS.md part B 3 item 9)
     # second call with the same penalties: silent; 11/2 -> the other reading is 9/2 (a row): its own note; 6/2 -> 4/2 is no row: silent
     lines = [l for l in second.splitlines() if l.startswith("[NOTE]")]
     assert len(lines) == 1 and "11/2" in lines[0] and "9/2" in lines[0], second
