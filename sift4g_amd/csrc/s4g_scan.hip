@@ -757,16 +757,28 @@ __device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned
 // s * rows + r.  With few rows one block per row leaves the chip idle while it reads a million scores four times over;
 // the caller then cuts the rows into segments and merges the segment lists (merge_rows keys on (score, id), so the
 // result is the same exact top-k).
+//
+// Round 5, the FAST PATH in front of the general one: k is a few hundred of 10^5 scores, and almost every score is small.  Pass A
+// (16-byte loads) counts the row into 63 bins of four scores (0 .. 251) + one bin for everything beyond, in a histogram that is
+// PRIVATE to each thread (LDS word [bin][thread]: no atomic ever meets another) -- the general path's first radix level put every
+// score below 4096 into ONE bin, 10^5 LDS atomics on one address per row.  The bins give t0, the lower edge of the bin that holds the
+// k-th largest score, and how many scores are >= t0; when those fit the block's LDS (8192 keys) pass B collects exactly them and a
+// bitonic sort on (score desc, id asc) yields the exact top-k: two reads of the row instead of four, no ordered tie scan.  A row
+// whose cut lies beyond 251, or with more than 8192 scores at or above its cut bin, takes the general path below, unchanged.
+constexpr int kFastBins = 64, kFastShift = 2, kFastCap = 8192;
+
 __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n_cols, uint32_t seg_len,
                                                         uint32_t k, uint32_t kpad,
                                                         int32_t min_score, uint32_t* __restrict__ out_ids,
                                                         int32_t* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
                                                         const uint32_t* __restrict__ col_ids,
                                                         const int32_t* __restrict__ row_min_scores) {
-    __shared__ unsigned hist[kBins];
-    __shared__ unsigned long long keys[kTopkMax];
+    __shared__ __attribute__((aligned(16))) unsigned long long buf[kFastCap];       // 64 KB: private histogram | collected keys | the general path's hist + keys
+    unsigned* const hist = reinterpret_cast<unsigned*>(buf);                        // general path: 4096 words (16 KB)
+    unsigned long long* const keys = buf + kBins / 2;                               // general path: 4096 keys behind them (32 KB)
     __shared__ int s_hi, s_cut, s_max;
     __shared__ unsigned s_above, s_quota, s_nout, s_tie_base, s_wave_cnt[kTopkBlock / 64];
+    __shared__ unsigned s_part[4][kFastBins], s_t0, s_take;
     const int tid = threadIdx.x;
     const uint32_t c0 = blockIdx.y * seg_len;
     const uint32_t n = c0 < n_cols ? (n_cols - c0 < seg_len ? n_cols - c0 : seg_len) : 0;
@@ -774,6 +786,90 @@ __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restric
     const uint64_t slot = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (row_min_scores) min_score = row_min_scores[blockIdx.x];       // per-query cut (e-value driven)
     if (min_score < 0) min_score = 0;
+
+    // ---- fast path ----
+    {
+        // every element of the row once: a scalar head up to 16-byte alignment, 16-byte vectors, a scalar tail
+        const uint32_t head = n ? std::min<uint32_t>(n, (uint32_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(row) & 15u)) & 15u) / 4u)) : 0u;
+        const uint32_t nv = (n - head) / 4;
+        const v4i* rv = reinterpret_cast<const v4i*>(row + head);
+        auto for_each = [&](auto&& f) {
+            for (uint32_t i = tid; i < head; i += kTopkBlock) f(row[i], i);
+            for (uint32_t j = tid; j < nv; j += kTopkBlock) {
+                const v4i x = rv[j];
+                const uint32_t i = head + 4 * j;
+                f(x[0], i); f(x[1], i + 1); f(x[2], i + 2); f(x[3], i + 3);
+            }
+            for (uint32_t i = head + 4 * nv + tid; i < n; i += kTopkBlock) f(row[i], i);
+        };
+        unsigned* const ph = reinterpret_cast<unsigned*>(buf);                      // [kFastBins][kTopkBlock]
+        for (int i = tid; i < kFastBins * kTopkBlock; i += kTopkBlock) ph[i] = 0;
+        __syncthreads();
+        for_each([&](int v, uint32_t) {
+            if (v >= min_score) {
+                const unsigned b = std::min<unsigned>((unsigned)v >> kFastShift, kFastBins - 1);
+                ph[b * kTopkBlock + tid] += 1;                                      // this thread's own word: no atomic needed
+            }
+        });
+        __syncthreads();
+        {   // bin totals: thread (part, bin) adds 64 threads' words, then the four parts
+            const int bin = tid & (kFastBins - 1), part = tid >> 6;
+            unsigned t = 0;
+            for (int j = 0; j < 64; ++j) t += ph[bin * kTopkBlock + part * 64 + ((j + tid) & 63)];
+            s_part[part][bin] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int b = kFastBins - 1;
+            for (; b >= 0; --b) {
+                const unsigned t = s_part[0][b] + s_part[1][b] + s_part[2][b] + s_part[3][b];
+                if (acc + t >= k) { acc += t; break; }
+                acc += t;
+            }
+            // b < 0: fewer than k scores pass min_score -- take them all.  b == the last bin: the cut lies beyond the fine bins.
+            s_t0 = b < 0 ? 0u : (unsigned)b << kFastShift;
+            s_take = (b == kFastBins - 1 || acc > (unsigned)kFastCap) ? 0xFFFFFFFFu : acc;
+            s_nout = 0;
+        }
+        __syncthreads();
+        const unsigned take = s_take;
+        if (take != 0xFFFFFFFFu) {
+            const int t0 = std::max((int)s_t0, min_score);
+            __syncthreads();                                                        // (everybody has read the totals: buf becomes the key list)
+            for_each([&](int v, uint32_t i) {
+                if (v >= t0) buf[atomicAdd(&s_nout, 1u)] = ((unsigned long long)(unsigned)(0x7FFFFFFF - v) << 32) | i;
+            });
+            __syncthreads();
+            const unsigned m_all = s_nout;                                          // == take
+            unsigned pad = 2;
+            while (pad < m_all) pad <<= 1;
+            for (unsigned i = m_all + tid; i < pad; i += kTopkBlock) buf[i] = ~0ull;
+            __syncthreads();
+            for (unsigned size = 2; size <= pad; size <<= 1) {
+                for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (unsigned t = tid; t < pad / 2; t += kTopkBlock) {
+                        const unsigned lo = 2 * t - (t & (stride - 1));
+                        const unsigned hi2 = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const unsigned long long x = buf[lo], y = buf[hi2];
+                        if ((x > y) == up) { buf[lo] = y; buf[hi2] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            const unsigned m = m_all < k ? m_all : k;
+            for (unsigned i = tid; i < k; i += kTopkBlock) {
+                const bool valid = i < m;
+                const unsigned long long key = valid ? buf[i] : 0ull;
+                out_ids[slot * k + i] = valid ? (col_ids ? col_ids[c0 + (uint32_t)key] : c0 + (uint32_t)key) : 0xFFFFFFFFu;
+                out_scores[slot * k + i] = valid ? 0x7FFFFFFF - (int)(key >> 32) : 0;
+            }
+            if (tid == 0) out_counts[slot] = m;
+            return;
+        }
+        __syncthreads();
+    }
 
     // ---- range of the row: scores beyond 2^24 - 1 (a query of a million residues) shift the radix digits up, and a third
     //      level then resolves the bits shifted out, so the cut is exact over the whole non-negative int32 range ----

@@ -434,6 +434,37 @@ def test_topk_heavy_ties_and_large_scores(s4g, scorer):
             assert (ids[i, cnt[i]:] == 0xFFFFFFFF).all() and (sc[i, cnt[i]:] == 0).all()
 
 
+def test_topk_fast_path_edges(s4g, scorer):
+    """topk_rows' fast path (round 5: a per-thread histogram of 63 bins of four scores, then the scores at or above the cut's bin
+    collected and sorted) and the general path behind it, on rows built to sit on both sides of every branch: a protein-like
+    distribution with a few large hits (fast path); the k-th score exactly on a bin edge; more than 8192 scores in the cut's bin
+    (general path); the cut beyond 251 (general path); fewer than k scores above min_score; min_score inside the cut's bin; row
+    lengths that are not multiples of 4 (the rows of a matrix then start at every alignment), thousands of ties at the cut."""
+    import torch
+    rng = np.random.default_rng(25)
+    for n in (9001, 9002, 9003, 20000):
+        db = s4g.Database([np.zeros(3, dtype=np.uint8)] * n)
+        prot = np.clip(rng.normal(45, 8, size=n), 0, None).astype(np.int64)
+        prot[rng.choice(n, 40, replace=False)] = rng.integers(300, 2500, size=40)
+        edge = np.where(np.arange(n) < 400, 64, rng.integers(0, 64, size=n))                    # exactly 400 scores >= 64 = a bin's lower edge
+        crowded = rng.integers(60, 64, size=n)                                                   # every score in one bin: > 8192 there
+        high = rng.integers(200, 900, size=n)                                                    # the 400th largest lies beyond 251
+        few = np.where(rng.random(n) < 0.01, rng.integers(1, 50, size=n), 0)
+        ties = np.where(rng.random(n) < 0.5, 66, rng.integers(0, 66, size=n))                    # thousands of ties at the cut
+        ramp = np.arange(n) % 240
+        rows = np.stack([prot, edge, crowded, high, few, ties, ramp, np.zeros(n, dtype=np.int64)]).astype(np.int32)
+        t = torch.from_numpy(rows).cuda()
+        for k, ms in ((1, 1), (37, 1), (400, 1), (400, 65), (400, 67), (2000, 30), (4096, 1)):
+            ids, sc, cnt = s4g.topk(db, t, k, ms)
+            for i in range(rows.shape[0]):
+                order = np.lexsort((np.arange(n), -rows[i].astype(np.int64)))
+                order = order[rows[i][order] >= ms][:k]
+                assert cnt[i] == len(order), (n, k, ms, i)
+                assert np.array_equal(ids[i, :cnt[i]].astype(np.int64), order), (n, k, ms, i)
+                assert np.array_equal(sc[i, :cnt[i]], rows[i][order]), (n, k, ms, i)
+                assert (ids[i, cnt[i]:] == 0xFFFFFFFF).all() and (sc[i, cnt[i]:] == 0).all()
+
+
 def test_tiled_database_scan(s4g, oracle_mod, blosum62, scorer):
     """the database is stored as tiles of the length-sorted order (incl. a separate long-sequence class):
     full-matrix scans must not depend on the tiling."""
