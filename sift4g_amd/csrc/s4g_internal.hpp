@@ -122,7 +122,7 @@ struct DeviceCtx {
     uint64_t qlist_cap = 0;
     int32_t* d_tile_scores = nullptr;   // s4g_scan_topk: [query batch][tile columns]
     uint64_t tile_scores_bytes = 0;
-    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0, grid_col = 0, grid_col24 = 0;
+    uint32_t grid_i32 = 0, grid_i16 = 0, grid_f16 = 0, grid_drift = 0, grid_col = 0;
     uint32_t grid_pair[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_trace[6] = {0, 0, 0, 0, 0, 0};
     uint32_t grid_pair_band = 0, grid_pair_trace_band = 0, grid_pair_recheck = 0;

@@ -41,7 +41,6 @@ struct Plan {
     bool speculative = false;       // some query runs in the drift tier on its frame alone: marked results need sw_pair_recheck
     uint64_t n_spec = 0;            // (query, tile) combinations routed speculatively (reporting)
     uint32_t spec_base = 0;         // sw_scan_pkd: 0x7BFF - bias - (max score + 2 ext); sw_scan_pkc: 0x7BFF - (max score + ext), in the frame
-    bool rows24 = false;            // EXPERIMENT: sw_scan_pkc<24, 4>
     bool col_frame = true;          // drift tier = sw_scan_pkc (column frame) rather than sw_scan_pkd (anti-diagonal frame)
 };
 // S4G_SCAN_FRAME=diag|col overrides the flag for a whole process (A/B runs of bench.py and the tests)
@@ -80,7 +79,6 @@ int warm_scan_kernels(DeviceCtx* cx) {
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pk<ArithI16M3, kStripRows16>, &cx->grid_f16);
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkd<kStripRows16>, &cx->grid_drift);
     if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkc<kStripRows16>, &cx->grid_col);
-    if (!rc) rc = grid_for(&probe, (const void*)sw_scan_pkc<24, 4>, &cx->grid_col24);
     return rc;
 }
 
@@ -120,11 +118,8 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     if (rc) return rc;
     rc = grid_for(db, (const void*)sw_scan_pkc<kStripRows16>, &cx->grid_col);
     if (rc) return rc;
-    rc = grid_for(db, (const void*)sw_scan_pkc<24, 4>, &cx->grid_col24);
-    if (rc) return rc;
-    p->rows24 = getenv("S4G_PKC_ROWS24") != nullptr;
     p->col_frame = frame_env() ? frame_env() == 2 : !(flags & S4G_SCAN_DIAG_FRAME);
-    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = p->col_frame ? (p->rows24 ? cx->grid_col24 : cx->grid_col) : cx->grid_drift;
+    p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = p->col_frame ? cx->grid_col : cx->grid_drift;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
     p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
     // bias of the maximum3-on-bit-patterns tiers: keeps diag+s, h-open, E-ext (and H~(0,-1) = B - ext in the drift frame) >= 0
@@ -309,8 +304,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         a.spec_base = p.speculative ? p.spec_base : 0;
         const uint32_t gd = grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift);
         a.clk = clk_region(gd, 0);
-        if (p.col_frame && p.rows24) hipLaunchKernelGGL((sw_scan_pkc<24, 4>), dim3(gd), dim3(kBlock), 0, stream, a);
-        else if (p.col_frame) hipLaunchKernelGGL((sw_scan_pkc<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
+        if (p.col_frame) hipLaunchKernelGGL((sw_scan_pkc<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
     }

@@ -977,7 +977,26 @@ __device__ __forceinline__ void pkc_rows8(int (&H)[R], int (&E)[R], int row0, co
     }
 }
 
-template <int R, int RR, bool FIRST>
+template <int R>
+__device__ __forceinline__ void pkc_rows4(int (&H)[R], int (&E)[R], int row0, const v4i& sc, int& diag, int& F, int& best,
+                                          int eo, int e2v, int zn) {
+    int hprev = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + i;
+        const int h = pk_maximum3((int)((unsigned)diag + (unsigned)sc[i]), E[r], F);
+        if (i & 1) best = pk_maximum3(best, hprev, h); else hprev = h;
+        const int hm = (int)((unsigned)h + (unsigned)eo);
+        E[r] = pk_maximum3(E[r], hm, zn);
+        F = (int)((unsigned)as_i(pk_max(as_s(F), as_s(hm))) - (unsigned)e2v);
+        diag = H[r];
+        H[r] = h;
+    }
+}
+
+// ROWS4: the strip profile's scores are fetched one block of FOUR rows ahead instead of eight (one ds_read_b128 in flight instead of
+// two): eight VGPRs less, which is what lets the kernel run at four waves per SIMD (128 VGPRs).
+template <int R, int RR, bool FIRST, bool ROWS4>
 __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, const char* prof, v4i* ws, int lane,
                                           bool last, int& best, int eo, int e2v, int e2, int B2) {
     constexpr bool first = FIRST;
@@ -988,7 +1007,10 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
     // Strip-boundary workspace of this kernel: dword [chunk c][H | F][column cc][lane] -- one 256-byte line per (chunk, row kind,
     // column).  A boundary value is loaded for the NEXT chunk into the register it was just read from, and stored as soon as its
     // column is done: no second set of registers for a chunk in flight and no copies between the sets (sw_scan_pkd moves 16-byte
-    // vectors per lane and pays six v_mov per chunk for the hand-over), and the loads still lead their use by four columns.
+    // vectors per lane and pays six v_mov per chunk for the hand-over), and the loads lead their use by three to four columns.
+    // (Round 5 measured two other hand-overs at four waves per SIMD, A/B on one device, EXPERIMENTS.md A.1: a ring of TWO values per
+    // row kind loaded two columns ahead -- no spills, 1.3 % slower -- and the next chunk staged through LDS by buffer_load ... lds --
+    // no ring at all, 1.1 % slower: its s_waitcnt vmcnt(0) per chunk also waits for the stores just issued.)
     const unsigned lane4 = (unsigned)lane * 4u;
     const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(res_u), 0, (int)(len4 * 256u), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_ws = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(len4 * 2048u), 0x00020000);
@@ -1016,7 +1038,8 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
     }
     v4i sc_n[2];
     unsigned taddr_first = pkc_taddr(res_n, 0);
-    pk_load8(sc_n, prof, taddr_first, 0);
+    if constexpr (ROWS4) sc_n[0] = *reinterpret_cast<const v4i*>(prof + taddr_first);
+    else pk_load8(sc_n, prof, taddr_first, 0);
     for (unsigned c = 0; c < len4; ++c) {
         const uint32_t r4 = res_n;
         const unsigned cn = (c + 1 < len4) ? c + 1 : c;
@@ -1029,11 +1052,20 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
             int diag = hdiag;
             int F = first ? zj : fbv[cc];            // first strip: F~(0,j) = z_j (F = 0)
             const int zn = zj + e2;
+            if constexpr (ROWS4) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                v4i sc[2] = {sc_n[0], sc_n[1]};
-                if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
-                pkc_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, e2v, zn);
+                for (int b = 0; b < 2 * NB; ++b) {
+                    const v4i sc = sc_n[0];
+                    sc_n[0] = *reinterpret_cast<const v4i*>(prof + (b + 1 < 2 * NB ? (b + 1) * 512 + taddr : taddr_next));
+                    pkc_rows4<R>(H, E, 4 * b, sc, diag, F, best, eo, e2v, zn);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    v4i sc[2] = {sc_n[0], sc_n[1]};
+                    if (b + 1 < NB) pk_load8(sc_n, prof, taddr, b + 1); else pk_load8(sc_n, prof, taddr_next, 0);
+                    pkc_rows8<R>(H, E, 8 * b, sc, diag, F, best, eo, e2v, zn);
+                }
             }
             hdiag = first ? zj : hbv[cc];            // first strip: H~(-1, j) = z_j (H = 0)
             zj = zn;
@@ -1041,7 +1073,7 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
             if (!first) {
                 // reload what has been consumed, into the registers it was consumed from: F of this column (its chain is over) for the
                 // next chunk, and H of the column BEFORE (its value went into the first row of this one; for column 0 that is column 3
-                // of the chunk before, whose successor is this chunk's).  Three columns of lead.
+                // of the chunk before, whose successor is this chunk's).
                 fbv[cc] = ld_ws(true, cn, cc);
                 const int pc = (cc + 3) & 3;
                 hbv[pc] = ld_ws(false, cc == 0 ? c : cn, pc);
@@ -1053,7 +1085,10 @@ __device__ __forceinline__ void pkc_strip(const uint32_t* res_u, unsigned len4, 
     }
 }
 
-template <int R, int WPS = 3>
+// WPS = waves per SIMD.  Four (round 5): 128 VGPRs -- 8 spilled, two scratch loads and two stores per 4-column chunk in the column
+// loop, measured cheaper than every spill-free alternative -- and +2.9 % over three waves A/B: a fourth wave to take the vector unit
+// while another waits for LDS, and more pairs of double-rate instructions meeting at the issue stage.
+template <int R, int WPS = 4>
 __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
     __shared__ __attribute__((aligned(16))) char lds[1024 + kWavesPerBlock * R * 128];
@@ -1131,16 +1166,16 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
 #define S4G_LAST_STRIP(RR_)                                                                                  \
             if constexpr (R > RR_) {                                                                         \
                 if (!done && rr == RR_) {                                                                    \
-                    if (first) pkc_strip<R, RR_, true>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2); \
-                    else pkc_strip<R, RR_, false>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);    \
+                    if (first) pkc_strip<R, RR_, true, WPS >= 4>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2); \
+                    else pkc_strip<R, RR_, false, WPS >= 4>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);    \
                     done = true;                                                                             \
                 }                                                                                            \
             }
             S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24) S4G_LAST_STRIP(32) S4G_LAST_STRIP(40)
 #undef S4G_LAST_STRIP
             if (!done) {
-                if (first) pkc_strip<R, R, true>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
-                else pkc_strip<R, R, false>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
+                if (first) pkc_strip<R, R, true, WPS >= 4>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
+                else pkc_strip<R, R, false, WPS >= 4>(res, len4, prof, wsH, lane, last, bf, eo, e2v, e2, B2);
             }
             ovf = as_i(__builtin_elementwise_max(as_u(ovf), as_u(bf)));
             best = (int)((unsigned)bf - (unsigned)zend);                // back to the true maximum (no borrow: bf >= zend in both halves)
