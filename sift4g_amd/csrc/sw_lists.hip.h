@@ -266,6 +266,10 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 // matrix.  (Twelve waves to a block, one block to a CU -- every strip of a 350-row query on a wave of its own -- were measured too:
 // the longest group of the bench tile, 11 strips x 3000 columns x 64 lanes, is 2.7 ms of ONE CU's issue slots however its strips
 // are spread; that form reached 3.8 ms for it against 5.2 ms here, but only 8.9 TCUPS once the chip is full against 10.9.)
+// (Round 5 tried sw_scan_pkc's memory side here too -- buffer instructions, boundary rows as per-column dwords reloaded in place, one
+// block of profile scores ahead: 837 instead of 845 vector instructions per chunk, no scratch, 159 VGPRs -- and measured it neutral
+// (729k pairs 10.2-10.8 against 10.5-10.9 ms, 8 queries x 100k 8.60 against 8.70 ms, 4 queries 5.70 against 5.56 ms); four waves
+// per SIMD would need 128 VGPRs, 31 fewer than the two score vectors and two residue streams of this kernel leave.  Not kept.)
 template <int R, bool SCAN = false>
 __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
