@@ -127,7 +127,7 @@ def cpu_baseline(cfg, n_threads, target_seconds=12.0):
         scan = oracle.scan_simd_ladder_flat
         # thread sweep on a short sample each: all hardware threads, the physical cores, halves of that
         topo = _cpu_topology()
-        counts = sorted({n_threads, topo[1] if topo else n_threads, max(1, n_threads // 2), max(1, n_threads // 4), max(1, n_threads // 8)}, reverse=True)
+        counts = sorted({n_threads, topo[1] if topo else n_threads, max(1, n_threads // 2), max(1, n_threads // 4), max(1, n_threads // 8), max(1, n_threads // 16)}, reverse=True)
         sweep = {}
         for c in counts:
             m = min(n_t, max(8192, 256 * c))      # >= 8 batches of 32 targets per thread: the queue balances unequal batches

@@ -7,7 +7,7 @@
 
 constexpr int kStripRows = 32;      // sw_scan_i32
 constexpr int kStripRows16 = 32;    // sw_scan_i16x2
-constexpr uint64_t kWorkspaceBudget = 24ull << 30;   // strip-boundary workspace cap; long-sequence tiles run on a smaller grid
+constexpr uint64_t kWorkspaceBudget = 40ull << 30;   // strip-boundary workspace cap (round 5: 40 GB, so that a tile of sequences up to 12 288 residues keeps the full grid of 4096 waves); longer-sequence tiles run on a smaller grid
 constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of the [query batch][tile columns] buffer
 
 // Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
