@@ -30,6 +30,28 @@ def test_synthetic_workload_is_deterministic():
     assert h.hexdigest() == "79275571666105ecacc64341f82cf4ff6b415edd831295a851524caccc517dac"
 
 
+def test_swissprot_tail_generator():
+    """synth.SWISSPROT_TAIL (bench.py --workload swissprot-tail): the clipped set's queries and planted homologs unchanged, the
+    lognormal unclipped, a thin 2-10 k component, eight giants of fixed lengths at ids no homolog uses, each holding a copy of a query."""
+    from sift4g_amd import synth
+    base = synth.make_config(3, n_queries=40, n_targets=20000)
+    tail = synth.make_config(3, n_queries=40, n_targets=20000, tail=synth.SWISSPROT_TAIL)
+    assert np.array_equal(base["q_codes"], tail["q_codes"]) and np.array_equal(base["q_off"], tail["q_off"])
+    assert tail["planted"][:len(base["planted"])] == base["planted"]
+    lens = np.diff(tail["t_off"].astype(np.int64))
+    giants = tail["giants"]
+    assert [int(lens[t]) for t in giants] == list(synth.SWISSPROT_TAIL["giants"]) and len(set(giants)) == 8
+    assert not set(giants) & {t for _, t in base["planted"]}
+    assert int(lens.max()) == 35213 and int((lens > 3000).sum()) >= 8 and np.diff(base["t_off"].astype(np.int64)).max() <= 3000
+    for q, t in tail["planted"][len(base["planted"]):]:          # the copies inside the giants
+        assert t in giants
+        qc = tail["q_codes"][int(tail["q_off"][q]):int(tail["q_off"][q + 1])]
+        tc = tail["t_codes"][int(tail["t_off"][t]):int(tail["t_off"][t + 1])]
+        assert any(np.array_equal(tc[i:i + len(qc)], qc) for i in np.nonzero(tc[:len(tc) - len(qc) + 1] == qc[0])[0])
+    again = synth.make_config(3, n_queries=40, n_targets=20000, tail=synth.SWISSPROT_TAIL)
+    assert all(np.array_equal(tail[k], again[k]) for k in ("q_codes", "q_off", "t_codes", "t_off")) and again["giants"] == giants
+
+
 def _run_bench(*argv, env=None, timeout=1500):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
                        env=dict(os.environ, **(env or {})))
@@ -93,6 +115,21 @@ def test_bench_prints_one_contract_json_line():
     pf = d["prefilter"]
     assert pf["targets"] == 3000 and pf["residues_per_s"] > 0 and pf["kmer_hits"] >= pf["pairs_with_a_hit"] > 0
     assert pf["check"] == dict(pf["check"], targets=2000, mismatches=0)
+
+
+@pytest.mark.gpu
+def test_bench_swissprot_tail_workload_line():
+    """--workload swissprot-tail at test size: the line names the workload, carries the `tail` leg (length statistics, the scan without
+    the sequences beyond 12 288 residues, the clipped set, their ratio) and the oracle re-score of its own results."""
+    d = _run_bench("--gpus", "1", "--workload", "swissprot-tail", "--steps", "1", "--warmup", "1", "--queries", "24", "--targets", "30000",
+                   "--no-cpu-baseline", "--no-tiers", "--no-prefilter")
+    _check_common(d, 1, 1, 1)
+    assert "unclipped Swiss-Prot-like length tail" in d["config"]["workload"] and "giants" in d["config"]["workload"]
+    t = d["tail"]
+    assert t["lengths"]["max"] == 35213 and t["lengths"]["over_12288"] >= 6 and t["giants"] == [10200, 12288, 12289, 14507, 18141, 22152, 27118, 35213]
+    assert len(t["tile_seqs"]) >= 2 and t["long_tile"]["cells"] > 0 and 0.3 < t["ratio_to_clipped"] < 1.5
+    assert t["clipped_at_3000"]["gcups"] > 0 and t["without_sequences_over_12288"]["gcups"] > 0
+    assert d["selfcheck"]["mismatches"] == 0
 
 
 @pytest.mark.gpu
