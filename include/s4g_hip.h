@@ -34,7 +34,7 @@
  *       /root/reference/sift4g/src/database_alignment.cpp:83-86
  *       (s4g_score_lists_host = the per-query candidate lists built by
  *       createFilteredDatabase, database_alignment.cpp:136-162)
- *   s4g_traceback_host
+ *   s4g_traceback_host / s4g_traceback_host_flags / s4g_traceback_submit / s4g_traceback_finish
  *       step 4 of swsharp alignDatabase: traceback of the survivors
  *   s4g_warmup
  *       the device initialisation swsharp does behind cudaCheckCards / its first alignDatabase call, main.cpp:186
@@ -262,6 +262,20 @@ int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
 int s4g_traceback_host_flags(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
                              const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
                              int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths, uint32_t flags);
+
+/* The same traceback in two halves, so that a host can do other work -- the reference's wrapper builds the NEXT query's candidate
+ * database, /root/reference/sift4g/src/database_alignment.cpp:70-92 -- while the device traces the survivors of this one.
+ * s4g_traceback_submit queues the kernels and the download on the device's stream and returns; the database's device tables and the
+ * query set may be destroyed right after it in the usual way ONLY IF their destruction is stream-ordered (a database made by
+ * s4g_db_create_cached is; s4g_queries_destroy frees memory and therefore waits for the device) -- the caller keeps `q` alive until
+ * finish.  s4g_traceback_finish waits for the job, writes h_out / h_paths exactly as s4g_traceback_host would (path_off as
+ * given to submit) and frees the job; a job is finished exactly once.  A request too large for one batch is traced at once, inside
+ * submit; finish then only copies. */
+typedef struct s4g_trace_job s4g_trace_job;
+int s4g_traceback_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                         const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score, const uint64_t* path_off,
+                         s4g_trace_job** job);
+int s4g_traceback_finish(s4g_trace_job* job, int32_t* h_out, uint8_t* h_paths);
 
 /* Introspection for measurement (bench.py): name and launch geometry of the
  * kernel s4g_scan dispatches for this (db, queries, scorer) combination. */

@@ -80,6 +80,9 @@ SIGNATURES = {
                                           c_i32p, c_i32p, c_u64p, c_u8p]),
     "s4g_traceback_host_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,
                                           c_i32p, c_i32p, c_u64p, c_u8p, ctypes.c_uint32]),
+    "s4g_traceback_submit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, c_u32p, c_u32p,
+                                            c_i32p, c_u64p, ctypes.POINTER(ctypes.c_void_p)]),
+    "s4g_traceback_finish": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.POINTER(ctypes.c_uint8)]),
     "s4g_warmup": (ctypes.c_int, [ctypes.c_int]),
     "s4g_scan_stats": (ctypes.c_int, [ctypes.c_int, c_u64p, ctypes.c_uint32]),
     "s4g_scan_clock": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_uint32]),

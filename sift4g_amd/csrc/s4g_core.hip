@@ -117,7 +117,7 @@ int warm_core_kernels(DeviceCtx* cx) {
 
 // ---------------------------------------------------------------------------
 S4G_API const char* s4g_last_error(void) { return g_err.c_str(); }
-S4G_API int s4g_abi_version(void) { return 5; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info, s4g_db_open_streamed, s4g_db_stream_stats; 5: + s4g_comm_*, s4g_gather_topk, s4g_merge_topk_host
+S4G_API int s4g_abi_version(void) { return 6; }      // 2: + s4g_scan_stats, s4g_clock_probe; 3: + s4g_prefilter_*; 4: + s4g_scan_clock, s4g_db_create_cached, s4g_chain_cache_info, s4g_db_open_streamed, s4g_db_stream_stats; 5: + s4g_comm_*, s4g_gather_topk, s4g_merge_topk_host; 6: + s4g_traceback_submit, s4g_traceback_finish
 
 S4G_API int s4g_device_count(int* count) {
     if (!count) return fail(S4G_ERR_INVALID, "count is NULL");
@@ -596,6 +596,7 @@ S4G_API int s4g_db_create(s4g_db** out, int device, const uint8_t* codes, const 
 
 S4G_API int s4g_db_destroy(s4g_db* db) {
     if (!db) return S4G_OK;
+    if (db->refs.fetch_sub(1) > 1) return S4G_OK;       // a traceback job in flight still reads it: its s4g_traceback_finish releases
     DeviceGuard guard(db->device);
     {   // launches that still read the tiles must have finished before they are freed
         DeviceCtx* cx = device_ctx(db->device);
@@ -750,6 +751,51 @@ S4G_API int s4g_queries_create(s4g_queries** out, int device, const uint8_t* cod
             if (c >= 26) { delete q; return fail(S4G_ERR_INVALID, "residue code %u out of range in query %u", c, i); }
             padded[off[i] + j] = c;
         }
+    // A small set -- the one query of the reference's per-query call, database_alignment.cpp:83-86 -- takes ONE device block out of a
+    // per-device cache and ONE asynchronous upload out of pinned staging: three hipMalloc, three synchronous pageable copies (each of
+    // which also waits for whatever the device is still doing, e.g. the previous call's traceback) and three hipFree per call otherwise.
+    const uint64_t o_off = (padded.size() + 255) / 256 * 256, o_len = o_off + (off.size() * 8 + 255) / 256 * 256;
+    const uint64_t blk_need = o_len + ((uint64_t)(n ? n : 1) * 4 + 255) / 256 * 256;
+    if (blk_need <= (1u << 20)) {
+        DeviceCtx* cx = device_ctx(device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        for (size_t k = 0; k < cx->query_blocks.size(); ++k)
+            if (cx->query_blocks[k].second >= blk_need) {
+                q->d_block = cx->query_blocks[k].first; q->block_bytes = cx->query_blocks[k].second;
+                cx->query_blocks.erase(cx->query_blocks.begin() + k);
+                break;
+            }
+        hipError_t e = hipSuccess;
+        if (!q->d_block) {
+            q->block_bytes = std::max<uint64_t>(blk_need, 16u << 10);
+            e = hipMalloc((void**)&q->d_block, q->block_bytes);
+        }
+        if (e == hipSuccess && cx->query_pin_bytes < blk_need) {
+            if (cx->h_query_pin) { (void)hipEventSynchronize(cx->query_pin_done); (void)hipHostFree(cx->h_query_pin); cx->h_query_pin = nullptr; cx->query_pin_bytes = 0; }
+            e = hipHostMalloc((void**)&cx->h_query_pin, 1u << 20, hipHostMallocDefault);
+            if (e == hipSuccess) cx->query_pin_bytes = 1u << 20;
+        }
+        if (e == hipSuccess && !cx->query_pin_done) e = hipEventCreateWithFlags(&cx->query_pin_done, hipEventDisableTiming);
+        else if (e == hipSuccess) e = hipEventSynchronize(cx->query_pin_done);                  // the previous set's upload out of the staging buffer
+        if (e == hipSuccess) {
+            memcpy(cx->h_query_pin, padded.data(), padded.size());
+            memcpy(cx->h_query_pin + o_off, off.data(), off.size() * 8);
+            if (n) memcpy(cx->h_query_pin + o_len, q->len.data(), (size_t)n * 4);
+            e = hipMemcpyAsync(q->d_block, cx->h_query_pin, blk_need, hipMemcpyHostToDevice, nullptr);
+        }
+        if (e == hipSuccess) e = hipEventRecord(cx->query_pin_done, nullptr);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (q->d_block) (void)hipFree(q->d_block);
+            delete q;
+            return fail(S4G_ERR_HIP, "query upload failed: %s", hipGetErrorString(e));
+        }
+        q->d_codes = reinterpret_cast<uint8_t*>(q->d_block);
+        q->d_off = reinterpret_cast<uint64_t*>(q->d_block + o_off);
+        q->d_len = reinterpret_cast<uint32_t*>(q->d_block + o_len);
+        *out = q;
+        return S4G_OK;
+    }
     hipError_t e;
     if ((e = hipMalloc((void**)&q->d_codes, padded.size())) != hipSuccess ||
         (e = hipMalloc((void**)&q->d_off, off.size() * 8)) != hipSuccess ||
@@ -767,7 +813,16 @@ S4G_API int s4g_queries_create(s4g_queries** out, int device, const uint8_t* cod
 S4G_API int s4g_queries_destroy(s4g_queries* q) {
     if (!q) return S4G_OK;
     DeviceGuard guard(q->device);
-    (void)hipFree(q->d_codes); (void)hipFree(q->d_off); (void)hipFree(q->d_len);
+    if (q->d_block) {
+        // back into the cache.  hipFree used to wait for the device here, and a caller may have queued a scan of these queries on a
+        // stream of its own: keep that guarantee (with nothing in flight -- the usual case: results have been waited for -- it costs
+        // microseconds), then the block can go to the next small set
+        (void)hipDeviceSynchronize();
+        DeviceCtx* cx = device_ctx(q->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (cx->query_blocks.size() < 8) cx->query_blocks.emplace_back(q->d_block, q->block_bytes);
+        else (void)hipFree(q->d_block);
+    } else { (void)hipFree(q->d_codes); (void)hipFree(q->d_off); (void)hipFree(q->d_len); }
     delete q;
     return S4G_OK;
 }

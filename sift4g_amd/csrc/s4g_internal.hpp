@@ -93,6 +93,8 @@ struct s4g_db {
     char* d_cached_block = nullptr;
     uint64_t cached_block_bytes = 0;
     mutable DbStream* stream = nullptr;         // s4g_db_open_streamed: no resident tiles, only s4g_scan_topk* serve it
+    mutable std::atomic<int> refs{1};           // the caller's handle + one per traceback job in flight (s4g_traceback_submit): the last
+                                                // s4g_db_destroy / s4g_traceback_finish releases the device memory
 };
 void chain_cache_release(s4g_db* db);           // s4g_chains.hip
 // s4g_stream.hip: tiles of a streamed database (db->stream != NULL) live in the file; two slots on the device
@@ -130,6 +132,18 @@ struct DeviceCtx {
     uint32_t grid_pair_pk[3] = {0, 0, 0};   // sw_pair_scan_pk<1, 2, 3> (sw_pair_pk.hip.h: two rows per register)
     uint64_t stat_pair_pk = 0;              // pairs of the last pair submission that ran there
     char* h_trace_pin = nullptr;        // pinned staging of traceback_pairs: items up, results back
+    std::vector<std::pair<char*, uint64_t>> query_blocks;        // device blocks of destroyed small query sets (stream-ordered reuse on the null stream)
+    char* h_query_pin = nullptr; uint64_t query_pin_bytes = 0;   // pinned staging of s4g_queries_create, guarded by query_pin_done
+    hipEvent_t query_pin_done = nullptr;
+    hipStream_t trace_stream = nullptr;      // tracebacks in flight (s4g_traceback_submit) run here, beside the next call's scoring on the null stream
+    hipEvent_t trace_inputs = nullptr;       // recorded on the null stream at submit: the uploads the job's kernels read
+    hipEvent_t trace_last = nullptr;         // behind the last job queued on trace_stream: what shares its buffers (the traceback arena, its
+                                             // counters, a change of the substitution table) on another stream waits for it
+    // pinned host memory of the tracebacks in flight (s4g_traceback_submit): slabs, a job takes a piece of the current one and gives
+    // it back at finish; a slab whose pieces have all come back starts over.  (A buffer per job was 200 hipHostMalloc of a megabyte
+    // for the 200 per-query calls of a run -- a quarter of a millisecond each -- and as many hipHostFree.)
+    struct PinSlab { char* p = nullptr; uint64_t cap = 0, used = 0; int live = 0; };
+    std::vector<PinSlab> trace_pin_slabs;
     uint64_t trace_pin_bytes = 0;
     hipStream_t coop_stream = nullptr;  // they run next to the one-wave-per-pair launches of the same submission, not behind them
     hipEvent_t coop_fork = nullptr, coop_join = nullptr;
@@ -197,6 +211,8 @@ struct s4g_queries {
     uint8_t* d_codes = nullptr;
     uint64_t* d_off = nullptr;
     uint32_t* d_len = nullptr;
+    char* d_block = nullptr;                 // small sets (a per-query call's one query): codes | offsets | lengths in ONE block out of the
+    uint64_t block_bytes = 0;                // device's query-block cache, uploaded by one asynchronous copy; destroy hands the block back
     std::vector<uint32_t> len;
     std::vector<uint8_t> codes;              // host copy (unpadded) for per-scorer bounds
     std::vector<uint64_t> off;
@@ -308,4 +324,4 @@ int recheck_marked(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sco
                    int32_t* d_scores, uint64_t stride, uint32_t n_cols, const uint32_t* d_col_ids, uint32_t max_lt, hipStream_t stream);
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
-                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths);
+                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths, s4g_trace_job* job = nullptr);

@@ -775,9 +775,28 @@ int launch_pair_trace(DeviceCtx* cx, PairTraceArgs a, uint32_t* grid_cache, hipS
 }
 
 // Traceback with one wave per pair (sw_pair_trace; sw_pair_trace_band beyond 1024 query residues): `sel` = pair indices.
+// A traceback in flight (s4g_traceback_submit / s4g_traceback_finish): everything finish needs once the stream has passed `done`.
+// The results sit in a pinned buffer of the job's own (taken from the device's pool, returned by finish): the next submission on
+// the same device reuses the device arena in stream order, but must not write its items into host memory a download is still landing in.
+struct s4g_trace_job {
+    const s4g_db* db = nullptr;             // a reference (s4g_db::refs) while in flight: released by finish
+    int device = 0;
+    uint32_t n_pairs = 0;
+    bool in_flight = false;                 // false: the results are in out5 / paths already (the synchronous fallback ran)
+    hipEvent_t done = nullptr;
+    char* pin = nullptr; int pin_slab = -1;           // a piece of cx->trace_pin_slabs[pin_slab]
+    uint64_t back_off = 0, best_off = 0, paths_off = 0;       // inside pin: out5 | best | paths, as they sit in the arena
+    std::vector<uint32_t> order;            // slot -> original pair index
+    std::vector<int32_t> want, score;       // per slot: the maximum the kernel must report, the score passed in
+    std::vector<uint64_t> path_end;         // per slot: end of the pair's path region (the walk writes backwards from it)
+    std::vector<uint64_t> path_off;         // the caller's layout (n_pairs + 1)
+    std::vector<int32_t> out5;              // fallback results
+    std::vector<uint8_t> paths;
+};
+
 int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const std::vector<uint32_t>& sel,
                     const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score,
-                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths) {
+                    int32_t* h_out, const uint64_t* path_off, uint8_t* h_paths, s4g_trace_job* job) {
     DeviceGuard guard(db->device);
     DeviceCtx* cx = device_ctx(db->device);
     std::lock_guard<std::mutex> lk(cx->mu);
@@ -790,6 +809,30 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
     if (cx->last_use) HIP_TRY(hipStreamWaitEvent(stream, cx->last_use, 0));
     { const int rcm = ensure_mat(cx, scorer, stream); if (rcm) return rcm; }
+    // A submission that may stay in flight (job != nullptr; pairs of the one-wave classes only: the banded and the cooperative kernels
+    // share workspaces with the scoring kernels) runs on the device's TRACE stream, behind an event on the null stream that covers the
+    // uploads its kernels read (the candidate database's tables, the query set, the substitution table): the next call's scoring, on
+    // the null stream, then runs beside it instead of behind it.  Whatever else uses the traceback arena waits for the last such job.
+    bool on_trace_stream = false;
+    if (job) {
+        bool plain = true;
+        for (uint32_t i = 0; i < (uint32_t)sel.size() && plain; ++i) {
+            const uint32_t pi = sel[i];
+            if (q->len[pair_q[pi]] > (uint32_t)kPairMaxRows) plain = false;
+        }
+        if (plain) {
+            if (!cx->trace_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&cx->trace_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&cx->trace_inputs, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&cx->trace_last, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(cx->trace_inputs, nullptr));
+            HIP_TRY(hipStreamWaitEvent(cx->trace_stream, cx->trace_inputs, 0));
+            stream = cx->trace_stream;
+            on_trace_stream = true;
+        }
+    }
+    if (!on_trace_stream && cx->trace_last) HIP_TRY(hipStreamWaitEvent(stream, cx->trace_last, 0));
     // class-major (the cooperative classes first: the longest pairs start first), longest target first inside a class (32-residue
     // granularity), as in pairs_enqueue
     const uint32_t n = (uint32_t)sel.size();
@@ -799,7 +842,7 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     for (uint32_t i = 0; i < n; ++i) cells_total += (double)q->len[pair_q[sel[i]]] * db->len[pair_t[sel[i]]];
     const CoopRule coop(cells_total, true);
     auto class_of = [&](uint32_t pi) {
-        const int cc = (pair_score[pi] > 0) ? coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]) : -1;
+        const int cc = (pair_score[pi] > 0 && !on_trace_stream) ? coop.cls(q->len[pair_q[pi]], db->len[pair_t[pi]]) : -1;
         return cc >= 0 ? cc : pair_class(q->len[pair_q[pi]]);
     };
     auto slot_of = [](int c) { return c >= kScanClasses ? c - kScanClasses : c + kCoopClasses; };      // position of class c in the order
@@ -874,9 +917,31 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
             HIP_TRY(hipHostMalloc((void**)&cx->h_trace_pin, want, hipHostMallocDefault));
             cx->trace_pin_bytes = want;
         }
-        memcpy(cx->h_trace_pin, items.data(), (size_t)ni * sizeof(PairTraceItem));
-        uint8_t* const back = reinterpret_cast<uint8_t*>(cx->h_trace_pin) + pin_items;
-        HIP_TRY(hipMemcpyAsync(A + o_items, cx->h_trace_pin, (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
+        // a submission (job != nullptr) that is ONE batch stays in flight: it gets a pinned buffer of its own out of the device's pool
+        const bool async = job && on_trace_stream && b0 == 0 && b1 == n && !big_dirs;
+        char* pin = cx->h_trace_pin;
+        if (async) {
+            const uint64_t need_pin = (pin_items + back_bytes + 255) / 256 * 256;
+            int pick = -1;
+            for (size_t k = 0; k < cx->trace_pin_slabs.size() && pick < 0; ++k)
+                if (cx->trace_pin_slabs[k].live > 0 && cx->trace_pin_slabs[k].cap - cx->trace_pin_slabs[k].used >= need_pin) pick = (int)k;
+            for (size_t k = 0; k < cx->trace_pin_slabs.size() && pick < 0; ++k)
+                if (cx->trace_pin_slabs[k].live == 0 && cx->trace_pin_slabs[k].cap >= need_pin) { cx->trace_pin_slabs[k].used = 0; pick = (int)k; }
+            if (pick < 0) {
+                DeviceCtx::PinSlab sl;
+                sl.cap = std::max<uint64_t>(need_pin, 8u << 20);
+                HIP_TRY(hipHostMalloc((void**)&sl.p, sl.cap, hipHostMallocDefault));
+                cx->trace_pin_slabs.push_back(sl);
+                pick = (int)cx->trace_pin_slabs.size() - 1;
+            }
+            DeviceCtx::PinSlab& sl = cx->trace_pin_slabs[(size_t)pick];
+            job->pin = sl.p + sl.used; job->pin_slab = pick;
+            sl.used += need_pin; ++sl.live;
+            pin = job->pin;
+        }
+        memcpy(pin, items.data(), (size_t)ni * sizeof(PairTraceItem));
+        uint8_t* const back = reinterpret_cast<uint8_t*>(pin) + pin_items;
+        HIP_TRY(hipMemcpyAsync(A + o_items, pin, (size_t)ni * sizeof(PairTraceItem), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(cx->d_counter + kPairTraceCounter, 0, kAllClasses * 4, stream));
         CoopFork coop_fork(cx, stream);
         for (int sl = 0; sl < kAllClasses; ++sl) {
@@ -943,6 +1008,23 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
         if (rc) return rc;
         // out5, best and the paths sit back to back in the arena: one download
         HIP_TRY(hipMemcpyAsync(back, A + o_out, back_bytes, hipMemcpyDeviceToHost, stream));
+        if (async) {
+            if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(job->done, stream));
+            HIP_TRY(hipEventRecord(cx->trace_last, stream));
+            job->in_flight = true;
+            job->db = db; db->refs.fetch_add(1);
+            job->back_off = pin_items; job->best_off = pin_items + (o_best - o_out); job->paths_off = pin_items + (o_paths - o_out);
+            job->order.assign(order.begin(), order.end());
+            job->want.resize(ni); job->score.resize(ni); job->path_end.resize(ni);
+            for (uint32_t x = 0; x < ni; ++x) {
+                const uint32_t pi = order[x];
+                job->score[x] = pair_score[pi];
+                job->want[x] = pair_score[pi] > 0 && q->len[pair_q[pi]] && db->len[pair_t[pi]] ? pair_score[pi] : 0;
+                job->path_end[x] = items[x].path_end;
+            }
+            return S4G_OK;
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         const int32_t* out5 = reinterpret_cast<const int32_t*>(back);
         const int32_t* best = reinterpret_cast<const int32_t*>(back + (o_best - o_out));
@@ -961,3 +1043,75 @@ int traceback_pairs(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc
     return S4G_OK;
 }
 
+// ---- the traceback in two halves (include/s4g_hip.h) ----
+S4G_API int s4g_traceback_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, uint32_t n_pairs,
+                                 const uint32_t* pair_q, const uint32_t* pair_t, const int32_t* pair_score, const uint64_t* path_off,
+                                 s4g_trace_job** out) {
+    if (!db || !q || !scorer || !out) return fail(S4G_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_pairs && (!pair_q || !pair_t || !pair_score || !path_off)) return fail(S4G_ERR_INVALID, "NULL argument");
+    if (db->device != q->device) return fail(S4G_ERR_INVALID, "db on device %d, queries on device %d", db->device, q->device);
+    if (db->stream) return fail(S4G_ERR_INVALID, "a streamed database (s4g_db_open_streamed) serves s4g_scan_topk / s4g_scan_topk_host only");
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        if (pair_q[i] >= q->n || pair_t[i] >= db->n_seqs) return fail(S4G_ERR_INVALID, "pair %u out of range", i);
+        if (q->len[pair_q[i]] >= 65535 || db->len[pair_t[i]] >= 65535)
+            return fail(S4G_ERR_INVALID, "pair %u: sequences of 65535 residues or more are not supported by the device traceback", i);
+        if (path_off[i + 1] - path_off[i] < (uint64_t)q->len[pair_q[i]] + db->len[pair_t[i]])
+            return fail(S4G_ERR_INVALID, "pair %u: path capacity must be at least query length + target length", i);
+    }
+    s4g_trace_job* job = new s4g_trace_job();
+    job->device = db->device; job->n_pairs = n_pairs;
+    if (n_pairs) {
+        job->path_off.assign(path_off, path_off + n_pairs + 1);
+        job->out5.assign((size_t)n_pairs * 5, 0);
+        job->paths.assign(path_off[n_pairs] ? path_off[n_pairs] : 1, 0);
+        std::vector<uint32_t> all(n_pairs);
+        std::iota(all.begin(), all.end(), 0u);
+        const int rc = traceback_pairs(db, q, scorer, all, pair_q, pair_t, pair_score, job->out5.data(), job->path_off.data(), job->paths.data(), job);
+        if (rc) {
+            if (job->pin_slab >= 0) { DeviceCtx* cx = device_ctx(job->device); std::lock_guard<std::mutex> lk(cx->mu); --cx->trace_pin_slabs[(size_t)job->pin_slab].live; }
+            if (job->done) (void)hipEventDestroy(job->done);
+            delete job;
+            return rc;
+        }
+        if (job->in_flight) { std::vector<int32_t>().swap(job->out5); std::vector<uint8_t>().swap(job->paths); }
+    }
+    *out = job;
+    return S4G_OK;
+}
+
+S4G_API int s4g_traceback_finish(s4g_trace_job* job, int32_t* h_out, uint8_t* h_paths) {
+    if (!job) return fail(S4G_ERR_INVALID, "job is NULL");
+    int rc = S4G_OK;
+    if (job->n_pairs && (!h_out || !h_paths)) rc = fail(S4G_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(job->device);
+    if (job->in_flight) {
+        if (hipEventSynchronize(job->done) != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = fail(S4G_ERR_HIP, "waiting for the traceback failed"); }
+        if (!rc) {
+            const int32_t* out5 = reinterpret_cast<const int32_t*>(job->pin + job->back_off);
+            const int32_t* best = reinterpret_cast<const int32_t*>(job->pin + job->best_off);
+            const uint8_t* paths = reinterpret_cast<const uint8_t*>(job->pin + job->paths_off);
+            for (uint32_t x = 0; x < job->n_pairs && !rc; ++x) {
+                const uint32_t pi = job->order[x];
+                if (best[x] != job->want[x] && !(job->score[x] <= 0 && best[x] == 0)) {
+                    rc = fail(S4G_ERR_INVALID, "pair %u: score %d passed in, traceback kernel computed %d", pi, job->score[x], best[x]);
+                    break;
+                }
+                memcpy(h_out + (size_t)pi * 5, out5 + (size_t)x * 5, 20);
+                const uint32_t len = (uint32_t)out5[(size_t)x * 5 + 4];
+                memcpy(h_paths + job->path_off[pi], paths + job->path_end[x] - len, len);
+            }
+        }
+        DeviceCtx* cx = device_ctx(job->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        --cx->trace_pin_slabs[(size_t)job->pin_slab].live;
+    } else if (!rc && job->n_pairs) {
+        memcpy(h_out, job->out5.data(), (size_t)job->n_pairs * 20);
+        for (uint32_t i = 0; i < job->n_pairs; ++i)
+            memcpy(h_paths + job->path_off[i], job->paths.data() + job->path_off[i], (size_t)job->out5[(size_t)i * 5 + 4]);
+    }
+    if (job->done) (void)hipEventDestroy(job->done);
+    if (job->db) (void)s4g_db_destroy(const_cast<s4g_db*>(job->db));       // the job's reference (the real destruction if the caller's is gone already)
+    delete job;
+    return rc;
+}

@@ -358,6 +358,7 @@ int ensure_mat(DeviceCtx* cx, const s4g_scorer* scorer, hipStream_t stream) {
     if (!cx->d_mat) HIP_TRY(hipMalloc((void**)&cx->d_mat, 1024));
     if (!cx->mat_ready) HIP_TRY(hipEventCreateWithFlags(&cx->mat_ready, hipEventDisableTiming));
     if (cx->mat_serial == scorer->serial && scorer->serial != 0) return hipStreamWaitEvent(stream, cx->mat_ready, 0) == hipSuccess ? S4G_OK : fail(S4G_ERR_HIP, "hipStreamWaitEvent failed");
+    if (cx->trace_last) HIP_TRY(hipStreamWaitEvent(stream, cx->trace_last, 0));      // a traceback in flight on its own stream still reads the old table
     HIP_TRY(hipMemcpyAsync(cx->d_mat, scorer->mat32, 1024, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(cx->mat_ready, stream));
     cx->mat_serial = scorer->serial;

@@ -295,6 +295,71 @@ SW_API void chainDatabaseDelete(ChainDatabase* db) {
     delete db;
 }
 
+// ------------------------------------------------------------------------------------------------ lazy tracebacks
+// The reference's wrapper calls alignDatabase once per query and looks, between two calls, at nothing of an alignment but its target
+// index (database_alignment.cpp:83-95); coordinates and paths are read a stage later (select_alignments.cpp:145-150, 244-300).  So a
+// per-query call SUBMITS the traceback of its survivors (s4g_traceback_submit) and returns alignments that know their score, value
+// and target; the device traces them while the host builds the next query's candidate database, and the first reader of a
+// coordinate or a path waits for the batch (s4g_traceback_finish) and fills every alignment of it in.  Same results, bit for bit:
+// the kernels, their inputs and the tie rules are those of the synchronous call.  S4G_LAZY_TRACEBACK=0 switches it off.
+namespace swimpl {
+namespace {
+struct TraceBatch {
+    s4g_trace_job* job = nullptr;
+    s4g_queries* dq = nullptr;                  // owned: the kernels read it, it is destroyed once the job has finished
+    int device = 0;
+    std::vector<DbAlignment*> members;          // NULL: deleted before the batch was resolved
+    std::vector<uint64_t> path_off;
+    int alive = 0;
+};
+std::mutex g_trace_mu;                          // guards every TraceBatch (readers come from the thread pool: select_alignments.cpp:64-69)
+
+void finish_locked(TraceBatch* b) {
+    const size_t n = b->members.size();
+    std::vector<int32_t> out5(n * 5 + 1);
+    std::vector<uint8_t> paths(b->path_off.back() ? b->path_off.back() : 1);
+    if (s4g_traceback_finish(b->job, out5.data(), paths.data()) != S4G_OK)
+        SW_FATAL("traceback failed on MI355X device %d: %s", b->device, s4g_last_error());
+    for (size_t x = 0; x < n; ++x) {
+        DbAlignment* a = b->members[x];
+        if (!a) continue;
+        a->query_start = out5[x * 5]; a->query_end = out5[x * 5 + 1];
+        a->target_start = out5[x * 5 + 2]; a->target_end = out5[x * 5 + 3];
+        a->path_len = out5[x * 5 + 4];
+        free(a->path);
+        a->path = (char*)xmalloc(a->path_len ? a->path_len : 1);
+        memcpy(a->path, paths.data() + b->path_off[x], a->path_len);
+        a->pending = NULL;
+    }
+    if (b->dq) s4g_queries_destroy(b->dq);
+    delete b;
+}
+}  // namespace
+
+void resolve(DbAlignment* a) {
+    if (!a || !a->pending) return;              // (pending is only ever cleared under the lock, and only read here without it when NULL is final)
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (a->pending) finish_locked((TraceBatch*)a->pending);
+}
+
+// an alignment that is deleted before anybody read it (dbAlignmentsMerge drops the losers of a chunk): it leaves its batch, and the
+// last one to leave finishes the job so that its buffers and the query set are released
+void forget(DbAlignment* a) {
+    if (!a->pending) return;
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    TraceBatch* b = (TraceBatch*)a->pending;
+    if (!b) return;
+    b->members[(size_t)a->pending_slot] = NULL;
+    a->pending = NULL;
+    if (--b->alive == 0) finish_locked(b);
+}
+
+bool lazy_tracebacks() {
+    static const bool on = []() { const char* e = getenv("S4G_LAZY_TRACEBACK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace swimpl
+
 // ------------------------------------------------------------------------------------------------ DbAlignment / Alignment
 static DbAlignment* make_db_alignment(Chain* query, int query_idx, Chain* target, int target_idx, double value,
                                       Scorer* scorer, const swimpl::PairResult& r) {
@@ -310,21 +375,22 @@ static DbAlignment* make_db_alignment(Chain* query, int query_idx, Chain* target
 
 SW_API Chain* dbAlignmentGetQuery(DbAlignment* a) { return a->query; }
 SW_API int dbAlignmentGetQueryIdx(DbAlignment* a) { return a->query_idx; }
-SW_API int dbAlignmentGetQueryStart(DbAlignment* a) { return a->query_start; }
-SW_API int dbAlignmentGetQueryEnd(DbAlignment* a) { return a->query_end; }
+SW_API int dbAlignmentGetQueryStart(DbAlignment* a) { swimpl::resolve(a); return a->query_start; }
+SW_API int dbAlignmentGetQueryEnd(DbAlignment* a) { swimpl::resolve(a); return a->query_end; }
 SW_API Chain* dbAlignmentGetTarget(DbAlignment* a) { return a->target; }
 SW_API int dbAlignmentGetTargetIdx(DbAlignment* a) { return a->target_idx; }
-SW_API int dbAlignmentGetTargetStart(DbAlignment* a) { return a->target_start; }
-SW_API int dbAlignmentGetTargetEnd(DbAlignment* a) { return a->target_end; }
+SW_API int dbAlignmentGetTargetStart(DbAlignment* a) { swimpl::resolve(a); return a->target_start; }
+SW_API int dbAlignmentGetTargetEnd(DbAlignment* a) { swimpl::resolve(a); return a->target_end; }
 SW_API int dbAlignmentGetScore(DbAlignment* a) { return a->score; }
 SW_API double dbAlignmentGetValue(DbAlignment* a) { return a->value; }
 SW_API Scorer* dbAlignmentGetScorer(DbAlignment* a) { return a->scorer; }
-SW_API int dbAlignmentGetPathLen(DbAlignment* a) { return a->path_len; }
-SW_API char dbAlignmentGetMove(DbAlignment* a, int index) { return a->path[index]; }
-SW_API void dbAlignmentCopyPath(DbAlignment* a, char* dest) { memcpy(dest, a->path, a->path_len); }
-SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { swimpl::scorer_release(a->scorer); free(a->path); free(a); } }
+SW_API int dbAlignmentGetPathLen(DbAlignment* a) { swimpl::resolve(a); return a->path_len; }
+SW_API char dbAlignmentGetMove(DbAlignment* a, int index) { swimpl::resolve(a); return a->path[index]; }
+SW_API void dbAlignmentCopyPath(DbAlignment* a, char* dest) { swimpl::resolve(a); memcpy(dest, a->path, a->path_len); }
+SW_API void dbAlignmentDelete(DbAlignment* a) { if (a) { swimpl::forget(a); swimpl::scorer_release(a->scorer); free(a->path); free(a); } }
 
 SW_API Alignment* dbAlignmentToAlignment(DbAlignment* d) {
+    swimpl::resolve(d);
     Alignment* a = (Alignment*)xcalloc(1, sizeof(Alignment));
     a->query = d->query; a->query_start = d->query_start; a->query_end = d->query_end;
     a->target = d->target; a->target_start = d->target_start; a->target_end = d->target_end;
@@ -450,9 +516,10 @@ SW_API void dbAlignmentsFromScores(DbAlignment*** dbAlignments, int* dbAlignment
 // ------------------------------------------------------------------------------------------------ step 1 + glue
 // Step 4 for a batch of queries: one device traceback of every survivor (keep[i][k].idx indexes cdb->chains), then the
 // DbAlignment objects.  `local0` = index of the batch's first query inside the device query set dq.
+// lazy_dq != NULL: submit only (see "lazy tracebacks"); *lazy_dq is the query set, whose ownership passes to the batch (set to NULL then).
 static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** queries, int query_idx0, uint32_t local0, uint32_t cnt,
                             const std::vector<std::vector<Survivor>>& keep, ChainDatabase* cdb, s4g_db* ddb, s4g_queries* dq, int device,
-                            Scorer* scorer) {
+                            Scorer* scorer, s4g_queries** lazy_dq = NULL) {
     std::vector<uint32_t> pair_q, pair_t;
     std::vector<int32_t> pair_score;
     std::vector<uint64_t> path_off(1, 0);
@@ -464,6 +531,37 @@ static void trace_and_build(DbAlignment*** out_lists, int* out_lens, Chain** que
             path_off.push_back(path_off.back() + (uint64_t)chainGetLength(queries[i]) + (uint64_t)chainGetLength(cdb->chains[sv.idx]));
         }
     const uint32_t np = (uint32_t)pair_q.size();
+    if (lazy_dq && np) {
+        swimpl::TraceBatch* b = new swimpl::TraceBatch();
+        b->device = device; b->path_off = path_off;
+        {
+            Phase ph(4);
+            if (s4g_traceback_submit(ddb, dq, scorer->dev, np, pair_q.data(), pair_t.data(), pair_score.data(), path_off.data(), &b->job) != S4G_OK)
+                SW_FATAL("traceback failed on MI355X device %d: %s", device, s4g_last_error());
+        }
+        Phase ph_build(5);
+        b->dq = *lazy_dq; *lazy_dq = NULL;
+        b->members.resize(np); b->alive = (int)np;
+        std::lock_guard<std::mutex> lk(swimpl::g_trace_mu);
+        uint32_t x = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const int n = (int)keep[i].size();
+            DbAlignment** out = n ? (DbAlignment**)xmalloc(sizeof(DbAlignment*) * n) : NULL;   /* malloc domain */
+            for (int k = 0; k < n; ++k, ++x) {
+                const Survivor& sv = keep[i][k];
+                DbAlignment* a = (DbAlignment*)xcalloc(1, sizeof(DbAlignment));
+                a->query = queries[i]; a->query_idx = query_idx0 + (int)i;
+                a->target = swimpl::real_chain(cdb, sv.idx); a->target_idx = sv.idx;
+                a->score = sv.score; a->value = sv.value; a->scorer = swimpl::scorer_retain(scorer);
+                a->pending = b; a->pending_slot = (int)x;
+                b->members[x] = a;
+                out[k] = a;
+            }
+            out_lists[i] = out;
+            out_lens[i] = n;
+        }
+        return;
+    }
     std::vector<int32_t> out5((size_t)np * 5);
     std::vector<uint8_t> paths(path_off.back() ? path_off.back() : 1);
     {
@@ -591,9 +689,13 @@ static void shotgun_on_card(DbAlignment*** out_all, int* out_lens, int type, Cha
             if (!subset.empty()) for (Survivor& sv : keep[i]) sv.idx = subset[sv.idx];     // index into the ChainDatabase
         }
         delete ph_sel;
-        trace_and_build(*dbAlignments + b, *dbAlignmentsLens + b, queries + b, q0 + (int)b, b, cnt, keep, cdb, ddb, dq, device, scorer);
+        // the reference's per-query call (cached form, the whole call one batch): the traceback stays on the device while the caller
+        // goes on ("lazy tracebacks" above); everything else traces before it returns
+        const bool lazy = use_cached && b == 0 && cnt == (uint32_t)queriesLen && swimpl::lazy_tracebacks();
+        trace_and_build(*dbAlignments + b, *dbAlignmentsLens + b, queries + b, q0 + (int)b, b, cnt, keep, cdb, ddb, dq, device, scorer,
+                        lazy ? &dq : NULL);
     }
-    s4g_queries_destroy(dq);
+    if (dq) s4g_queries_destroy(dq);
 }
 
 

@@ -95,6 +95,9 @@ struct DbAlignment {
     int score; double value;
     Scorer* scorer;
     char* path; int path_len;
+    // a traceback still on the device (align.cpp, "lazy tracebacks"): the batch this alignment belongs to and its slot there; the
+    // coordinates and the path above are filled in by the first call that needs any of them (swimpl::resolve)
+    void* pending; int pending_slot;
 };
 
 struct Alignment {
@@ -117,6 +120,9 @@ struct PairResult {
     int score, q_start, q_end, t_start, t_end;
     std::vector<char> path;   // MOVE_* from start to end
 };
+// Waits for the device traceback an alignment still depends on, if any (align.cpp); every reader of coordinates or path calls it first.
+void resolve(DbAlignment* a);
+void forget(DbAlignment* a);             // a DbAlignment is being deleted: it leaves the batch it may still wait for
 // Host Smith-Waterman with traceback (the "traceback of the <= maxAlignments survivors" stage).
 void sw_traceback(const char* q, int lq, const char* t, int lt, const Scorer* sc, PairResult* out);
 

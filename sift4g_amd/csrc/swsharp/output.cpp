@@ -10,6 +10,7 @@ namespace {
 struct Stats { int identities, mismatches, gap_opens, gaps, positives; };
 
 Stats path_stats(DbAlignment* a) {
+    swimpl::resolve(a);                     // (every output line of an alignment starts here)
     Stats s = {0, 0, 0, 0, 0};
     int qi = a->query_start, ti = a->target_start;
     char prev = MOVE_STOP;

@@ -125,6 +125,27 @@ API int s4g_traceback_host(const s4g_db* db, const s4g_queries* q, const s4g_sco
     return S4G_OK;
 }
 
+// the traceback in two halves: the stand-in traces at submit, finish hands the results over (same results, no overlap)
+struct s4g_trace_job { uint32_t n; std::vector<int32_t> out; std::vector<uint8_t> paths; std::vector<uint64_t> off; };
+API int s4g_traceback_submit(const s4g_db* db, const s4g_queries* q, const s4g_scorer* sc, uint32_t n, const uint32_t* pq, const uint32_t* pt,
+                             const int32_t* ps, const uint64_t* path_off, s4g_trace_job** job) {
+    s4g_trace_job* j = new s4g_trace_job();
+    j->n = n; j->out.assign((size_t)n * 5 + 1, 0); j->off.assign(path_off, path_off + n + 1); j->paths.assign(n ? path_off[n] + 1 : 1, 0);
+    const int rc = n ? s4g_traceback_host(db, q, sc, n, pq, pt, ps, j->out.data(), path_off, j->paths.data()) : S4G_OK;
+    if (rc) { delete j; return rc; }
+    *job = j;
+    return S4G_OK;
+}
+API int s4g_traceback_finish(s4g_trace_job* j, int32_t* out, uint8_t* paths) {
+    if (!j) return fail(S4G_ERR_INVALID, "job is NULL");
+    for (uint32_t i = 0; i < j->n; ++i) {
+        for (int k = 0; k < 5; ++k) out[(size_t)i * 5 + k] = j->out[(size_t)i * 5 + k];
+        memcpy(paths + j->off[i], j->paths.data() + j->off[i], (size_t)j->out[(size_t)i * 5 + 4]);
+    }
+    delete j;
+    return S4G_OK;
+}
+
 // the k-mer prefilter (device_database_search.cpp): answered by oracle/kmer_prefilter.c
 struct s4g_prefilter { void* h; };
 API int s4g_prefilter_create(s4g_prefilter** out, int, const uint8_t* codes, const uint64_t* offsets, uint32_t n, uint32_t k, uint32_t max_candidates) {

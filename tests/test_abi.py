@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/s4g_hip.h but not exported by libs4g_hip.so"
     assert sorted(_lib.SIGNATURES) == declared, "sift4g_amd/_lib.py SIGNATURES out of sync with include/s4g_hip.h"
-    assert _lib.lib.s4g_abi_version() == 5
+    assert _lib.lib.s4g_abi_version() == 6
 
 
 def test_header_cites_reference_interfaces():

@@ -48,6 +48,77 @@ def test_align_database_equals_selection_on_oracle_scores(oracle_mod, blosum62, 
     L.deleteEValueParams(ev); L.chainDatabaseDelete(cdb); L.scorerDelete(s)
 
 
+_LAZY_SCRIPT = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+from conftest import rand_seqs
+import swsharp_ctypes as sw
+from swsharp_ctypes import L, vp, pvp, ci
+rng = np.random.default_rng(77)
+qs = rand_seqs(rng, 5, 120, 380)
+ts = rand_seqs(rng, 900, 30, 420)
+for k in range(120):                                  # homologs with indels: paths with all three moves
+    m = qs[k %% 5].copy(); idx = rng.choice(len(m), size=len(m) // 4, replace=False)
+    m[idx] = rand_seqs(rng, 1, len(idx), len(idx))[0]
+    cut = int(rng.integers(10, len(m) - 10)); m = np.concatenate([m[:cut], rand_seqs(rng, 1, 3, 3)[0], m[cut + 2:]])
+    ts[k * 7] = m
+s = sw.scorer(10, 1)
+tch = [sw.chain("t%%d" %% i, t) for i, t in enumerate(ts)]
+qch = [sw.chain("q%%d" %% i, q) for i, q in enumerate(qs)]
+ev = L.createEValueParams(int(sum(len(t) for t in ts)), s)
+cb = sw.evalue_callback()
+cards = (ci * 1)(0)
+parts = [(0, 300), (300, 300), (600, 300)]            # three "chunks" of the database, as database_alignment.cpp:36-47 would read them
+total, lens = None, None
+K = 12
+for (start, n) in parts:
+    part = (pvp * len(qch))(); plens = (ci * len(qch))()
+    for qi, q in enumerate(qch):                      # the wrapper's loop: database_alignment.cpp:61-95
+        arr = sw.chain_array(tch[start:start + n])
+        cdb = L.chainDatabaseCreate(arr, 0, n, cards, 1)
+        out, cnt = pvp(), ci()
+        L.alignDatabase(ctypes.byref(out), ctypes.byref(cnt), 0, q, cdb, s, K, cb, ev, 10.0, None, 0, cards, 1, None)
+        _ = [L.dbAlignmentGetTargetIdx(out[k]) for k in range(cnt.value)]      # :89, all the wrapper reads between two calls
+        L.chainDatabaseDelete(cdb)                                               # :92, while the traceback may still be running
+        part[qi] = out; plens[qi] = cnt.value
+    if total is None:
+        total, lens = part, plens
+    else:                                             # :97-104: losers are deleted before anybody read their paths
+        L.dbAlignmentsMerge(total, lens, part, plens, len(qch), K)
+res = []
+for qi in range(len(qch)):
+    for k in range(lens[qi]):
+        a = total[qi][k]
+        res.append([qi, L.chainGetName(L.dbAlignmentGetTarget(a)).decode(), L.dbAlignmentGetScore(a), L.dbAlignmentGetQueryStart(a),
+                    L.dbAlignmentGetQueryEnd(a), L.dbAlignmentGetTargetStart(a), L.dbAlignmentGetTargetEnd(a),
+                    sw.path_of(L.dbAlignmentGetPathLen, L.dbAlignmentGetMove, a)])
+for qi in range(len(qch)):
+    for k in range(lens[qi]): L.dbAlignmentDelete(total[qi][k])
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_lazy_tracebacks_equal_eager_ones(oracle_mod, blosum62):
+    """Round 5: a per-query alignDatabase call submits its traceback and returns; coordinates and paths are filled in by their first
+    reader.  The reference's call pattern -- candidate database created and DELETED around every call, only target indices read in
+    between, dbAlignmentsMerge deleting unread losers across three chunks, readers afterwards -- in a child process with the lazy
+    path on (default) and off: identical alignments, and every path re-scores to its alignment's score under the oracle's rules."""
+    import json, sys
+    outs = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _LAZY_SCRIPT % dict(root=ROOT)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, S4G_LAZY_TRACEBACK=mode))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert outs["1"] == outs["0"] and len(outs["1"]) >= 40
+    moves = {m for rec in outs["1"] for m in rec[7]}
+    assert moves == {1, 2, 3}
+    for rec in outs["1"][:10]:
+        qi, name, score, q0, q1, t0, t1, path = rec
+        assert q0 >= 0 and q1 >= q0 and t1 >= t0 and len(path) >= max(q1 - q0, t1 - t0) + 1 and score > 0
+
+
 def test_shotgun_database_batch(oracle_mod, blosum62):
     rng = np.random.default_rng(31)
     qs = rand_seqs(rng, 12, 60, 200)
