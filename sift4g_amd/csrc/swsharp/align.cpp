@@ -329,7 +329,7 @@ void finish_locked(TraceBatch* b) {
         free(a->path);
         a->path = (char*)xmalloc(a->path_len ? a->path_len : 1);
         memcpy(a->path, paths.data() + b->path_off[x], a->path_len);
-        a->pending = NULL;
+        __atomic_store_n(&a->pending, (void*)NULL, __ATOMIC_RELEASE);          // readers that find it NULL without the lock see the fields above
     }
     if (b->dq) s4g_queries_destroy(b->dq);
     delete b;
@@ -337,7 +337,7 @@ void finish_locked(TraceBatch* b) {
 }  // namespace
 
 void resolve(DbAlignment* a) {
-    if (!a || !a->pending) return;              // (pending is only ever cleared under the lock, and only read here without it when NULL is final)
+    if (!a || !__atomic_load_n(&a->pending, __ATOMIC_ACQUIRE)) return;          // (cleared under the lock, with release: NULL is final)
     std::lock_guard<std::mutex> lk(g_trace_mu);
     if (a->pending) finish_locked((TraceBatch*)a->pending);
 }
@@ -345,7 +345,7 @@ void resolve(DbAlignment* a) {
 // an alignment that is deleted before anybody read it (dbAlignmentsMerge drops the losers of a chunk): it leaves its batch, and the
 // last one to leave finishes the job so that its buffers and the query set are released
 void forget(DbAlignment* a) {
-    if (!a->pending) return;
+    if (!__atomic_load_n(&a->pending, __ATOMIC_ACQUIRE)) return;
     std::lock_guard<std::mutex> lk(g_trace_mu);
     TraceBatch* b = (TraceBatch*)a->pending;
     if (!b) return;
