@@ -6,5 +6,5 @@ used by tests, bench.py and the multi-GPU driver: ctypes for the C ABI, torch on
 device buffers, streams and torch.distributed.
 """
 from . import _lib  # noqa: F401  (raises if the HIP library is not built: no fallback)
-from .device import Scorer, Database, QuerySet, device_count, scan, scan_host, topk, topk_device, scan_topk, score_lists, score_pairs, traceback  # noqa: F401
+from .device import Scorer, Database, QuerySet, device_count, scan, scan_host, topk, topk_device, scan_topk, score_lists, score_pairs, traceback, TraceJob  # noqa: F401
 from .seqio import encode, decode, read_fasta  # noqa: F401

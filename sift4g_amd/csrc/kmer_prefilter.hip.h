@@ -27,8 +27,15 @@
 //                      best max_candidates kept (unordered)
 //   pf_finish_rows     one block per query: its list by ascending id -> the rows the caller gets
 //
-// HBM-bound integer work: no MFMA anywhere; what matters is coalesced target reads (a wave walks one target), the random
-// 8-byte bucket lookups (32^5 slots = 134 MB: MALL-resident, not L2) and the radix sorts (rocPRIM).
+// Round 5 -- the index is COMPACT (hash.cpp:56-85 keeps a vector per possible k-mer: 32^5 slots): one 8-byte slot per 32 possible
+// k-mers = (presence bits, number of present k-mers before this word), and the bucket bounds of the PRESENT k-mers only, indexed by
+// that rank.  A thousand queries hold ~350 000 distinct k-mers: 8 MB of slots (of which the 20-letter alphabet touches a quarter) and
+// 1.4 MB of bounds instead of a 134 MB table whose every lookup was a 128-byte line from the fabric (round 4: 3/5 of the kernel's
+// counter traffic).  And the candidates are brought into query order by ONE counting pass (pf_cand_count / pf_cand_scatter) instead
+// of a two-pass radix sort over the whole capacity of the candidate regions.
+//
+// HBM-bound integer work: no MFMA anywhere; what matters is coalesced target reads (a wave walks one target), index lookups that stay
+// in L2, and writes that leave a block as whole lines.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,12 +56,11 @@ __device__ __forceinline__ uint32_t pf_kmer(const uint8_t* __restrict__ c, uint3
 }
 
 // One thread per query residue g (flat over all queries).  key[g] = k-mer starting there, or the invalid key 1 << 5k when fewer
-// than k residues are left in that query; val[g] = g; pos_q[g] / pos_j[g] = query index / position of g; count[kmer] += 1;
-// bit kmer of `present` set.
+// than k residues are left in that query; val[g] = g; pos_q[g] / pos_j[g] = query index / position of g; the k-mer's bit set in its
+// index slot (slots[kmer >> 5].x).
 __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ off, uint32_t nq, uint64_t total,
                                uint32_t k, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos_q,
-                               uint32_t* __restrict__ pos_j, uint32_t* __restrict__ count, uint32_t* __restrict__ present,
-                               unsigned* __restrict__ bad) {
+                               uint32_t* __restrict__ pos_j, uint2* __restrict__ slots, unsigned* __restrict__ bad) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     uint32_t lo = 0, hi = nq;                   // last q with off[q] <= g  (queries of length 0 share an offset: take the last)
@@ -66,8 +72,7 @@ __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t
     if (j + k <= len) {
         const uint32_t v = pf_kmer(codes + g, k);
         key[g] = v;
-        atomicAdd(&count[v], 1u);
-        atomicOr(&present[v >> 5], 1u << (v & 31));
+        atomicOr(&slots[v >> 5].x, 1u << (v & 31));
     } else {
         key[g] = 1u << (k * kKmerBits);
     }
@@ -84,12 +89,32 @@ __global__ void pf_hash_hits(const uint32_t* __restrict__ sorted_val, const uint
     hit_qp[i] = ((uint64_t)pos_j[g] << 32) | pos_q[g];
 }
 
+// The compact index.  slots[w] = (bits of the k-mers 32 w .. 32 w + 31 that some query holds, number of such k-mers below 32 w):
+// pf_slot_count -> exclusive scan -> pf_slot_rank fill in the second half.
+__global__ void pf_slot_count(const uint2* __restrict__ slots, uint32_t n_words, uint32_t* __restrict__ cnt) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_words) cnt[w] = (uint32_t)__popc(slots[w].x);
+}
+__global__ void pf_slot_rank(uint2* __restrict__ slots, uint32_t n_words, const uint32_t* __restrict__ before) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_words) slots[w].y = before[w];
+}
+__device__ __forceinline__ uint32_t pf_rank(uint2 slot, uint32_t v) { return slot.y + (uint32_t)__popc(slot.x & ((1u << (v & 31)) - 1u)); }
+// bounds[r] = first hit of the r-th present k-mer in the k-mer-sorted hit list, bounds[number of present k-mers] = n_hits
+__global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, uint64_t n_hits, const uint2* __restrict__ slots, uint32_t* __restrict__ bounds) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hits) return;
+    const uint32_t v = sorted_key[i];
+    const uint32_t r = pf_rank(slots[v >> 5], v);
+    if (i == 0 || sorted_key[i - 1] != v) bounds[r] = (uint32_t)i;
+    if (i + 1 == n_hits) bounds[r + 1] = (uint32_t)n_hits;
+}
+
 struct PfChunk {
     const uint8_t* codes;       // residues of the chunk, flat
     const uint64_t* off;        // [nt + 1]
-    const uint32_t* starts;     // [32^k + 1] CSR index of the queries' k-mers
-    const uint32_t* present;    // one bit per k-mer: does any query hold it?  (4 MB at k = 5: answers nine lookups in ten from L2
-                                // instead of a random 64-byte fetch from the 134 MB of `starts`)
+    const uint2* slots;         // [32^k / 32] (presence bits, present k-mers before the word): nine lookups in ten end here
+    const uint32_t* bounds;     // [present k-mers + 1] CSR bounds of the queries' k-mers, by rank
     const uint32_t* hit_q;      // bucket contents
     const uint32_t* hit_p;
     const uint64_t* hit_qp;     // the same, interleaved: position << 32 | query (one load per hit in the fused path)
@@ -106,10 +131,12 @@ __device__ __forceinline__ uint32_t pf_bucket(const PfChunk& a, const uint8_t* _
         const uint32_t prev = ((uint32_t)(c[j - 1] & 31u) << ((a.k - 1) * kKmerBits)) | (v >> kKmerBits);
         if (prev == v) return 0;
     }
-    if (!((a.present[v >> 5] >> (v & 31)) & 1u)) return 0;
-    const uint32_t s = a.starts[v];
+    const uint2 slot = a.slots[v >> 5];
+    if (!((slot.x >> (v & 31)) & 1u)) return 0;
+    const uint32_t r = pf_rank(slot, v);
+    const uint32_t s = a.bounds[r];
     *first = s;
-    return a.starts[v + 1] - s;
+    return a.bounds[r + 1] - s;
 }
 
 __device__ __forceinline__ uint64_t pf_wave_sum(uint64_t v) {
@@ -306,7 +333,7 @@ __device__ __forceinline__ void pf_lds_fence() { asm volatile("s_waitcnt lgkmcnt
 
 // Buckets of four chunks of 64 positions from `base`: lane l gets those of positions base + 64 u + l (u = 0..3).  One byte per
 // lane and chunk comes from memory, the k-mers are put together from the neighbours' bytes (shuffles), and the dependent rounds of
-// loads -- residues, presence bitmap, bucket bounds, the bucket's first hit -- are each issued for all four chunks before any is
+// loads -- residues, index slot, bucket bounds, the bucket's first hit -- are each issued for all four chunks before any is
 // waited for.  hq / hp: query and position of the bucket's first hit (most buckets hold exactly one).
 struct PfBlock { uint32_t first[4], n[4], hq[4], hp[4]; };
 __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t base,
@@ -334,15 +361,15 @@ __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __r
         const uint32_t j = base + 64 * u + lane;
         look[u] = j < n_kmers && !(j != 0 && prev == x);            // database_search.cpp:212: equal to the k-mer before it
     }
-    uint32_t bits[4];
+    uint2 slot[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bits[u] = look[u] ? a.present[v[u] >> 5] : 0u;
+    for (int u = 0; u < 4; ++u) slot[u] = look[u] ? a.slots[v[u] >> 5] : make_uint2(0u, 0u);
     uint32_t s0[4], s1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        look[u] = look[u] && ((bits[u] >> (v[u] & 31)) & 1u);
-        uint64_t se = 0;                                             // starts[v], starts[v + 1]: one 8-byte load (4-byte aligned)
-        if (look[u]) __builtin_memcpy(&se, a.starts + v[u], 8);
+        look[u] = look[u] && ((slot[u].x >> (v[u] & 31)) & 1u);
+        uint64_t se = 0;                                             // bounds[r], bounds[r + 1]: one 8-byte load (4-byte aligned)
+        if (look[u]) __builtin_memcpy(&se, a.bounds + pf_rank(slot[u], v[u]), 8);
         s0[u] = (uint32_t)se; s1[u] = (uint32_t)(se >> 32);
     }
 #pragma unroll
@@ -678,6 +705,73 @@ __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ lis
         at += take;
     }
     if (threadIdx.x == 0) list_cnt[q] = cur;
+}
+
+// ---- candidates into query order by one counting pass (up to kPfScatterMaxQ queries: a block keeps a counter per query in LDS) ----
+// The candidates sit in n_regions regions of region_cap slots, the first counters[8 r] of region r used (counters == NULL: one
+// region with `single_n` used slots).  A block takes a tile of kPfTile slots of one region.
+constexpr uint32_t kPfScatterMaxQ = 8192;
+constexpr uint32_t kPfTile = 16384;             // a thousand queries: ~16 candidates = 128 bytes per query and tile leave a block together
+
+__device__ __forceinline__ bool pf_tile(uint64_t region_cap, const unsigned long long* __restrict__ counters, uint64_t single_n,
+                                        uint32_t tiles_per_region, uint64_t* b, uint64_t* e) {
+    const uint32_t r = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+    const uint64_t used = counters ? min((uint64_t)counters[8 * r], region_cap) : single_n;
+    const uint64_t lo = (uint64_t)tile * kPfTile;
+    if (lo >= used) return false;
+    *b = (uint64_t)r * region_cap + lo;
+    *e = (uint64_t)r * region_cap + min(used, lo + kPfTile);
+    return true;
+}
+
+// q_count[q] += candidates of query q
+__global__ __launch_bounds__(512) void pf_cand_count(const uint32_t* __restrict__ cand_q, uint64_t region_cap, const unsigned long long* __restrict__ counters,
+                                                     uint64_t single_n, uint32_t tiles_per_region, uint32_t nq, uint32_t* __restrict__ q_count) {
+    extern __shared__ uint32_t pf_h[];
+    uint64_t b, e;
+    if (!pf_tile(region_cap, counters, single_n, tiles_per_region, &b, &e)) return;     // (block-uniform)
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
+    __syncthreads();
+    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&pf_h[cand_q[i]], 1u);
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) atomicAdd(&q_count[q], c); }
+}
+
+// one block: first[q] = candidates of the queries before q (first[nq] = all of them); cursor[q] = first[q]
+__global__ __launch_bounds__(512) void pf_cand_first(const uint32_t* __restrict__ q_count, uint32_t nq, uint32_t* __restrict__ first, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t part[512];
+    const uint32_t per = (nq + 511) / 512;
+    const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t q = lo; q < hi; ++q) sum += q_count[q];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 512; d <<= 1) {
+        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t q = lo; q < hi; ++q) { first[q] = run; cursor[q] = run; run += q_count[q]; }
+    if (threadIdx.x == 511) first[nq] = part[511];
+}
+
+// out[first[q] ..] = the (score, id) words of query q's candidates, in no particular order
+__global__ __launch_bounds__(512) void pf_cand_scatter(const uint32_t* __restrict__ cand_q, const uint64_t* __restrict__ cand_sv, uint64_t region_cap,
+                                                       const unsigned long long* __restrict__ counters, uint64_t single_n, uint32_t tiles_per_region,
+                                                       uint32_t nq, uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
+    extern __shared__ uint32_t pf_h[];
+    uint64_t b, e;
+    if (!pf_tile(region_cap, counters, single_n, tiles_per_region, &b, &e)) return;
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
+    __syncthreads();
+    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&pf_h[cand_q[i]], 1u);
+    __syncthreads();
+    // the tile's share of every query's range, reserved with one atomic per query that occurs; the counter then becomes the write position
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) pf_h[q] = atomicAdd(&cursor[q], c); }
+    __syncthreads();
+    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) out[atomicAdd(&pf_h[cand_q[i]], 1u)] = cand_sv[i];
 }
 
 // first[q] = index of the first candidate of query q in the query-sorted array (first[nq] = n): one thread per candidate boundary

@@ -28,10 +28,10 @@ struct s4g_prefilter {
     uint32_t nq = 0, k = 0, max_c = 0;
     uint32_t q_bits = 1;            // bits of a query index inside a hit key
     uint32_t list_q_bits = 1;       // bits of the query field of a candidate key that take part in the sort (covers the empty mark)
-    uint64_t n_slots = 0;           // 32^k + 1
+    uint32_t n_words = 0;           // 32^k / 32 index slots
     hipStream_t stream = nullptr;
-    uint32_t* d_starts = nullptr;   // [n_slots + 1]
-    uint32_t* d_present = nullptr;  // [n_slots / 32 + 1] bitmap of the k-mers any query holds
+    uint2* d_slots = nullptr;       // [n_words] (presence bits, present k-mers before the word)   (kmer_prefilter.hip.h)
+    uint32_t* d_bounds = nullptr;   // [n_hash_hits + 2] bucket bounds of the present k-mers, by rank
     uint32_t* d_hit_q = nullptr;
     uint32_t* d_hit_p = nullptr;
     uint64_t* d_hit_qp = nullptr;   // interleaved (position << 32 | query): what the fused path reads
@@ -52,6 +52,7 @@ struct s4g_prefilter {
     uint64_t stat_hits = 0, stat_pairs = 0, stat_long = 0, stat_chunks = 0;
     // the fused path (kmer_prefilter.hip.h): lists = nq rows of max_c keys ~score << 32 | id, ascending, d_list_cnt entries used
     bool fused = false;
+    bool scatter = false;           // candidates into query order by the counting pass (pf_cand_*) rather than a radix sort
     uint32_t lds_keys = 0;          // 64-bit keys a block of pf_merge_lists sorts in LDS
     uint32_t* d_list_cnt = nullptr;
     uint64_t cand_guess = 0;        // candidates the last chunk produced (sizes the next chunk's arrays)
@@ -88,11 +89,10 @@ struct Arena {
 // Builds the CSR index of the queries' k-mers on the device (hash.cpp:56-85).
 int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     const uint64_t total = off[p->nq] - off[0];
-    p->n_slots = (1ull << (p->k * s4g::kKmerBits)) + 1;
-    HIP_TRY(hipMalloc((void**)&p->d_starts, (p->n_slots + 1) * 4));
+    p->n_words = (uint32_t)((1ull << (p->k * s4g::kKmerBits)) >> 5);
     HIP_TRY(hipMalloc((void**)&p->d_q_kmers, (uint64_t)std::max(1u, p->nq) * 4));
-    HIP_TRY(hipMalloc((void**)&p->d_present, (p->n_slots / 32 + 1) * 4));
-    HIP_TRY(hipMemsetAsync(p->d_present, 0, (p->n_slots / 32 + 1) * 4, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_slots, (uint64_t)p->n_words * 8));
+    HIP_TRY(hipMemsetAsync(p->d_slots, 0, (uint64_t)p->n_words * 8, p->stream));
     std::vector<uint32_t> q_kmers(std::max(1u, p->nq), 0);
     std::vector<uint64_t> rel(p->nq + 1);
     for (uint32_t q = 0; q <= p->nq; ++q) rel[q] = off[q] - off[0];
@@ -107,11 +107,12 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     HIP_TRY(hipMalloc((void**)&p->d_hit_q, std::max<uint64_t>(1, p->n_hash_hits) * 4));
     HIP_TRY(hipMalloc((void**)&p->d_hit_p, std::max<uint64_t>(1, p->n_hash_hits) * 4));
     HIP_TRY(hipMalloc((void**)&p->d_hit_qp, std::max<uint64_t>(1, p->n_hash_hits) * 8));
-    DevBuf<uint32_t> count;                              // [n_slots + 1]: bucket sizes, then scanned into d_starts
-    HIP_TRY(count.alloc(p->n_slots + 1));
-    HIP_TRY(hipMemsetAsync(count.p, 0, (p->n_slots + 1) * 4, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_bounds, (p->n_hash_hits + 2) * 4));
+    HIP_TRY(hipMemsetAsync(p->d_bounds, 0, (p->n_hash_hits + 2) * 4, p->stream));
+    DevBuf<uint32_t> cnt, before;                        // per index word: present k-mers in it, and before it
+    HIP_TRY(cnt.alloc(p->n_words)); HIP_TRY(before.alloc(p->n_words));
     size_t cub_scan = 0, cub_sort = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(p->n_slots + 1), p->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)p->n_words, p->stream));
     if (total) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                                           (uint32_t*)nullptr, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
     DevBuf<char> tmp;
@@ -124,15 +125,21 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
         HIP_TRY(hipMemcpyAsync(d_codes.p, codes + off[0], total, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, p->stream));
         hipLaunchKernelGGL(s4g::pf_query_kmers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, d_codes.p, d_off.p, p->nq, total, p->k,
-                           key.p, val.p, pos_q.p, pos_j.p, count.p, p->d_present, p->d_flags);
+                           key.p, val.p, pos_q.p, pos_j.p, p->d_slots, p->d_flags);
         size_t t = std::max(cub_scan, cub_sort);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
         if (p->n_hash_hits)
             hipLaunchKernelGGL(s4g::pf_hash_hits, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, val2.p, pos_q.p, pos_j.p,
                                p->n_hash_hits, p->d_hit_q, p->d_hit_p, p->d_hit_qp);
     }
+    // ranks of the present k-mers, then the bucket bounds by rank (the k-mers without a full window sorted behind the n_hash_hits real ones)
+    hipLaunchKernelGGL(s4g::pf_slot_count, dim3((p->n_words + 255) / 256), dim3(256), 0, p->stream, p->d_slots, p->n_words, cnt.p);
     size_t t = std::max(cub_scan, cub_sort);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, count.p, p->d_starts, (int)(p->n_slots + 1), p->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, cnt.p, before.p, (int)p->n_words, p->stream));
+    hipLaunchKernelGGL(s4g::pf_slot_rank, dim3((p->n_words + 255) / 256), dim3(256), 0, p->stream, p->d_slots, p->n_words, before.p);
+    if (p->n_hash_hits)
+        hipLaunchKernelGGL(s4g::pf_bucket_bounds, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, key2.p, p->n_hash_hits,
+                           p->d_slots, p->d_bounds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));            // the temporaries above go out of scope here
@@ -153,7 +160,8 @@ int merge_candidates(s4g_prefilter* p, uint64_t* cand_key, uint32_t* cand_val, u
     return S4G_OK;
 }
 
-int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint64_t n);
+int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint32_t n_regions, uint64_t region_cap,
+                const unsigned long long* d_counters);
 int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes);
 
 // The general path: every pass through HBM.  tlist == NULL: targets 0 .. nt of the chunk, the whole prefilter in this form
@@ -162,7 +170,7 @@ int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes);
 int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, const uint32_t* tlist) {
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, tlist};
+    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, tlist};
 
     // ---- pass 0: hits per target, their offsets, down to the host (which cuts the chunk into passes) ----
     size_t cub_scan = 0;
@@ -265,7 +273,7 @@ int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* 
             uint32_t* fq = cand_val2;
             uint64_t* fsv = cand_key2;
             hipLaunchKernelGGL(s4g::pf_append, dim3((n_seg + 255) / 256), dim3(256), 0, p->stream, cand_key + slots, cand_val + slots, n_seg, fq, fsv, (uint64_t)0, (uint64_t)n_seg);
-            S4G_TRY(merge_fused(p, (char*)cub, b_cub, fq, fsv, n_seg));
+            S4G_TRY(merge_fused(p, (char*)cub, b_cub, fq, fsv, 1, n_seg, nullptr));
         }
         HIP_TRY(hipStreamSynchronize(p->stream));
         chunk_pairs += n_seg; chunk_long += p->h_flags[1];
@@ -281,31 +289,49 @@ int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* 
 
 
 // ---- the fused path ----
-// scratch of one merge: the candidates sorted by query (q2, sv2), first[nq + 1], the sort's own temporary storage
+// scratch of one merge of up to n candidates: the candidates in query order (sv2), first[nq + 1], and either the counting pass's
+// per-query counters or (more than kPfScatterMaxQ queries) the query column and the radix sort's own temporary storage
 int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes) {
     size_t cub = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr,
-                                               (uint64_t*)nullptr, (int)std::max<uint64_t>(n, 1), 0, (int)p->q_bits + 1, p->stream));
-    *bytes = align256(n * 4) + align256(n * 8) + align256(((uint64_t)p->nq + 1) * 4) + align256(cub) + 1024;
+    if (!p->scatter)
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr,
+                                                   (uint64_t*)nullptr, (int)std::max<uint64_t>(n, 1), 0, (int)p->q_bits + 1, p->stream));
+    *bytes = align256(n * 4) + align256(n * 8) + 3 * align256(((uint64_t)p->nq + 1) * 4) + align256(cub) + 1024;
     return S4G_OK;
 }
 
-// n candidates (query, ~score << 32 | id), any order -> into the running lists: one radix sort by query (q_bits bits of key),
-// then one block per query sorts its list and its new candidates in LDS and keeps the best max_c.  Asynchronous on p->stream.
-int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint64_t n) {
+// Candidates (query, ~score << 32 | id) in n_regions regions of region_cap slots (the first d_counters[8 r] of region r used; d_counters
+// == NULL: one region, all region_cap slots used), any order -> into the running lists: brought into query order by a counting pass
+// (or, beyond kPfScatterMaxQ queries, a radix sort over the whole capacity: the unused slots then must hold 0xFFFFFFFF), then one
+// block per query selects the best max_c of its list and its new candidates in LDS.  Asynchronous on p->stream.
+int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint32_t n_regions, uint64_t region_cap,
+                const unsigned long long* d_counters) {
+    const uint64_t n = (uint64_t)n_regions * region_cap;
     if (!n) return S4G_OK;
     if (n > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidates in one merge", (unsigned long long)n);
     uint64_t need = 0;
     S4G_TRY(merge_fused_bytes(p, n, &need));
     if (arena_bytes < need) return fail(S4G_ERR_INVALID, "prefilter: internal error: merge scratch of %llu bytes, %llu needed", (unsigned long long)arena_bytes, (unsigned long long)need);
     Arena A{arena};
-    uint32_t* q2 = A.take<uint32_t>(n);
     uint64_t* sv2 = A.take<uint64_t>(n);
     uint32_t* first = A.take<uint32_t>((uint64_t)p->nq + 1);
-    size_t cub = arena_bytes - A.at;
-    // (q_bits + 1 bits of key: the unused slots of the candidate regions hold 0xFFFFFFFF and sort behind every query)
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(arena + A.at, cub, cand_q, q2, cand_sv, sv2, (int)n, 0, (int)p->q_bits + 1, p->stream));
-    hipLaunchKernelGGL(s4g::pf_bucket_first, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, p->stream, q2, (uint32_t)n, p->nq, first);
+    if (p->scatter) {
+        uint32_t* q_count = A.take<uint32_t>((uint64_t)p->nq + 1);
+        uint32_t* cursor = A.take<uint32_t>((uint64_t)p->nq + 1);
+        const uint32_t tiles = (uint32_t)((region_cap + s4g::kPfTile - 1) / s4g::kPfTile);
+        const dim3 grid(n_regions * tiles), block(512);
+        const size_t lds = (size_t)p->nq * 4;
+        HIP_TRY(hipMemsetAsync(q_count, 0, ((uint64_t)p->nq + 1) * 4, p->stream));
+        hipLaunchKernelGGL(s4g::pf_cand_count, grid, block, lds, p->stream, cand_q, region_cap, d_counters, region_cap, tiles, p->nq, q_count);
+        hipLaunchKernelGGL(s4g::pf_cand_first, dim3(1), dim3(512), 0, p->stream, q_count, p->nq, first, cursor);
+        hipLaunchKernelGGL(s4g::pf_cand_scatter, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, region_cap, tiles, p->nq, cursor, sv2);
+    } else {
+        uint32_t* q2 = A.take<uint32_t>(n);
+        size_t cub = arena_bytes - A.at;
+        // (q_bits + 1 bits of key: the unused slots of the candidate regions hold 0xFFFFFFFF and sort behind every query)
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(arena + A.at, cub, cand_q, q2, cand_sv, sv2, (int)n, 0, (int)p->q_bits + 1, p->stream));
+        hipLaunchKernelGGL(s4g::pf_bucket_first, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, p->stream, q2, (uint32_t)n, p->nq, first);
+    }
     // LDS of a block: the smallest power of two that leaves a quarter of it to a slice of new candidates (5000 -> 8192 keys = 64 KB:
     // two blocks per CU)
     uint32_t keys = 1024;
@@ -318,7 +344,7 @@ int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* c
 int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, uint64_t residues) {
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_starts, p->d_present, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, nullptr};
+    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, nullptr};
     constexpr uint32_t R = s4g::kPfRegions;
     constexpr uint64_t kCounterWords = 8 * R + 8;
     unsigned long long counters[kCounterWords];
@@ -344,7 +370,7 @@ int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_
         char* scratch = p->d_work + A.at;
         HIP_TRY(hipMemsetAsync(d_counters, 0, kCounterWords * 8, p->stream));
         HIP_TRY(hipMemsetAsync(p->d_flags, 0, 16, p->stream));
-        HIP_TRY(hipMemsetAsync(cand_q, 0xFF, cand_cap * 4, p->stream));         // unused slots: a query index behind every real one
+        if (!p->scatter) HIP_TRY(hipMemsetAsync(cand_q, 0xFF, cand_cap * 4, p->stream));      // the radix merge sorts the whole capacity: unused slots behind every query
         s4g::PfFused f{c, first_id, p->nq, cand_q, cand_sv, region_cap, d_counters, overflow, p->d_flags};
         const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nt + 3) / 4, p->grid_waves / 4);
         hipLaunchKernelGGL(s4g::pf_target_lis, dim3(grid), dim3(256), 0, p->stream, f);
@@ -364,7 +390,7 @@ int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_
             ++p->stat_repeats;
             continue;
         }
-        S4G_TRY(merge_fused(p, scratch, p->work_cap - A.at, cand_q, cand_sv, cand_cap));
+        S4G_TRY(merge_fused(p, scratch, p->work_cap - A.at, cand_q, cand_sv, R, region_cap, d_counters));
         break;
     }
     p->stat_hits += n_hits; p->stat_pairs += n_cand; p->stat_long += n_long; p->stat_overflow += n_over;
@@ -447,6 +473,7 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
         p->lds_keys = 1024;
         while (p->lds_keys < 16384 && (uint64_t)p->lds_keys * 2 * 8 <= (uint64_t)lds_bytes) p->lds_keys *= 2;
         p->fused = getenv("S4G_PREFILTER_GLOBAL_SORT") == nullptr && p->q_bits + s4g::kPfOrderBits <= 32 && max_candidates <= p->lds_keys / 2;
+        p->scatter = p->fused && n_queries <= s4g::kPfScatterMaxQ && getenv("S4G_PREFILTER_RADIX_MERGE") == nullptr;
         HIP_TRY(hipMalloc((void**)&p->d_list_key, slots * 8));
         if (p->fused) {
             HIP_TRY(hipMalloc((void**)&p->d_list_cnt, (uint64_t)std::max(1u, n_queries) * 4));
@@ -608,7 +635,7 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     if (!p) return S4G_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_starts); (void)hipFree(p->d_present); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_slots); (void)hipFree(p->d_bounds); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
     (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
     if (p->h_stage) (void)hipHostFree(p->h_stage);

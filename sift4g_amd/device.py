@@ -378,6 +378,38 @@ def traceback(db, queries, scorer, pair_q, pair_t, pair_score, route=None):
                  t_end=int(out[i, 3]), path=paths[int(off[i]):int(off[i]) + int(out[i, 4])].copy()) for i in range(n)]
 
 
+class TraceJob:
+    """s4g_traceback_submit / s4g_traceback_finish (include/s4g_hip.h): the traceback of `traceback` in two halves.  The job is
+    queued at construction; result() waits for it and returns what traceback() returns, once."""
+
+    def __init__(self, db, queries, scorer, pair_q, pair_t, pair_score):
+        self.pair_q = np.ascontiguousarray(pair_q, dtype=np.uint32)
+        self.pair_t = np.ascontiguousarray(pair_t, dtype=np.uint32)
+        self.pair_score = np.ascontiguousarray(pair_score, dtype=np.int32)
+        n = self.n = len(self.pair_q)
+        cap = (np.take(queries.lengths, self.pair_q, mode="clip").astype(np.uint64) +
+               np.take(db.lengths, self.pair_t, mode="clip").astype(np.uint64)) if n else np.zeros(0, np.uint64)
+        self.off = np.zeros(n + 1, dtype=np.uint64)
+        self.off[1:] = np.cumsum(cap)
+        self._queries = queries                       # the query set must outlive the job (header); the database need not
+        self._h = ctypes.c_void_p()
+        check(lib.s4g_traceback_submit(db._h, queries._h, scorer._h, n, _ptr(self.pair_q, c_u32p), _ptr(self.pair_t, c_u32p),
+                                       _ptr(self.pair_score, c_i32p), _ptr(self.off, c_u64p), ctypes.byref(self._h)),
+              "s4g_traceback_submit")
+
+    def result(self):
+        if self._h is None:
+            raise RuntimeError("a trace job is finished exactly once")
+        n, off = self.n, self.off
+        out = np.zeros((max(n, 1), 5), dtype=np.int32)
+        paths = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+        h, self._h = self._h, None
+        check(lib.s4g_traceback_finish(h, _ptr(out, c_i32p), _ptr(paths, c_u8p)), "s4g_traceback_finish")
+        self._queries = None
+        return [dict(score=int(self.pair_score[i]), q_start=int(out[i, 0]), q_end=int(out[i, 1]), t_start=int(out[i, 2]),
+                     t_end=int(out[i, 3]), path=paths[int(off[i]):int(off[i]) + int(out[i, 4])].copy()) for i in range(n)]
+
+
 class Prefilter:
     """searchDatabase's compute on the device (database_search.cpp:66-253, hash.cpp:21-90): the queries' k-mer index, then
     database chunks in ascending id order through add(); finish() -> (ids [nq, max_candidates], counts [nq], scores) with the

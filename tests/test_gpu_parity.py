@@ -590,6 +590,51 @@ def test_device_traceback_equals_oracle(s4g, oracle_mod, blosum62, scorer):
         s4g.traceback(db, q, scorer, [0], [0], [int(scores[0, 0]) + 1])
 
 
+def test_traceback_in_two_halves_equals_the_synchronous_one(s4g, oracle_mod, blosum62, scorer):
+    """s4g_traceback_submit / s4g_traceback_finish: several jobs in flight at once, finished out of order, the database handle
+    destroyed between submit and finish (include/s4g_hip.h allows it), a score scan queued behind the jobs -- every job's
+    coordinates and paths equal s4g_traceback_host's, which test_device_traceback_equals_oracle pins to the oracle."""
+    rng = np.random.default_rng(31)
+    qs = rand_seqs(rng, 12, 30, 420)
+    ts = rand_seqs(rng, 400, 1, 500)
+    for k in range(120):
+        src = qs[k % 12]
+        cut = int(rng.integers(5, len(src) - 5))
+        ts[k] = np.concatenate([src[:cut], rand_seqs(rng, 1, 1 + k % 9, 1 + k % 9)[0], src[cut + (k % 3):]])
+    q = s4g.QuerySet(qs)
+    db = s4g.Database(ts)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    scores = s4g.scan_host(db, q, scorer)
+    assert np.array_equal(scores, exp)
+    sets = []
+    for j in range(5):
+        n = (0, 1, 64, 700, 2500)[j]
+        pq = rng.integers(0, len(qs), n); pt = rng.integers(0, len(ts), n)
+        sets.append((pq, pt, scores[pq, pt]))
+    want = [s4g.traceback(db, q, scorer, *s) for s in sets]
+    assert sum(r["score"] > 0 for w in want for r in w) > 2000
+    db2 = s4g.Database(ts)                                # its tables go away while jobs that read them are in flight
+    jobs = [s4g.TraceJob(db2 if j % 2 else db, q, scorer, *s) for j, s in enumerate(sets)]
+    del db2
+    import gc; gc.collect()
+    again = s4g.scan_host(db, q, scorer)                  # the scan's stream work and the jobs' do not disturb each other
+    assert np.array_equal(again, exp)
+    for j in (3, 0, 4, 1, 2):
+        got = jobs[j].result()
+        assert len(got) == len(want[j])
+        for r, o in zip(got, want[j]):
+            assert (r["score"], r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["score"], o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+            assert np.array_equal(r["path"], o["path"])
+    with pytest.raises(RuntimeError):
+        jobs[0].result()
+    # a wrong score surfaces at submit or at finish, never as a silently wrong path
+    with pytest.raises(Exception):
+        s4g.TraceJob(db, q, scorer, [0], [0], [int(scores[0, 0]) + 1]).result()
+    # and the library is still usable after the failed job
+    ok = s4g.TraceJob(db, q, scorer, sets[2][0], sets[2][1], sets[2][2]).result()
+    assert all(np.array_equal(r["path"], o["path"]) for r, o in zip(ok, want[2]))
+
+
 def test_packed_database_file_roundtrip(s4g, oracle_mod, blosum62, scorer, tmp_path):
     """s4g_db_save / s4g_db_load: a database placed from its packed file scans identically (full matrix, streaming
     top-k and traceback all work off the loaded tiles)."""

@@ -195,6 +195,33 @@ def test_arguments_are_checked():
     p.close()
 
 
+@pytest.mark.parametrize("mode", ["S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_GLOBAL_SORT"])
+def test_the_other_merge_paths_agree(monkeypatch, mode):
+    """the candidates reach query order by a counting pass (pf_cand_count / pf_cand_scatter) by default; the radix sort it replaced
+    (still the path beyond 8192 queries) and the all-global general passes give the same lists"""
+    queries, targets = _workload(21, 40, 6000)
+    chunks = [targets[:2500], targets[2500:2501], targets[2501:]]
+    base, ref, stats = _both(queries, chunks, 5, 60)
+    _assert_equal(base, ref)
+    assert stats["fused"]
+    monkeypatch.setenv(mode, "1")
+    other, ref2, stats2 = _both(queries, chunks, 5, 60)
+    _assert_equal(other, ref2)
+    assert stats2["fused"] == (mode == "S4G_PREFILTER_RADIX_MERGE")
+
+
+def test_more_queries_than_the_counting_pass_holds():
+    """9000 short queries: beyond kPfScatterMaxQ the merge falls back to the radix sort over the candidate regions"""
+    rng = np.random.default_rng(22)
+    queries = [rng.integers(0, 20, size=int(n)).astype(np.uint8) for n in rng.integers(5, 14, size=9000)]
+    targets = [rng.integers(0, 20, size=int(n)).astype(np.uint8) for n in rng.integers(3, 300, size=800)]
+    for i in range(0, 800, 7):
+        targets[i] = np.concatenate([targets[i], queries[(i * 13) % 9000], queries[(i * 29) % 9000]])
+    dev, ref, stats = _both(queries, [targets[:300], targets[300:]], 4, 25)
+    _assert_equal(dev, ref)
+    assert stats["fused"]
+
+
 def test_chunk_already_on_the_device():
     import torch
     import oracle
