@@ -105,4 +105,11 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean dropin dropin-batched dropin-fullscan dropin-devsearch dropin-prefilter-dump
+.PHONY: all oracle isa clean pf-timing dropin dropin-batched dropin-fullscan dropin-devsearch dropin-prefilter-dump
+
+# A measuring build of the library: pf_target_lis with shader-clock counters per section (kmer_prefilter.hip.h: PF_TIMING), printed per
+# chunk on stderr.  S4G_LIB=build/pf_timing/libs4g_hip.so python tools/prefilter_call_probe.py
+pf-timing: $(LIBDIR)/libs4g_hip.so
+	@mkdir -p build/pf_timing
+	$(HIPCC) $(HIPFLAGS) -DPF_TIMING -Iinclude -c $(CSRC)/s4g_prefilter.hip -o build/pf_timing/s4g_prefilter.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/pf_timing/libs4g_hip.so $(filter-out build/obj/s4g_prefilter.o,$(HIPOBJ)) build/pf_timing/s4g_prefilter.o -ldl

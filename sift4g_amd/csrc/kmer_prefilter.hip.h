@@ -47,19 +47,23 @@ constexpr uint32_t kPfSmallMax = 32;            // longest segment a single thre
 constexpr uint32_t kPfLdsTails = 4096;          // tails a wave keeps in LDS (16 KB)
 constexpr uint64_t kPfNoEntry = ~0ull;          // empty slot of a candidate list: sorts behind everything
 
-// the k-mer starting at codes[j] (hash.cpp:33-43: ((kmer << 5) | code) & mask, most significant residue first)
+// the k-mer starting at codes[j] (hash.cpp:33-43: ((kmer << 5) | code) & mask, most significant residue first) -- as a number in the
+// index's own radix: letter[code] = rank of the code among the codes the QUERIES use, every other code = one shared digit behind them
+// (a k-mer with such a digit is in no query and in no slot; two different k-mers may then share a number, but neither has a hit), so that
+// the index is as dense as the queries' alphabet allows: 21^5 / 32 slots of 8 bytes = 1 MB for twenty amino acids instead of 32^5 / 32 = 8 MB
+// of which every 128-byte line holds 7 or 13 live slots.  All 32 codes in use: radix 32, letter = code, the reference's own number.
 // (codes are cut to 5 bits: a code of 32 or more is reported through the `bad` flag, and must not index past the tables first)
-__device__ __forceinline__ uint32_t pf_kmer(const uint8_t* __restrict__ c, uint32_t k) {
+__device__ __forceinline__ uint32_t pf_kmer(const uint8_t* __restrict__ c, uint32_t k, const uint8_t* __restrict__ letter, uint32_t radix) {
     uint32_t v = 0;
-    for (uint32_t i = 0; i < k; ++i) v = (v << kKmerBits) | (c[i] & 31u);
+    for (uint32_t i = 0; i < k; ++i) v = v * radix + letter[c[i] & 31u];
     return v;
 }
 
 // One thread per query residue g (flat over all queries).  key[g] = k-mer starting there, or the invalid key 1 << 5k when fewer
-// than k residues are left in that query; val[g] = g; pos_q[g] / pos_j[g] = query index / position of g; the k-mer's bit set in its
-// index slot (slots[kmer >> 5].x).
+// than k residues are left in that query (radix^k: behind every real one); val[g] = g; pos_q[g] / pos_j[g] = query index / position
+// of g; the k-mer's bit set in its index slot (slots[kmer >> 5].x).
 __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ off, uint32_t nq, uint64_t total,
-                               uint32_t k, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos_q,
+                               uint32_t k, const uint8_t* __restrict__ letter, uint32_t radix, uint32_t invalid_key, uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ pos_q,
                                uint32_t* __restrict__ pos_j, uint2* __restrict__ slots, unsigned* __restrict__ bad) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -70,11 +74,11 @@ __global__ void pf_query_kmers(const uint8_t* __restrict__ codes, const uint64_t
     pos_q[g] = lo; pos_j[g] = j; val[g] = (uint32_t)g;
     if (codes[g] >= 32) atomicOr(bad, 1u);
     if (j + k <= len) {
-        const uint32_t v = pf_kmer(codes + g, k);
+        const uint32_t v = pf_kmer(codes + g, k, letter, radix);
         key[g] = v;
         atomicOr(&slots[v >> 5].x, 1u << (v & 31));
     } else {
-        key[g] = 1u << (k * kKmerBits);
+        key[g] = invalid_key;
     }
 }
 
@@ -100,13 +104,24 @@ __global__ void pf_slot_rank(uint2* __restrict__ slots, uint32_t n_words, const 
     if (w < n_words) slots[w].y = before[w];
 }
 __device__ __forceinline__ uint32_t pf_rank(uint2 slot, uint32_t v) { return slot.y + (uint32_t)__popc(slot.x & ((1u << (v & 31)) - 1u)); }
-// bounds[r] = first hit of the r-th present k-mer in the k-mer-sorted hit list, bounds[number of present k-mers] = n_hits
-__global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, uint64_t n_hits, const uint2* __restrict__ slots, uint32_t* __restrict__ bounds) {
+// bounds[r] = first hit of the r-th present k-mer in the k-mer-sorted hit list, bounds[number of present k-mers] = n_hits;
+// fhit[r] = that first hit itself, position << f_q_bits | query, with bit 31 set when the bucket holds more than it (two k-mers in three
+// occur once in a thousand queries: their lookup ends here, in a 4-byte table of 1.3 MB).  f_q_bits = 0: positions and queries do not
+// fit 31 bits together; every entry then says "more" and the bucket is read through bounds / hit_qp.
+constexpr uint32_t kPfMore = 0x80000000u;
+__global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ pos_q,
+                                 const uint32_t* __restrict__ pos_j, uint64_t n_hits, const uint2* __restrict__ slots, uint32_t f_q_bits,
+                                 uint32_t* __restrict__ bounds, uint32_t* __restrict__ fhit) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint32_t v = sorted_key[i];
     const uint32_t r = pf_rank(slots[v >> 5], v);
-    if (i == 0 || sorted_key[i - 1] != v) bounds[r] = (uint32_t)i;
+    if (i == 0 || sorted_key[i - 1] != v) {
+        bounds[r] = (uint32_t)i;
+        const uint32_t g = sorted_val[i];
+        const bool more = f_q_bits == 0 || (i + 1 < n_hits && sorted_key[i + 1] == v);
+        fhit[r] = more ? kPfMore : (pos_j[g] << f_q_bits) | pos_q[g];
+    }
     if (i + 1 == n_hits) bounds[r + 1] = (uint32_t)n_hits;
 }
 
@@ -115,6 +130,9 @@ struct PfChunk {
     const uint64_t* off;        // [nt + 1]
     const uint2* slots;         // [32^k / 32] (presence bits, present k-mers before the word): nine lookups in ten end here
     const uint32_t* bounds;     // [present k-mers + 1] CSR bounds of the queries' k-mers, by rank
+    const uint32_t* fhit;       // [present k-mers] first hit of the bucket, packed, or kPfMore (pf_bucket_bounds)
+    const uint8_t* letter;      // [32] code -> digit of the index's radix (pf_kmer)
+    uint32_t radix, f_q_bits;
     const uint32_t* hit_q;      // bucket contents
     const uint32_t* hit_p;
     const uint64_t* hit_qp;     // the same, interleaved: position << 32 | query (one load per hit in the fused path)
@@ -126,11 +144,8 @@ __device__ __forceinline__ uint32_t pf_target(const PfChunk& a, uint32_t i) { re
 // number of hits the k-mer at position j of a target contributes, and where its bucket starts
 __device__ __forceinline__ uint32_t pf_bucket(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t j, uint32_t n_kmers, uint32_t* first) {
     if (j >= n_kmers) return 0;
-    const uint32_t v = pf_kmer(c + j, a.k);
-    if (j != 0) {                                                       // database_search.cpp:212: equal to the k-mer before it
-        const uint32_t prev = ((uint32_t)(c[j - 1] & 31u) << ((a.k - 1) * kKmerBits)) | (v >> kKmerBits);
-        if (prev == v) return 0;
-    }
+    const uint32_t v = pf_kmer(c + j, a.k, a.letter, a.radix);
+    if (j != 0 && pf_kmer(c + j - 1, a.k, a.letter, a.radix) == v) return 0;       // database_search.cpp:212: equal to the k-mer before it
     const uint2 slot = a.slots[v >> 5];
     if (!((slot.x >> (v & 31)) & 1u)) return 0;
     const uint32_t r = pf_rank(slot, v);
@@ -313,6 +328,26 @@ constexpr uint32_t kPfRegions = 64;            // the candidate array is cut int
                                                 // (a line apart): 100 000 waves reserving slots through ONE counter spent a quarter of the
                                                 // kernel waiting for that atomic
 
+// -DPF_TIMING: shader clocks per section of pf_target_lis, summed over the waves (a measuring build: `make pf-timing`, tools/README.md):
+// [0] index lookups of a target's first 256 positions (issued ahead), [1] collecting the hits into LDS (+ lookups beyond 256), [2] the
+// sort, [3] segment count + slot reservation, [4] the LIS of the short segments + candidates out, [5] long segments, [6] targets walked
+// once per range of queries, [7] everything else
+#ifdef PF_TIMING
+__device__ unsigned long long pf_times[8];
+struct PfClock {
+    unsigned long long t, acc[8];
+    __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); for (int i = 0; i < 8; ++i) acc[i] = 0; }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
+    __device__ __forceinline__ void flush(uint32_t lane) { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&pf_times[i], acc[i]); }
+};
+#else
+struct PfClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(uint32_t) {}
+};
+#endif
+
 struct PfFused {
     PfChunk c;
     uint32_t first_id, nq;
@@ -332,27 +367,29 @@ struct PfFused {
 __device__ __forceinline__ void pf_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Buckets of four chunks of 64 positions from `base`: lane l gets those of positions base + 64 u + l (u = 0..3).  One byte per
-// lane and chunk comes from memory, the k-mers are put together from the neighbours' bytes (shuffles), and the dependent rounds of
-// loads -- residues, index slot, bucket bounds, the bucket's first hit -- are each issued for all four chunks before any is
-// waited for.  hq / hp: query and position of the bucket's first hit (most buckets hold exactly one).
+// lane and chunk comes from memory, the k-mers are put together from the neighbours' digits (shuffles), and the dependent rounds of
+// loads -- residues, index slot, the bucket's first hit -- are each issued for all four chunks before any is waited for; a bucket
+// of several hits (kPfMore) costs two more rounds, bounds and its first entry.  hq / hp: query and position of the bucket's first hit.
+// letter: the radix digits of the 32 codes, in LDS.
 struct PfBlock { uint32_t first[4], n[4], hq[4], hp[4]; };
 __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t base,
-                                            uint32_t lane, PfBlock& blk, unsigned& wrong) {
+                                            uint32_t lane, PfBlock& blk, unsigned& wrong, const uint8_t* letter) {
     uint32_t (&first)[4] = blk.first; uint32_t (&n)[4] = blk.n; uint32_t (&hq)[4] = blk.hq; uint32_t (&hp)[4] = blk.hp;
-    uint32_t carry = base ? pf_kmer(c + base - 1, a.k) : 0xFFFFFFFFu;   // the k-mer before this block's first (the "equal to its predecessor" rule)
+    uint32_t carry = base ? pf_kmer(c + base - 1, a.k, letter, a.radix) : 0xFFFFFFFFu;   // the k-mer before this block's first (the "equal to its predecessor" rule)
     uint32_t b[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) { const uint32_t j = base + 64 * u + lane; b[u] = (j < len && (u < 4 || lane < 8)) ? c[j] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { if (b[u] >= 32) wrong = 1; b[u] = letter[b[u] & 31u]; }
     uint32_t v[4];
     bool look[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        if (b[u] >= 32) wrong = 1;
         uint32_t x = 0;
-        for (uint32_t i = 0; i < a.k; ++i) {            // byte of position j + i: lane + i of this chunk, or of the next one
+        for (uint32_t i = 0; i < a.k; ++i) {            // digit of position j + i: lane + i of this chunk, or of the next one
             const uint32_t src = lane + i;
             const uint32_t own = (uint32_t)__shfl((int)b[u], (int)(src & 63), 64), nxt = (uint32_t)__shfl((int)b[u + 1], (int)(src & 63), 64);
-            x = (x << kKmerBits) | ((src < 64 ? own : nxt) & 31u);
+            x = x * a.radix + (src < 64 ? own : nxt);
         }
         v[u] = x;
         uint32_t prev = (uint32_t)__shfl_up((int)x, 1, 64);
@@ -364,18 +401,37 @@ __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __r
     uint2 slot[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) slot[u] = look[u] ? a.slots[v[u] >> 5] : make_uint2(0u, 0u);
-    uint32_t s0[4], s1[4];
+    uint32_t r[4], f[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         look[u] = look[u] && ((slot[u].x >> (v[u] & 31)) & 1u);
-        uint64_t se = 0;                                             // bounds[r], bounds[r + 1]: one 8-byte load (4-byte aligned)
-        if (look[u]) __builtin_memcpy(&se, a.bounds + pf_rank(slot[u], v[u]), 8);
-        s0[u] = (uint32_t)se; s1[u] = (uint32_t)(se >> 32);
+        r[u] = pf_rank(slot[u], v[u]);
+        f[u] = look[u] ? a.fhit[r[u]] : 0u;
     }
+    const uint32_t q_mask = (1u << a.f_q_bits) - 1u;
+    bool more = false;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { first[u] = s0[u]; n[u] = s1[u] - s0[u]; }
+    for (int u = 0; u < 4; ++u) {
+        first[u] = 0; n[u] = look[u] ? 1u : 0u;
+        hq[u] = f[u] & q_mask; hp[u] = (f[u] & ~kPfMore) >> a.f_q_bits;
+        more = more || (f[u] & kPfMore);
+    }
+    if (__ballot(more)) {                                            // (uniform: the rare rounds are skipped by the whole wave)
+        uint32_t s0[4], s1[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const uint64_t qp = n[u] ? a.hit_qp[first[u]] : 0ull; hq[u] = (uint32_t)qp; hp[u] = (uint32_t)(qp >> 32); }
+        for (int u = 0; u < 4; ++u) {
+            uint64_t se = 0;                                         // bounds[r], bounds[r + 1]: one 8-byte load (4-byte aligned)
+            if (f[u] & kPfMore) __builtin_memcpy(&se, a.bounds + r[u], 8);
+            s0[u] = (uint32_t)se; s1[u] = (uint32_t)(se >> 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (f[u] & kPfMore) {
+                first[u] = s0[u]; n[u] = s1[u] - s0[u];
+                const uint64_t qp = a.hit_qp[first[u]];
+                hq[u] = (uint32_t)qp; hp[u] = (uint32_t)(qp >> 32);
+            }
+    }
 }
 
 // One sweep over a target: its hits with a query in [qa, qb) (FILTER) or all of them go into key / pos in the order the reference
@@ -384,12 +440,12 @@ __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __r
 template <bool FILTER>
 __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t lane,
                                                uint32_t qa, uint32_t qb, uint32_t* key, uint32_t* pos, bool* fits, unsigned& wrong,
-                                               const PfBlock* block0) {      // block0: the buckets of positions 0 .. 255, if the caller has them
+                                               const PfBlock* block0, const uint8_t* letter) {      // block0: the buckets of positions 0 .. 255, if the caller has them
     uint64_t out = 0;
     bool ok = true;
     for (uint32_t base = 0; base < n_kmers; base += 256) {
         PfBlock blk;
-        if (base == 0 && block0) blk = *block0; else pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong);
+        if (base == 0 && block0) blk = *block0; else pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong, letter);
         uint32_t (&first)[4] = blk.first; uint32_t (&n)[4] = blk.n; uint32_t (&hq)[4] = blk.hq; uint32_t (&hp)[4] = blk.hp;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -419,7 +475,7 @@ __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t*
 
 // The `total` hits in key / pos: sorted by (query, order), cut into segments, the LIS of every segment, one candidate each.
 __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uint32_t lane, uint32_t region, uint32_t* key, const uint32_t* pos,
-                                           int32_t* tail, uint32_t* lng, float flen, uint32_t id, unsigned long long& sum_long) {
+                                           int32_t* tail, uint32_t* lng, float flen, uint32_t id, unsigned long long& sum_long, PfClock& ck) {
     uint32_t m = 64;                                         // sort size: a power of two >= total
     while (m < total) m <<= 1;
     for (uint32_t i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
@@ -436,6 +492,7 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
             }
             pf_lds_fence();
         }
+    ck.mark(2);
     // ---- segments = runs of one query; count them, reserve their candidates with one atomic on the wave's region ----
     uint32_t n_seg = 0;
     for (uint32_t base = 0; base < total; base += 64) {
@@ -454,6 +511,7 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
         a.cand_q[region_base + slot] = q;
         a.cand_sv[region_base + slot] = ((uint64_t)(uint32_t)~__float_as_uint(score) << 32) | id;
     };
+    ck.mark(3);
     // ---- the LIS of every segment: a lane per segment of up to kPfSmallMax hits ----
     uint32_t rank0 = 0;
     for (uint32_t base = 0; base < total; base += 64) {
@@ -505,6 +563,7 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
         }
     }
     pf_lds_fence();
+    ck.mark(4);
     // ---- long segments, the whole wave on each.  The tails live in REGISTERS, tail l in lane l % 64 of register l / 64 (eight
     //      registers: kPfCap tails), unused ones at +infinity: the number of tails below x is eight ballots and their popcounts, the
     //      update one predicated move -- no LDS round trip inside the dependent chain (with tails in LDS a hit cost ~300 clocks) ----
@@ -535,6 +594,7 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
         if (lane == 0) emit(key[i0] >> kPfOrderBits, llen, slot0 + rank);
     }
     pf_lds_fence();
+    ck.mark(5);
 }
 
 // One wave per target (grid-stride).  See the header of this file.
@@ -543,6 +603,10 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
     __shared__ uint32_t s_pos[4][kPfCap];       // query position of the hit with order index i
     __shared__ int32_t s_tail[4][kPfCap];       // LIS tails: a segment that starts at sorted position i uses [i, i + its length)
     __shared__ uint32_t s_misc[4][kPfMaxLong * 3 + 1 + kPfRanges];     // [0] count, then (start, length, rank) of long segments; the range histogram
+    __shared__ uint8_t s_letter[32];
+    if (threadIdx.x < 32) s_letter[threadIdx.x] = a.c.letter[threadIdx.x];
+    __syncthreads();
+    const uint8_t* letter = s_letter;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t* key = s_key[wv];
     uint32_t* pos = s_pos[wv];
@@ -561,9 +625,11 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
     PfBlock ahead;
     uint64_t o_next = 0;
     uint32_t len_next = 0;
+    PfClock ck;
+    ck.start();
     if (wave_id < c0.nt) {
         o_next = c0.off[wave_id]; len_next = (uint32_t)(c0.off[wave_id + 1] - o_next);
-        pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong);
+        pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong, letter);
     }
     for (uint32_t t = wave_id; t < c0.nt; t += waves) {
         const uint64_t o = o_next;
@@ -575,14 +641,17 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
         const uint32_t id = a.first_id + t;
         bool fits = false;
         const PfBlock mine_block = ahead;
-        const uint64_t total64 = pf_collect<false>(c0, c, len, n_kmers, lane, 0u, 0xFFFFFFFFu, key, pos, &fits, wrong, n_kmers ? &mine_block : nullptr);
+        ck.mark(7);
+        const uint64_t total64 = pf_collect<false>(c0, c, len, n_kmers, lane, 0u, 0xFFFFFFFFu, key, pos, &fits, wrong, n_kmers ? &mine_block : nullptr, letter);
+        ck.mark(1);
         if (t + waves < c0.nt) {
             o_next = c0.off[t + waves]; len_next = (uint32_t)(c0.off[t + waves + 1] - o_next);
-            pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong);
+            pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong, letter);
         }
+        ck.mark(0);
         if (total64 == 0) continue;
         sum_hits += total64;
-        if (fits) { pf_process(a, (uint32_t)total64, lane, region, key, pos, tail, lng, flen, id, sum_long); continue; }
+        if (fits) { pf_process(a, (uint32_t)total64, lane, region, key, pos, tail, lng, flen, id, sum_long, ck); continue; }
         // ---- more hits than a wave keeps: once per range of queries.  Histogram of the hits over kPfRanges slices of the query
         //      indices, consecutive slices grouped into passes of at most kPfCap hits ----
         pf_lds_fence();
@@ -590,7 +659,7 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
         pf_lds_fence();
         for (uint32_t base = 0; base < n_kmers; base += 256) {
             PfBlock blk;
-            pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong);
+            pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong, letter);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 for (uint32_t h = 0; h < blk.n[u]; ++h) atomicAdd(&hist[(h ? (uint32_t)c0.hit_qp[blk.first[u] + h] : blk.hq[u]) / q_per_range], 1u);
@@ -606,10 +675,13 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
             const uint32_t qa = r0 * q_per_range, qb = r1 * q_per_range;
             r0 = r1;
             if (acc == 0) continue;
-            const uint64_t tot = pf_collect<true>(c0, c, len, n_kmers, lane, qa, qb, key, pos, &fits, wrong, nullptr);
-            if (tot) pf_process(a, (uint32_t)tot, lane, region, key, pos, tail, lng, flen, id, sum_long);
+            const uint64_t tot = pf_collect<true>(c0, c, len, n_kmers, lane, qa, qb, key, pos, &fits, wrong, nullptr, letter);
+            if (tot) pf_process(a, (uint32_t)tot, lane, region, key, pos, tail, lng, flen, id, sum_long, ck);
         }
+        ck.mark(6);
     }
+    ck.mark(7);
+    ck.flush(lane);
     if (lane == 0) {
         if (sum_hits) atomicAdd(&a.counters[8 * kPfRegions + 0], sum_hits);
         if (sum_long) atomicAdd(&a.counters[8 * kPfRegions + 1], sum_long);
@@ -709,30 +781,44 @@ __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ lis
 
 // ---- candidates into query order by one counting pass (up to kPfScatterMaxQ queries: a block keeps a counter per query in LDS) ----
 // The candidates sit in n_regions regions of region_cap slots, the first counters[8 r] of region r used (counters == NULL: one
-// region with `single_n` used slots).  A block takes a tile of kPfTile slots of one region.
+// region with `single_n` used slots).  A block takes a tile of kPfTile USED slots, counted through the regions in order.
 constexpr uint32_t kPfScatterMaxQ = 8192;
-constexpr uint32_t kPfTile = 16384;             // a thousand queries: ~16 candidates = 128 bytes per query and tile leave a block together
+constexpr uint32_t kPfTile = 32768;             // a thousand queries: ~32 candidates = 256 bytes per query and tile leave a block together
 
-__device__ __forceinline__ bool pf_tile(uint64_t region_cap, const unsigned long long* __restrict__ counters, uint64_t single_n,
-                                        uint32_t tiles_per_region, uint64_t* b, uint64_t* e) {
-    const uint32_t r = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
-    const uint64_t used = counters ? min((uint64_t)counters[8 * r], region_cap) : single_n;
-    const uint64_t lo = (uint64_t)tile * kPfTile;
-    if (lo >= used) return false;
-    *b = (uint64_t)r * region_cap + lo;
-    *e = (uint64_t)r * region_cap + min(used, lo + kPfTile);
-    return true;
+// use(load(physical index)) for every used slot of this block's tile, eight loads in flight per thread (a loop of load -> LDS atomic
+// runs at one memory latency per candidate); pre: LDS words for n_regions + 1 prefix sums
+template <typename T, typename L, typename U>
+__device__ __forceinline__ void pf_tile_for_each(uint64_t region_cap, const unsigned long long* __restrict__ counters, uint32_t n_regions,
+                                                 uint64_t single_n, uint64_t* prefix, L load, U use) {
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t r = 0; r < n_regions; ++r) { prefix[r] = acc; acc += counters ? min((uint64_t)counters[8 * r], region_cap) : single_n; }
+        prefix[n_regions] = acc;
+    }
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * kPfTile, hi = min(prefix[n_regions], lo + kPfTile);
+    for (uint32_t r = 0; r < n_regions; ++r) {
+        const uint64_t a = max(lo, prefix[r]), b = min(hi, prefix[r + 1]);          // (block-uniform)
+        if (a >= b) continue;
+        const uint64_t shift = (uint64_t)r * region_cap - prefix[r];
+        for (uint64_t i = a + threadIdx.x; i < b; i += 8 * blockDim.x) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i + u * blockDim.x < b) v[u] = load(i + u * blockDim.x + shift);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i + u * blockDim.x < b) use(v[u]);
+        }
+    }
 }
 
 // q_count[q] += candidates of query q
 __global__ __launch_bounds__(512) void pf_cand_count(const uint32_t* __restrict__ cand_q, uint64_t region_cap, const unsigned long long* __restrict__ counters,
-                                                     uint64_t single_n, uint32_t tiles_per_region, uint32_t nq, uint32_t* __restrict__ q_count) {
+                                                     uint32_t n_regions, uint64_t single_n, uint32_t nq, uint32_t* __restrict__ q_count) {
     extern __shared__ uint32_t pf_h[];
-    uint64_t b, e;
-    if (!pf_tile(region_cap, counters, single_n, tiles_per_region, &b, &e)) return;     // (block-uniform)
+    __shared__ uint64_t prefix[kPfRegions + 1];
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
-    __syncthreads();
-    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&pf_h[cand_q[i]], 1u);
+    pf_tile_for_each<uint32_t>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return cand_q[i]; },
+                               [&](uint32_t q) { atomicAdd(&pf_h[q], 1u); });
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) atomicAdd(&q_count[q], c); }
 }
@@ -759,19 +845,19 @@ __global__ __launch_bounds__(512) void pf_cand_first(const uint32_t* __restrict_
 
 // out[first[q] ..] = the (score, id) words of query q's candidates, in no particular order
 __global__ __launch_bounds__(512) void pf_cand_scatter(const uint32_t* __restrict__ cand_q, const uint64_t* __restrict__ cand_sv, uint64_t region_cap,
-                                                       const unsigned long long* __restrict__ counters, uint64_t single_n, uint32_t tiles_per_region,
+                                                       const unsigned long long* __restrict__ counters, uint32_t n_regions, uint64_t single_n,
                                                        uint32_t nq, uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
     extern __shared__ uint32_t pf_h[];
-    uint64_t b, e;
-    if (!pf_tile(region_cap, counters, single_n, tiles_per_region, &b, &e)) return;
+    __shared__ uint64_t prefix[kPfRegions + 1];
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
-    __syncthreads();
-    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&pf_h[cand_q[i]], 1u);
+    pf_tile_for_each<uint32_t>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return cand_q[i]; },
+                               [&](uint32_t q) { atomicAdd(&pf_h[q], 1u); });
     __syncthreads();
     // the tile's share of every query's range, reserved with one atomic per query that occurs; the counter then becomes the write position
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) pf_h[q] = atomicAdd(&cursor[q], c); }
-    __syncthreads();
-    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) out[atomicAdd(&pf_h[cand_q[i]], 1u)] = cand_sv[i];
+    struct QS { uint32_t q; uint64_t sv; };
+    pf_tile_for_each<QS>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return QS{cand_q[i], cand_sv[i]}; },
+                         [&](const QS& c) { out[atomicAdd(&pf_h[c.q], 1u)] = c.sv; });
 }
 
 // first[q] = index of the first candidate of query q in the query-sorted array (first[nq] = n): one thread per candidate boundary

@@ -28,7 +28,11 @@ struct s4g_prefilter {
     uint32_t nq = 0, k = 0, max_c = 0;
     uint32_t q_bits = 1;            // bits of a query index inside a hit key
     uint32_t list_q_bits = 1;       // bits of the query field of a candidate key that take part in the sort (covers the empty mark)
-    uint32_t n_words = 0;           // 32^k / 32 index slots
+    uint32_t n_words = 0;           // radix^k / 32 index slots
+    uint32_t radix = 32;            // digits of a k-mer's number: the codes the queries use + one for all others (kmer_prefilter.hip.h: pf_kmer)
+    uint32_t f_q_bits = 0;          // packing of d_fhit (0: unused, every bucket through d_bounds)
+    uint8_t* d_letter = nullptr;    // [32] code -> digit
+    uint32_t* d_fhit = nullptr;     // [n_hash_hits + 1] first hit of the present k-mers, by rank
     hipStream_t stream = nullptr;
     uint2* d_slots = nullptr;       // [n_words] (presence bits, present k-mers before the word)   (kmer_prefilter.hip.h)
     uint32_t* d_bounds = nullptr;   // [n_hash_hits + 2] bucket bounds of the present k-mers, by rank
@@ -88,20 +92,44 @@ struct Arena {
 
 // Builds the CSR index of the queries' k-mers on the device (hash.cpp:56-85).
 int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
+    const auto t_index0 = Clock::now();
     const uint64_t total = off[p->nq] - off[0];
-    p->n_words = (uint32_t)((1ull << (p->k * s4g::kKmerBits)) >> 5);
+    // the index's radix: one digit per code that occurs in a query (in code order), one more for every other code
+    uint8_t letter[32];
+    {
+        bool used[32] = {};
+        parallel_for(total, parallel_parts(total, 1u << 22), [&](unsigned, unsigned, uint64_t b, uint64_t e) {
+            bool mine[32] = {};
+            for (uint64_t i = b; i < e; ++i) mine[codes[off[0] + i] & 31u] = true;
+            for (int c = 0; c < 32; ++c) if (mine[c]) __atomic_store_n(&used[c], true, __ATOMIC_RELAXED);
+        });
+        uint32_t n_used = 0;
+        for (int c = 0; c < 32; ++c) n_used += used[c];
+        if (n_used >= 31) { p->radix = 32; for (int c = 0; c < 32; ++c) letter[c] = (uint8_t)c; }
+        else { p->radix = n_used + 1; uint32_t d = 0; for (int c = 0; c < 32; ++c) letter[c] = (uint8_t)(used[c] ? d++ : n_used); }
+    }
+    uint64_t n_kmer_values = 1;
+    for (uint32_t i = 0; i < p->k; ++i) n_kmer_values *= p->radix;
+    const uint32_t invalid_key = (uint32_t)n_kmer_values;            // sorts behind every real k-mer
+    const int key_bits = (int)bits_for(n_kmer_values + 1);
+    p->n_words = (uint32_t)(n_kmer_values / 32 + 1);
+    HIP_TRY(hipMalloc((void**)&p->d_letter, 32));
+    HIP_TRY(hipMemcpyAsync(p->d_letter, letter, 32, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc((void**)&p->d_q_kmers, (uint64_t)std::max(1u, p->nq) * 4));
     HIP_TRY(hipMalloc((void**)&p->d_slots, (uint64_t)p->n_words * 8));
     HIP_TRY(hipMemsetAsync(p->d_slots, 0, (uint64_t)p->n_words * 8, p->stream));
     std::vector<uint32_t> q_kmers(std::max(1u, p->nq), 0);
     std::vector<uint64_t> rel(p->nq + 1);
+    uint64_t longest = 0;
     for (uint32_t q = 0; q <= p->nq; ++q) rel[q] = off[q] - off[0];
     for (uint32_t q = 0; q < p->nq; ++q) {
         const uint64_t len = off[q + 1] - off[q];
         if (off[q + 1] < off[q] || len > 0x7FFFFFF0ull) return fail(S4G_ERR_INVALID, "bad query offsets at %u", q);
         q_kmers[q] = len >= p->k ? (uint32_t)(len - p->k + 1) : 0;
         p->n_hash_hits += q_kmers[q];
+        longest = std::max(longest, len);
     }
+    p->f_q_bits = p->q_bits + bits_for(longest + 1) <= 31 ? p->q_bits : 0;
     if (total >= (1ull << 32)) return fail(S4G_ERR_INVALID, "prefilter: more than 2^32 query residues");
     HIP_TRY(hipMemcpyAsync(p->d_q_kmers, q_kmers.data(), q_kmers.size() * 4, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc((void**)&p->d_hit_q, std::max<uint64_t>(1, p->n_hash_hits) * 4));
@@ -109,12 +137,13 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     HIP_TRY(hipMalloc((void**)&p->d_hit_qp, std::max<uint64_t>(1, p->n_hash_hits) * 8));
     HIP_TRY(hipMalloc((void**)&p->d_bounds, (p->n_hash_hits + 2) * 4));
     HIP_TRY(hipMemsetAsync(p->d_bounds, 0, (p->n_hash_hits + 2) * 4, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_fhit, (p->n_hash_hits + 1) * 4));
     DevBuf<uint32_t> cnt, before;                        // per index word: present k-mers in it, and before it
     HIP_TRY(cnt.alloc(p->n_words)); HIP_TRY(before.alloc(p->n_words));
     size_t cub_scan = 0, cub_sort = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)p->n_words, p->stream));
     if (total) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                          (uint32_t*)nullptr, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
+                                                          (uint32_t*)nullptr, (int)total, 0, key_bits, p->stream));
     DevBuf<char> tmp;
     HIP_TRY(tmp.alloc(std::max(cub_scan, cub_sort)));
     DevBuf<uint8_t> d_codes; DevBuf<uint64_t> d_off; DevBuf<uint32_t> key, val, key2, val2, pos_q, pos_j;
@@ -125,24 +154,28 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
         HIP_TRY(hipMemcpyAsync(d_codes.p, codes + off[0], total, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, p->stream));
         hipLaunchKernelGGL(s4g::pf_query_kmers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, d_codes.p, d_off.p, p->nq, total, p->k,
-                           key.p, val.p, pos_q.p, pos_j.p, p->d_slots, p->d_flags);
+                           p->d_letter, p->radix, invalid_key, key.p, val.p, pos_q.p, pos_j.p, p->d_slots, p->d_flags);
         size_t t = std::max(cub_scan, cub_sort);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, (int)(p->k * s4g::kKmerBits + 1), p->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, key2.p, val.p, val2.p, (int)total, 0, key_bits, p->stream));
         if (p->n_hash_hits)
             hipLaunchKernelGGL(s4g::pf_hash_hits, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, val2.p, pos_q.p, pos_j.p,
                                p->n_hash_hits, p->d_hit_q, p->d_hit_p, p->d_hit_qp);
     }
+    const auto t_queued = Clock::now();
     // ranks of the present k-mers, then the bucket bounds by rank (the k-mers without a full window sorted behind the n_hash_hits real ones)
     hipLaunchKernelGGL(s4g::pf_slot_count, dim3((p->n_words + 255) / 256), dim3(256), 0, p->stream, p->d_slots, p->n_words, cnt.p);
     size_t t = std::max(cub_scan, cub_sort);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, cnt.p, before.p, (int)p->n_words, p->stream));
     hipLaunchKernelGGL(s4g::pf_slot_rank, dim3((p->n_words + 255) / 256), dim3(256), 0, p->stream, p->d_slots, p->n_words, before.p);
     if (p->n_hash_hits)
-        hipLaunchKernelGGL(s4g::pf_bucket_bounds, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, key2.p, p->n_hash_hits,
-                           p->d_slots, p->d_bounds);
+        hipLaunchKernelGGL(s4g::pf_bucket_bounds, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, key2.p, val2.p, pos_q.p, pos_j.p,
+                           p->n_hash_hits, p->d_slots, p->f_q_bits, p->d_bounds, p->d_fhit);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));            // the temporaries above go out of scope here
+    if (getenv("S4G_PROFILE"))
+        fprintf(stderr, "[s4g profile] prefilter index: radix %u, %u slots, allocations + uploads + first kernels queued %.0f us, rest + wait %.0f us\n",
+                p->radix, p->n_words, us(t_index0, t_queued), us(t_queued, Clock::now()));
     if (p->h_flags[0]) return fail(S4G_ERR_INVALID, "prefilter: query residue code out of range (5-bit codes, hash.cpp:16-17)");
     return S4G_OK;
 }
@@ -161,7 +194,7 @@ int merge_candidates(s4g_prefilter* p, uint64_t* cand_key, uint32_t* cand_val, u
 }
 
 int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint32_t n_regions, uint64_t region_cap,
-                const unsigned long long* d_counters);
+                const unsigned long long* d_counters, uint64_t n_used);
 int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes);
 
 // The general path: every pass through HBM.  tlist == NULL: targets 0 .. nt of the chunk, the whole prefilter in this form
@@ -170,7 +203,7 @@ int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes);
 int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, const uint32_t* tlist) {
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, tlist};
+    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_fhit, p->d_letter, p->radix, p->f_q_bits, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, tlist};
 
     // ---- pass 0: hits per target, their offsets, down to the host (which cuts the chunk into passes) ----
     size_t cub_scan = 0;
@@ -273,7 +306,7 @@ int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* 
             uint32_t* fq = cand_val2;
             uint64_t* fsv = cand_key2;
             hipLaunchKernelGGL(s4g::pf_append, dim3((n_seg + 255) / 256), dim3(256), 0, p->stream, cand_key + slots, cand_val + slots, n_seg, fq, fsv, (uint64_t)0, (uint64_t)n_seg);
-            S4G_TRY(merge_fused(p, (char*)cub, b_cub, fq, fsv, 1, n_seg, nullptr));
+            S4G_TRY(merge_fused(p, (char*)cub, b_cub, fq, fsv, 1, n_seg, nullptr, n_seg));
         }
         HIP_TRY(hipStreamSynchronize(p->stream));
         chunk_pairs += n_seg; chunk_long += p->h_flags[1];
@@ -301,13 +334,13 @@ int merge_fused_bytes(s4g_prefilter* p, uint64_t n, uint64_t* bytes) {
 }
 
 // Candidates (query, ~score << 32 | id) in n_regions regions of region_cap slots (the first d_counters[8 r] of region r used; d_counters
-// == NULL: one region, all region_cap slots used), any order -> into the running lists: brought into query order by a counting pass
+// == NULL: one region, all region_cap slots used; n_used: the used slots of all regions together), any order -> into the running lists: brought into query order by a counting pass
 // (or, beyond kPfScatterMaxQ queries, a radix sort over the whole capacity: the unused slots then must hold 0xFFFFFFFF), then one
 // block per query selects the best max_c of its list and its new candidates in LDS.  Asynchronous on p->stream.
 int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* cand_q, uint64_t* cand_sv, uint32_t n_regions, uint64_t region_cap,
-                const unsigned long long* d_counters) {
+                const unsigned long long* d_counters, uint64_t n_used) {
     const uint64_t n = (uint64_t)n_regions * region_cap;
-    if (!n) return S4G_OK;
+    if (!n || !n_used) return S4G_OK;
     if (n > kMaxPassHits) return fail(S4G_ERR_INVALID, "prefilter: %llu candidates in one merge", (unsigned long long)n);
     uint64_t need = 0;
     S4G_TRY(merge_fused_bytes(p, n, &need));
@@ -318,13 +351,12 @@ int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* c
     if (p->scatter) {
         uint32_t* q_count = A.take<uint32_t>((uint64_t)p->nq + 1);
         uint32_t* cursor = A.take<uint32_t>((uint64_t)p->nq + 1);
-        const uint32_t tiles = (uint32_t)((region_cap + s4g::kPfTile - 1) / s4g::kPfTile);
-        const dim3 grid(n_regions * tiles), block(512);
+        const dim3 grid((unsigned)((n_used + s4g::kPfTile - 1) / s4g::kPfTile)), block(512);
         const size_t lds = (size_t)p->nq * 4;
         HIP_TRY(hipMemsetAsync(q_count, 0, ((uint64_t)p->nq + 1) * 4, p->stream));
-        hipLaunchKernelGGL(s4g::pf_cand_count, grid, block, lds, p->stream, cand_q, region_cap, d_counters, region_cap, tiles, p->nq, q_count);
+        hipLaunchKernelGGL(s4g::pf_cand_count, grid, block, lds, p->stream, cand_q, region_cap, d_counters, n_regions, region_cap, p->nq, q_count);
         hipLaunchKernelGGL(s4g::pf_cand_first, dim3(1), dim3(512), 0, p->stream, q_count, p->nq, first, cursor);
-        hipLaunchKernelGGL(s4g::pf_cand_scatter, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, region_cap, tiles, p->nq, cursor, sv2);
+        hipLaunchKernelGGL(s4g::pf_cand_scatter, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, n_regions, region_cap, p->nq, cursor, sv2);
     } else {
         uint32_t* q2 = A.take<uint32_t>(n);
         size_t cub = arena_bytes - A.at;
@@ -344,7 +376,7 @@ int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* c
 int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_off, uint32_t nt, uint32_t first_id, uint64_t residues) {
     const bool profile = getenv("S4G_PROFILE") != nullptr;
     const auto t_begin = Clock::now();
-    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, nullptr};
+    s4g::PfChunk c{d_codes, d_off, p->d_slots, p->d_bounds, p->d_fhit, p->d_letter, p->radix, p->f_q_bits, p->d_hit_q, p->d_hit_p, p->d_hit_qp, p->k, nt, nullptr};
     constexpr uint32_t R = s4g::kPfRegions;
     constexpr uint64_t kCounterWords = 8 * R + 8;
     unsigned long long counters[kCounterWords];
@@ -390,7 +422,7 @@ int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_
             ++p->stat_repeats;
             continue;
         }
-        S4G_TRY(merge_fused(p, scratch, p->work_cap - A.at, cand_q, cand_sv, R, region_cap, d_counters));
+        S4G_TRY(merge_fused(p, scratch, p->work_cap - A.at, cand_q, cand_sv, R, region_cap, d_counters, n_cand));
         break;
     }
     p->stat_hits += n_hits; p->stat_pairs += n_cand; p->stat_long += n_long; p->stat_overflow += n_over;
@@ -407,6 +439,20 @@ int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_
         S4G_TRY(add_chunk_general(p, d_codes, d_off, (uint32_t)n_over, first_id, tlist.p));
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
+#ifdef PF_TIMING
+    {
+        unsigned long long tm[8];
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpyFromSymbol(tm, HIP_SYMBOL(s4g::pf_times), sizeof(tm)));
+        unsigned long long zero[8] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(s4g::pf_times), zero, sizeof(zero)));
+        unsigned long long all = 0;
+        for (int i = 0; i < 8; ++i) all += tm[i];
+        fprintf(stderr, "[s4g profile] pf_target_lis wave clocks: lookups ahead %.1f %%, collect %.1f %%, sort %.1f %%, segments %.1f %%, short LIS + out %.1f %%, long %.1f %%, "
+                        "per-range walks %.1f %%, rest %.1f %% of %.3e\n", 100.0 * tm[0] / all, 100.0 * tm[1] / all, 100.0 * tm[2] / all, 100.0 * tm[3] / all,
+                100.0 * tm[4] / all, 100.0 * tm[5] / all, 100.0 * tm[6] / all, 100.0 * tm[7] / all, (double)all);
+    }
+#endif
     if (profile)
         fprintf(stderr, "[s4g profile] prefilter chunk (fused): %u targets from %u, %llu hits, %llu pairs (%llu on a wave), %llu targets through the general passes: "
                         "target kernel + sync %.0f us, rest %.0f us\n", nt, first_id, n_hits, n_cand, n_long, n_over, us(t_begin, t_fused), us(t_fused, Clock::now()));
@@ -457,6 +503,9 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
     p->q_bits = bits_for(std::max(1u, n_queries));
     p->list_q_bits = std::min(32u, bits_for((uint64_t)n_queries + 1));
     if (const char* e = getenv("S4G_PREFILTER_PASS_HITS")) { const long long v = atoll(e); if (v > 0) p->pass_hits = (uint64_t)v; }
+    const bool profile = getenv("S4G_PROFILE") != nullptr;
+    const auto t_begin = Clock::now();
+    auto t_setup = t_begin;
     auto body = [&]() -> int {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -485,9 +534,11 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
             hipLaunchKernelGGL(s4g::pf_fill, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, p->stream, p->d_list_key, slots);
             HIP_TRY(hipGetLastError());
         }
+        t_setup = Clock::now();
         return build_index(p, codes, offsets);
     };
     const int rc = body();
+    if (profile) fprintf(stderr, "[s4g profile] prefilter create: stream, flags, lists %.0f us, index %.0f us\n", us(t_begin, t_setup), us(t_setup, Clock::now()));
     if (rc != S4G_OK) { s4g_prefilter_destroy(p); return rc; }
     *out = p;
     return S4G_OK;
@@ -535,32 +586,34 @@ S4G_API int s4g_prefilter_add(s4g_prefilter* p, const uint8_t* codes, const uint
     return add_chunk(p, p->d_codes, p->d_off, n_targets, first_id, residues);
 }
 
-// Rows to the host through the pinned staging buffer, piece by piece: the copy of a piece into the caller's (pageable) memory runs
-// on the worker pool underneath the transfer of the next one.  (Straight into pageable memory the runtime stages the 60 MB of a
-// thousand queries itself, single-threaded: 5.5 ms.)
+// Rows to the host through the pinned staging buffer, in pieces on a ring: while the worker pool copies a piece that has landed into
+// the caller's (pageable) memory, the transfers of the next pieces are already queued behind it, so the link never waits for the host.
+// (Straight into pageable memory the runtime stages the 60 MB of a thousand queries itself, single-threaded: 5.5 ms; with two 8 MB
+// pieces taking turns the link idled during every host copy: 1.07 ms per 20 MB; this ring: see profiles/r05_prefilter.)
 static int rows_to_host(s4g_prefilter* p, const void* d_src, void* h_dst, uint64_t bytes) {
-    const uint64_t piece = 8ull << 20;
-    S4G_TRY(ensure_stage(p, 2 * piece));
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    constexpr uint64_t piece = 2ull << 20;
+    constexpr int kRing = 6;
+    S4G_TRY(ensure_stage(p, kRing * piece));
+    hipEvent_t ev[kRing] = {};
+    for (int i = 0; i < kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     const uint64_t n = (bytes + piece - 1) / piece;
     int rc = S4G_OK;
-    for (uint64_t k = 0; k <= n && rc == S4G_OK; ++k) {
-        if (k < n) {
-            const uint64_t b = std::min(piece, bytes - k * piece);
-            if (hipMemcpyAsync(p->h_stage + (k & 1) * piece, (const char*)d_src + k * piece, b, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
-                hipEventRecord(ev[k & 1], p->stream) != hipSuccess) rc = fail(S4G_ERR_HIP, "prefilter: download failed");
-        }
-        if (k > 0 && rc == S4G_OK) {
-            const uint64_t j = k - 1, b = std::min(piece, bytes - j * piece);
-            if (hipEventSynchronize(ev[j & 1]) != hipSuccess) { rc = fail(S4G_ERR_HIP, "prefilter: download failed"); break; }
-            const char* src = p->h_stage + (j & 1) * piece;
-            char* dst = (char*)h_dst + j * piece;
-            parallel_for(b, parallel_parts(b, 1u << 20), [&](unsigned, unsigned, uint64_t x, uint64_t y) { memcpy(dst + x, src + x, y - x); });
-        }
+    auto queue = [&](uint64_t k) {
+        const uint64_t b = std::min(piece, bytes - k * piece);
+        if (hipMemcpyAsync(p->h_stage + (k % kRing) * piece, (const char*)d_src + k * piece, b, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+            hipEventRecord(ev[k % kRing], p->stream) != hipSuccess) rc = fail(S4G_ERR_HIP, "prefilter: download failed");
+    };
+    for (uint64_t k = 0; k < std::min<uint64_t>(n, kRing) && rc == S4G_OK; ++k) queue(k);
+    for (uint64_t j = 0; j < n && rc == S4G_OK; ++j) {
+        const uint64_t b = std::min(piece, bytes - j * piece);
+        if (hipEventSynchronize(ev[j % kRing]) != hipSuccess) { rc = fail(S4G_ERR_HIP, "prefilter: download failed"); break; }
+        const char* src = p->h_stage + (j % kRing) * piece;
+        char* dst = (char*)h_dst + j * piece;
+        parallel_for(b, parallel_parts(b, 1u << 18), [&](unsigned, unsigned, uint64_t x, uint64_t y) { memcpy(dst + x, src + x, y - x); });
+        if (j + kRing < n) queue(j + kRing);
     }
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    if (rc != S4G_OK) (void)hipStreamSynchronize(p->stream);         // nothing may still be landing in the staging buffer
+    for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 
@@ -635,7 +688,7 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     if (!p) return S4G_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_slots); (void)hipFree(p->d_bounds); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_slots); (void)hipFree(p->d_bounds); (void)hipFree(p->d_fhit); (void)hipFree(p->d_letter); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
     (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
