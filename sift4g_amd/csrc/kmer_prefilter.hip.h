@@ -366,6 +366,18 @@ struct PfFused {
 // global store in flight -- the candidates just written -- which is microseconds per target.
 __device__ __forceinline__ void pf_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// inclusive prefix sum over the 64 lanes by DPP: rows of 16 by shifted adds (zeros shifted in), then the row totals handed on
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six dependent adds, no LDS crossbar, no waits
+__device__ __forceinline__ uint32_t pf_scan64(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);       // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Buckets of four chunks of 64 positions from `base`: lane l gets those of positions base + 64 u + l (u = 0..3).  One byte per
 // lane and chunk comes from memory, the k-mers are put together from the neighbours' digits (shuffles), and the dependent rounds of
 // loads -- residues, index slot, the bucket's first hit -- are each issued for all four chunks before any is waited for; a bucket
@@ -385,16 +397,15 @@ __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __r
     bool look[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        uint32_t x = 0;
-        for (uint32_t i = 0; i < a.k; ++i) {            // digit of position j + i: lane + i of this chunk, or of the next one
-            const uint32_t src = lane + i;
-            const uint32_t own = (uint32_t)__shfl((int)b[u], (int)(src & 63), 64), nxt = (uint32_t)__shfl((int)b[u + 1], (int)(src & 63), 64);
-            x = x * a.radix + (src < 64 ? own : nxt);
+        uint32_t s = b[u], x = s;                       // digit of position j + i: lane + i of this chunk, or of the next one --
+        for (uint32_t i = 1; i < a.k; ++i) {            // the chunk shifted down a lane at a time (DPP wave_shl:1), the next chunk's digits entering at lane 63
+            const int in = __builtin_amdgcn_readlane((int)b[u + 1], (int)(i - 1));
+            s = (uint32_t)__builtin_amdgcn_update_dpp(in, (int)s, 0x130, 0xf, 0xf, false);
+            x = x * a.radix + s;
         }
         v[u] = x;
-        uint32_t prev = (uint32_t)__shfl_up((int)x, 1, 64);
-        if (lane == 0) prev = carry;
-        carry = (uint32_t)__shfl((int)x, 63, 64);
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 <- carry
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
         const uint32_t j = base + 64 * u + lane;
         look[u] = j < n_kmers && !(j != 0 && prev == x);            // database_search.cpp:212: equal to the k-mer before it
     }
@@ -451,9 +462,8 @@ __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t*
         for (int u = 0; u < 4; ++u) {
             uint32_t mine_n = n[u];                 // this position's hits inside the query range (a bucket is ordered by query)
             if (FILTER) { mine_n = 0; for (uint32_t h = 0; h < n[u]; ++h) { const uint32_t q = h ? (uint32_t)c0.hit_qp[first[u] + h] : hq[u]; mine_n += (q >= qa && q < qb); } }
-            uint32_t incl = mine_n;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += up; }
-            const uint32_t chunk = __shfl(incl, 63, 64);
+            const uint32_t incl = pf_scan64(mine_n);
+            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             ok = ok && out + chunk <= kPfCap;
             if (ok) {
                 uint32_t w = (uint32_t)out + incl - mine_n;
@@ -473,25 +483,98 @@ __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t*
     return out;
 }
 
+// ---- bitonic sort of 64 NREG keys in registers: key i in lane i % 64 of v[i / 64] ----
+// A compare-exchange over a stride of 64 or more pairs two registers of the same lane (min / max); below 64 the partner comes across the
+// lanes without touching LDS memory -- DPP quad_perm (1, 2), two masked DPP row shifts (4, 8), ds_swizzle (16), ds_bpermute (32) -- and
+// the lane keeps its own key or the partner's by one compare and one select under a CONSTANT lane mask (which lanes keep the smaller
+// key is a property of stride, size and register): 3 vector + 2 scalar instructions per register and stage, all 64 lanes at work, where
+// the sort in LDS spent two reads, two writes and a wait per stage on half the lanes.
+template <int STRIDE>
+__device__ __forceinline__ uint32_t pf_xor_lane(uint32_t v, uint32_t lane) {
+    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);       // quad_perm:[1,0,3,2]
+    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+    else if constexpr (STRIDE == 4) {
+        const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);                                  // row_shl:4 into banks 0, 2
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xa, false);                                    // row_shr:4 into banks 1, 3
+    } else if constexpr (STRIDE == 8) {
+        const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xf, 0x3, false);                                  // row_shl:8 into banks 0, 1
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xf, 0xc, false);                                    // row_shr:8 into banks 2, 3
+    } else if constexpr (STRIDE == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                        // swizzle(SWAP, 16)
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)v);
+}
+constexpr uint64_t pf_low_lanes(int s) {         // lanes whose bit s is clear (s = 1 .. 32)
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) if (!(l & s)) m |= 1ull << l;
+    return m;
+}
+template <int NREG, int SIZE, int STRIDE>
+__device__ __forceinline__ void pf_bitonic_step(uint32_t (&v)[NREG], uint32_t lane) {
+    if constexpr (STRIDE >= 64) {
+        constexpr int SR = STRIDE / 64;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+            if (!(r & SR)) {
+                const uint32_t a = v[r], b = v[r | SR];
+                const bool up = ((r * 64) & SIZE) == 0;
+                v[r] = up ? min(a, b) : max(a, b);
+                v[r | SR] = up ? max(a, b) : min(a, b);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            // the lanes that keep the smaller key: (bit STRIDE of the index clear) == (ascending block: bit SIZE of the index clear)
+            const uint64_t up = SIZE < 64 ? pf_low_lanes(SIZE) : (((r * 64) & SIZE) == 0 ? ~0ull : 0ull);
+            const uint64_t keep_min = ~(pf_low_lanes(STRIDE) ^ up);
+            const uint32_t p = pf_xor_lane<STRIDE>(v[r], lane);
+            const uint64_t take = ~(__ballot(p < v[r]) ^ keep_min);          // the partner's key: it is smaller and this lane keeps the smaller, or neither
+            v[r] = __builtin_amdgcn_inverse_ballot_w64(take) ? p : v[r];     // (equal keys -- the padding -- may go either way)
+        }
+    }
+    if constexpr (STRIDE > 1) pf_bitonic_step<NREG, SIZE, STRIDE / 2>(v, lane);
+}
+template <int NREG, int SIZE>
+__device__ __forceinline__ void pf_bitonic_from(uint32_t (&v)[NREG], uint32_t lane) {
+    pf_bitonic_step<NREG, SIZE, SIZE / 2>(v, lane);
+    if constexpr (SIZE < 64 * NREG) pf_bitonic_from<NREG, SIZE * 2>(v, lane);
+}
+// key[0 .. total) sorted ascending in place, key[total .. 64 NREG) = 0xFFFFFFFF behind them
+template <int NREG>
+__device__ __forceinline__ void pf_sort_keys(uint32_t* key, uint32_t total, uint32_t lane) {
+    uint32_t v[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) v[r] = r * 64 + lane < total ? key[r * 64 + lane] : 0xFFFFFFFFu;
+    pf_bitonic_from<NREG, 2>(v, lane);
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) key[r * 64 + lane] = v[r];
+}
+
+// cnt hits (lanes 0 .. cnt - 1 of xs, in order) through the tails method with the tails in registers: tail l in lane l % 64 of T[l / 64],
+// unused tails at +infinity.  NR = registers that can come into play during this chunk (llen + cnt <= 64 NR): per hit one broadcast,
+// NR compares + scalar popcounts, one predicated move -- nothing of it touches LDS or waits for memory.
+template <int NR>
+__device__ __forceinline__ void pf_lis_chunk(int32_t (&T)[8], uint32_t& llen, int32_t xs, uint32_t cnt, uint32_t lane) {
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const int32_t x = __builtin_amdgcn_readlane(xs, (int)k);
+        uint32_t lo = 0;                                                    // tails below x (tails ascending; +infinity is below nothing)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) lo += (uint32_t)__popcll(__ballot(T[r] < x));
+        const uint32_t reg = lo >> 6;                                       // (uniform)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if ((NR == 1 || reg == (uint32_t)r) && lane == (lo & 63)) T[r] = x;
+        llen = max(llen, lo + 1);
+    }
+}
+
 // The `total` hits in key / pos: sorted by (query, order), cut into segments, the LIS of every segment, one candidate each.
 __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uint32_t lane, uint32_t region, uint32_t* key, const uint32_t* pos,
                                            int32_t* tail, uint32_t* lng, float flen, uint32_t id, unsigned long long& sum_long, PfClock& ck) {
-    uint32_t m = 64;                                         // sort size: a power of two >= total
-    while (m < total) m <<= 1;
-    for (uint32_t i = total + lane; i < m; i += 64) key[i] = 0xFFFFFFFFu;
+    // ---- the keys sorted (in registers: pf_sort_keys): grouped by query, the reference's order inside a query ----
     pf_lds_fence();
-    // ---- bitonic sort of the keys: grouped by query, the reference's order inside a query ----
-    for (uint32_t size = 2; size <= m; size <<= 1)
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = lane; i < m / 2; i += 64) {
-                const uint32_t lo = 2 * i - (i & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t x = key[lo], y = key[hi];
-                if ((x > y) == up) { key[lo] = y; key[hi] = x; }
-            }
-            pf_lds_fence();
-        }
+    if (total <= 64) pf_sort_keys<1>(key, total, lane);
+    else if (total <= 128) pf_sort_keys<2>(key, total, lane);
+    else if (total <= 256) pf_sort_keys<4>(key, total, lane);
+    else pf_sort_keys<8>(key, total, lane);
+    pf_lds_fence();
     ck.mark(2);
     // ---- segments = runs of one query; count them, reserve their candidates with one atomic on the wave's region ----
     uint32_t n_seg = 0;
@@ -502,7 +585,7 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
     }
     unsigned long long slot0 = 0;
     if (lane == 0) { slot0 = atomicAdd(&a.counters[8 * region], (unsigned long long)n_seg); lng[0] = 0; }
-    slot0 = ((unsigned long long)(uint32_t)__shfl((int)(slot0 >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)slot0, 0, 64);
+    slot0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot0);
     pf_lds_fence();
     const uint64_t region_base = (uint64_t)region * a.region_cap;
     auto emit = [&](uint32_t q, uint32_t lis, unsigned long long slot) {
@@ -564,9 +647,9 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
     }
     pf_lds_fence();
     ck.mark(4);
-    // ---- long segments, the whole wave on each.  The tails live in REGISTERS, tail l in lane l % 64 of register l / 64 (eight
-    //      registers: kPfCap tails), unused ones at +infinity: the number of tails below x is eight ballots and their popcounts, the
-    //      update one predicated move -- no LDS round trip inside the dependent chain (with tails in LDS a hit cost ~300 clocks) ----
+    // ---- long segments, the whole wave on each.  The tails live in REGISTERS (pf_lis_chunk; eight registers: kPfCap tails): no LDS
+    //      round trip inside the dependent chain (with tails in LDS a hit cost ~300 clocks), and only as many registers are searched as
+    //      the run found so far plus the chunk at hand can reach (most runs stay below 64: 34 -> 7 instructions per hit) ----
     const uint32_t n_long = lng[0];
     sum_long += n_long;
     for (uint32_t w = 0; w < n_long; ++w) {
@@ -578,18 +661,11 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
         for (uint32_t base = 0; base < n; base += 64) {
             const int32_t xs = base + lane < n ? (int32_t)pos[key[i0 + base + lane] & (kPfCap - 1)] : 0;     // 64 hits of the segment at a time
             const uint32_t cnt = min(64u, n - base);
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const int32_t x = __builtin_amdgcn_readlane(xs, (int)k);
-                uint32_t lo = 0;                                                    // tails below x (positions are distinct, tails ascending)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if ((uint32_t)r * 64 <= llen) lo += (uint32_t)__popcll(__ballot(T[r] < x));
-                const uint32_t reg = lo >> 6;
-                if (lane == (lo & 63)) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) if (reg == (uint32_t)r) T[r] = x;
-                }
-                llen = max(llen, lo + 1);
-            }
+            const uint32_t reach = llen + cnt;                                       // (uniform)
+            if (reach <= 64) pf_lis_chunk<1>(T, llen, xs, cnt, lane);
+            else if (reach <= 128) pf_lis_chunk<2>(T, llen, xs, cnt, lane);
+            else if (reach <= 256) pf_lis_chunk<4>(T, llen, xs, cnt, lane);
+            else pf_lis_chunk<8>(T, llen, xs, cnt, lane);
         }
         if (lane == 0) emit(key[i0] >> kPfOrderBits, llen, slot0 + rank);
     }
