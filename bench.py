@@ -193,7 +193,8 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
         stats = p.stats()
         p.close()
         best = dict(index=min(best["index"], t1 - t0), add=min(best["add"], t2 - t1), finish=min(best["finish"], t3 - t2),
-                    call=min(best["call"], t3 - t0), finish_ids=min(best["finish_ids"], t4 - t3))
+                    call=min(best["call"], t3 - t0), finish_ids=min(best["finish_ids"], t4 - t3),
+                    call_ids=min(best.get("call_ids", 1e9), (t2 - t0) + (t4 - t3)))
     m = min(check_targets, nt)
     sample = [cfg["t_codes"][int(t_off[i]):int(t_off[i + 1])] for i in range(m)]
     t0 = time.perf_counter()
@@ -211,7 +212,7 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
         bad += int((ids[q, :n] != r_ids[q, :n]).sum()) + int((scores[q, :n].view(np.uint32) != r_scores[q, :n].view(np.uint32)).sum())
     # against the HBM roof: what the stage has to move at the least -- every residue in once, one 12-byte candidate (query, score, id)
     # out per (query, target) pair with a hit -- over the time of the call; the counter traffic of the same call (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE passes of tools/prefilter_bench.py, profiles/r03_prefilter) rides along
+    # FETCH_SIZE / WRITE_SIZE passes of tools/prefilter_bench.py, profiles/r05_prefilter) rides along
     alg_bytes = residues + 12.0 * stats["pairs"]
     traffic = None
     try:
@@ -225,15 +226,19 @@ def prefilter_leg(cfg, dev_index, reps=3, check_targets=2000):
             "frac": round(alg_bytes / best["call"] / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes,
             "traffic": traffic["hbm_bytes_per_add"] if traffic else None, "traffic_measured_in_run": False,
             "traffic_source": traffic["source"] if traffic else None,
-            "note": "integer gather work: the target kernel is bound by vector issue and scattered 4/8-byte lookups (bitmap, bucket bounds, hits), "
-                    "not by streaming; traffic = FETCH_SIZE + WRITE_SIZE of every kernel of one add call"}
+            "traffic_full_size_add": traffic.get("hbm_bytes_per_full_size_add") if traffic else None,
+            "note": "integer gather work: the target kernel is bound by vector issue (sorting and walking a target's hits in LDS / registers), its index "
+                    "lookups stay in L2 (1 MB of slots + 1.3 MB of bucket words); traffic = FETCH_SIZE + WRITE_SIZE of every kernel of one add call, "
+                    "averaged over the add calls of the profiled run as in rounds 3-4 (traffic_full_size_add: the 100 000-target calls alone)"}
     return {"stage": "k-mer prefilter (database_search.cpp:66-253) on the device, database resident in HBM",
             "kmer_length": 5, "max_candidates": 5000, "queries": nq, "targets": nt, "residues": residues, "roofline": roof,
             "path": "fused" if stats.get("fused") else "general", "general_path_targets": stats.get("general_path_targets"),
             "index_ms": round(best["index"] * 1e3, 3), "add_ms": round(best["add"] * 1e3, 3), "finish_ms": round(best["finish"] * 1e3, 3),
             "finish_ids_only_ms": round(best["finish_ids"] * 1e3, 3),
             "call_ms": round(best["call"] * 1e3, 3), "residues_per_s": round(residues / best["call"], 1),
-            "residues_per_s_basis": "database residues / (index + add + finish) of the fastest whole call",
+            "residues_per_s_basis": "database residues / (index + add + finish with ids AND scores) of the fastest whole call",
+            "call_ids_only_ms": round(best["call_ids"] * 1e3, 3), "residues_per_s_ids_only": round(residues / best["call_ids"], 1),
+            "ids_only_basis": "index + add + finish with ids only: what searchDatabase returns (database_search.cpp:166-178) and the drop-in asks for",
             "add_residues_per_s": round(residues / best["add"], 1), "kmer_hits": stats["hits"], "pairs_with_a_hit": stats["pairs"],
             "check": {"targets": m, "mismatches": bad, "against": "oracle/kmer_prefilter.c (CPU restatement, 1 thread)",
                       "cpu_residues_per_s": round(int(t_off[m]) / cpu_s, 1)}}

@@ -105,10 +105,12 @@ __global__ void pf_slot_rank(uint2* __restrict__ slots, uint32_t n_words, const 
 }
 __device__ __forceinline__ uint32_t pf_rank(uint2 slot, uint32_t v) { return slot.y + (uint32_t)__popc(slot.x & ((1u << (v & 31)) - 1u)); }
 // bounds[r] = first hit of the r-th present k-mer in the k-mer-sorted hit list, bounds[number of present k-mers] = n_hits;
-// fhit[r] = that first hit itself, position << f_q_bits | query, with bit 31 set when the bucket holds more than it (two k-mers in three
-// occur once in a thousand queries: their lookup ends here, in a 4-byte table of 1.3 MB).  f_q_bits = 0: positions and queries do not
-// fit 31 bits together; every entry then says "more" and the bucket is read through bounds / hit_qp.
+// fhit[r] = the bucket in one word.  A bucket of ONE hit (two k-mers in three occur once in a thousand queries): the hit itself, position
+// << f_q_bits | query.  Otherwise bit 31 (kPfMore) and, where they fit, the bucket's start in hit_qp << 8 | its size (start below 2^23,
+// size below 256); kPfMore alone sends the lookup to bounds[].  f_q_bits = 0: positions and queries do not fit 31 bits together, every
+// bucket is a kPfMore one.  The lookup of nearly every k-mer ends in this 4-byte table (1.3 MB for a thousand queries).
 constexpr uint32_t kPfMore = 0x80000000u;
+constexpr uint32_t kPfNoBucket = 0xFFFFFFFFu;   // PfBlock::first of a position whose one hit is in hq / hp
 __global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ pos_q,
                                  const uint32_t* __restrict__ pos_j, uint64_t n_hits, const uint2* __restrict__ slots, uint32_t f_q_bits,
                                  uint32_t* __restrict__ bounds, uint32_t* __restrict__ fhit) {
@@ -119,8 +121,10 @@ __global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, const 
     if (i == 0 || sorted_key[i - 1] != v) {
         bounds[r] = (uint32_t)i;
         const uint32_t g = sorted_val[i];
-        const bool more = f_q_bits == 0 || (i + 1 < n_hits && sorted_key[i + 1] == v);
-        fhit[r] = more ? kPfMore : (pos_j[g] << f_q_bits) | pos_q[g];
+        uint32_t cnt = 1;
+        while (cnt < 256 && i + cnt < n_hits && sorted_key[i + cnt] == v) ++cnt;
+        if (f_q_bits != 0 && cnt == 1) fhit[r] = (pos_j[g] << f_q_bits) | pos_q[g];
+        else fhit[r] = kPfMore | (cnt < 256 && i < (1u << 23) ? ((uint32_t)i << 8) | cnt : 0u);
     }
     if (i + 1 == n_hits) bounds[r + 1] = (uint32_t)n_hits;
 }
@@ -380,9 +384,9 @@ __device__ __forceinline__ uint32_t pf_scan64(uint32_t v) {
 
 // Buckets of four chunks of 64 positions from `base`: lane l gets those of positions base + 64 u + l (u = 0..3).  One byte per
 // lane and chunk comes from memory, the k-mers are put together from the neighbours' digits (shuffles), and the dependent rounds of
-// loads -- residues, index slot, the bucket's first hit -- are each issued for all four chunks before any is waited for; a bucket
-// of several hits (kPfMore) costs two more rounds, bounds and its first entry.  hq / hp: query and position of the bucket's first hit.
-// letter: the radix digits of the 32 codes, in LDS.
+// loads -- residues, index slot, the bucket's word -- are each issued for all four chunks before any is waited for.  n: hits of the
+// position; first: kPfNoBucket and the hit in hq / hp, or where the bucket starts in hit_qp (pf_collect fetches those hits, all lanes
+// at once).  letter: the radix digits of the 32 codes, in LDS.
 struct PfBlock { uint32_t first[4], n[4], hq[4], hp[4]; };
 __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t base,
                                             uint32_t lane, PfBlock& blk, unsigned& wrong, const uint8_t* letter) {
@@ -420,34 +424,33 @@ __device__ __forceinline__ void pf_buckets4(const PfChunk& a, const uint8_t* __r
         f[u] = look[u] ? a.fhit[r[u]] : 0u;
     }
     const uint32_t q_mask = (1u << a.f_q_bits) - 1u;
-    bool more = false;
+    bool unpacked = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        first[u] = 0; n[u] = look[u] ? 1u : 0u;
+        first[u] = kPfNoBucket; n[u] = look[u] ? 1u : 0u;
         hq[u] = f[u] & q_mask; hp[u] = (f[u] & ~kPfMore) >> a.f_q_bits;
-        more = more || (f[u] & kPfMore);
+        if (f[u] & kPfMore) { first[u] = (f[u] & ~kPfMore) >> 8; n[u] = f[u] & 255u; unpacked = unpacked || n[u] == 0; }
     }
-    if (__ballot(more)) {                                            // (uniform: the rare rounds are skipped by the whole wave)
-        uint32_t s0[4], s1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint64_t se = 0;                                         // bounds[r], bounds[r + 1]: one 8-byte load (4-byte aligned)
-            if (f[u] & kPfMore) __builtin_memcpy(&se, a.bounds + r[u], 8);
-            s0[u] = (uint32_t)se; s1[u] = (uint32_t)(se >> 32);
-        }
+    if (__ballot(unpacked)) {                                        // (uniform: the rare round -- buckets of 256 hits and more -- is skipped by the whole wave)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (f[u] & kPfMore) {
-                first[u] = s0[u]; n[u] = s1[u] - s0[u];
-                const uint64_t qp = a.hit_qp[first[u]];
-                hq[u] = (uint32_t)qp; hp[u] = (uint32_t)(qp >> 32);
+            if ((f[u] & kPfMore) && n[u] == 0) {
+                uint64_t se = 0;                                     // bounds[r], bounds[r + 1]: one 8-byte load (4-byte aligned)
+                __builtin_memcpy(&se, a.bounds + r[u], 8);
+                first[u] = (uint32_t)se; n[u] = (uint32_t)(se >> 32) - (uint32_t)se;
             }
     }
+}
+
+// hit h of a position's bucket
+__device__ __forceinline__ uint64_t pf_hit(const PfChunk& c0, const PfBlock& blk, int u, uint32_t h) {
+    return blk.first[u] != kPfNoBucket ? c0.hit_qp[blk.first[u] + h] : (((uint64_t)blk.hp[u] << 32) | blk.hq[u]);
 }
 
 // One sweep over a target: its hits with a query in [qa, qb) (FILTER) or all of them go into key / pos in the order the reference
 // appends them (by target position, then bucket order) -- as long as they fit: once kPfCap would be passed nothing more is written
 // and only the count goes on.  -> the number of such hits (the same in every lane); *fits = all of them are in LDS.
+constexpr uint32_t kPfFetch = 0x80000000u;       // pos[] of a hit that is still to be fetched: kPfFetch | its index in hit_qp
 template <bool FILTER>
 __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t* __restrict__ c, uint32_t len, uint32_t n_kmers, uint32_t lane,
                                                uint32_t qa, uint32_t qb, uint32_t* key, uint32_t* pos, bool* fits, unsigned& wrong,
@@ -460,20 +463,29 @@ __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t*
         uint32_t (&first)[4] = blk.first; uint32_t (&n)[4] = blk.n; uint32_t (&hq)[4] = blk.hq; uint32_t (&hp)[4] = blk.hp;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (base + 64 * u >= n_kmers) break;    // (uniform)
             uint32_t mine_n = n[u];                 // this position's hits inside the query range (a bucket is ordered by query)
-            if (FILTER) { mine_n = 0; for (uint32_t h = 0; h < n[u]; ++h) { const uint32_t q = h ? (uint32_t)c0.hit_qp[first[u] + h] : hq[u]; mine_n += (q >= qa && q < qb); } }
+            if (FILTER) { mine_n = 0; for (uint32_t h = 0; h < n[u]; ++h) { const uint32_t q = (uint32_t)pf_hit(c0, blk, u, h); mine_n += (q >= qa && q < qb); } }
             const uint32_t incl = pf_scan64(mine_n);
             const uint32_t chunk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             ok = ok && out + chunk <= kPfCap;
-            if (ok) {
+            if (ok && chunk) {
                 uint32_t w = (uint32_t)out + incl - mine_n;
-                for (uint32_t h = 0; h < n[u]; ++h) {
-                    const uint64_t qp = h ? c0.hit_qp[first[u] + h] : (((uint64_t)hp[u] << 32) | hq[u]);
-                    const uint32_t q = (uint32_t)qp;
-                    if (FILTER && (q < qa || q >= qb)) continue;
-                    key[w] = (q << kPfOrderBits) | w;
-                    pos[w] = (uint32_t)(qp >> 32);
-                    ++w;
+                if (FILTER) {
+                    for (uint32_t h = 0; h < n[u]; ++h) {
+                        const uint64_t qp = pf_hit(c0, blk, u, h);
+                        const uint32_t q = (uint32_t)qp;
+                        if (q < qa || q >= qb) continue;
+                        key[w] = (q << kPfOrderBits) | w;
+                        pos[w] = (uint32_t)(qp >> 32);
+                        ++w;
+                    }
+                } else if (first[u] == kPfNoBucket) {
+                    if (n[u]) { key[w] = (hq[u] << kPfOrderBits) | w; pos[w] = hp[u]; }
+                } else {
+                    // a bucket of several hits: only WHERE its hits are goes into LDS now (a lane that fetched its own bucket hit by hit would
+                    // wait for memory once per hit, and the wave for its longest bucket); pf_fetch_hits then brings them in 64 at a time
+                    for (uint32_t h = 0; h < n[u]; ++h) pos[w + h] = kPfFetch | (first[u] + h);
                 }
             }
             out += chunk;
@@ -481,6 +493,35 @@ __device__ __forceinline__ uint64_t pf_collect(const PfChunk& c0, const uint8_t*
     }
     *fits = ok;
     return out;
+}
+// The hits pf_collect<false> left as references, fetched by all lanes at once -- in two halves, so that the lookups of the wave's next
+// target can be issued between them: pf_fetch_issue puts the loads of the first 128 slots in flight, pf_fetch_land writes them (and
+// fetches whatever lies beyond 128) where the hits belong.
+struct PfFetch { uint64_t qp[2]; bool on[2]; };
+__device__ __forceinline__ void pf_fetch_issue(const PfChunk& c0, uint32_t total, uint32_t lane, const uint32_t* pos, PfFetch& f) {
+    pf_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t k = r * 64 + lane;
+        const uint32_t ref = k < total ? pos[k] : 0u;
+        f.on[r] = (ref & kPfFetch) != 0;
+        f.qp[r] = f.on[r] ? c0.hit_qp[ref & ~kPfFetch] : 0ull;
+    }
+}
+__device__ __forceinline__ void pf_fetch_land(const PfChunk& c0, uint32_t total, uint32_t lane, uint32_t* key, uint32_t* pos, const PfFetch& f) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t k = r * 64 + lane;
+        if (f.on[r]) { key[k] = ((uint32_t)f.qp[r] << kPfOrderBits) | k; pos[k] = (uint32_t)(f.qp[r] >> 32); }
+    }
+    for (uint32_t k = 128 + lane; k < total; k += 64) {
+        const uint32_t ref = pos[k];
+        if (ref & kPfFetch) {
+            const uint64_t qp = c0.hit_qp[ref & ~kPfFetch];
+            key[k] = ((uint32_t)qp << kPfOrderBits) | k;
+            pos[k] = (uint32_t)(qp >> 32);
+        }
+    }
 }
 
 // ---- bitonic sort of 64 NREG keys in registers: key i in lane i % 64 of v[i / 64] ----
@@ -674,7 +715,10 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
 }
 
 // One wave per target (grid-stride).  See the header of this file.
-__global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
+#ifndef PF_WPE
+#define PF_WPE 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WPE, PF_WPE))) void pf_target_lis(PfFused a) {
     __shared__ uint32_t s_key[4][kPfCap];       // query << 9 | order, sorted in place
     __shared__ uint32_t s_pos[4][kPfCap];       // query position of the hit with order index i
     __shared__ int32_t s_tail[4][kPfCap];       // LIS tails: a segment that starts at sorted position i uses [i, i + its length)
@@ -690,7 +734,6 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
     uint32_t* lng = s_misc[wv];
     uint32_t* hist = s_misc[wv] + kPfMaxLong * 3 + 1;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t region = wave_id % kPfRegions;
     const PfChunk& c0 = a.c;
     const uint32_t q_per_range = (a.nq + kPfRanges - 1) / kPfRanges;
@@ -703,11 +746,31 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
     uint32_t len_next = 0;
     PfClock ck;
     ck.start();
-    if (wave_id < c0.nt) {
-        o_next = c0.off[wave_id]; len_next = (uint32_t)(c0.off[wave_id + 1] - o_next);
+    // Targets are dealt out by counters, not by wave index: a target costs from a tenth to ten times the average, and with two dozen
+    // targets per wave fixed in advance the slowest of 4096 waves had half as much again as the mean.  One counter for all waves would
+    // serialise 100 000 returning atomics on one address (measured: the kernel doubled); the waves of a region share one instead (64
+    // counters, a line apart, beside the regions' fill counters) that deals out the targets region, region + 64, ... -- all regions walk
+    // the database front to back together.  The index a wave will work on two targets from now is drawn while the current one is
+    // processed and only looked at an iteration later, so the atomic's latency is never waited for.
+    const uint32_t groups = min(kPfRegions, gridDim.x * (blockDim.x >> 6));      // (a small chunk runs on fewer waves than there are regions)
+    auto draw = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(&a.counters[8 * region + 1], 1ull);
+        return v;
+    };
+    auto target_of = [&](unsigned long long drawn) -> uint32_t {
+        const unsigned long long i = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(drawn >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)drawn);
+        return (uint32_t)min(i * groups + region, (unsigned long long)0xFFFFFFFFull);
+    };
+    uint32_t t = target_of(draw()), t_next = target_of(draw());
+    unsigned long long drawn = 0;
+    if (t < c0.nt) {
+        o_next = c0.off[t]; len_next = (uint32_t)(c0.off[t + 1] - o_next);
         pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong, letter);
     }
-    for (uint32_t t = wave_id; t < c0.nt; t += waves) {
+    for (; t < c0.nt; t = t_next, t_next = target_of(drawn)) {
+        drawn = draw();
         const uint64_t o = o_next;
         const uint32_t len = len_next;
         const uint8_t* c = c0.codes + o;
@@ -719,15 +782,17 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
         const PfBlock mine_block = ahead;
         ck.mark(7);
         const uint64_t total64 = pf_collect<false>(c0, c, len, n_kmers, lane, 0u, 0xFFFFFFFFu, key, pos, &fits, wrong, n_kmers ? &mine_block : nullptr, letter);
+        PfFetch fetch;
+        if (fits) pf_fetch_issue(c0, (uint32_t)total64, lane, pos, fetch);
         ck.mark(1);
-        if (t + waves < c0.nt) {
-            o_next = c0.off[t + waves]; len_next = (uint32_t)(c0.off[t + waves + 1] - o_next);
+        if (t_next < c0.nt) {
+            o_next = c0.off[t_next]; len_next = (uint32_t)(c0.off[t_next + 1] - o_next);
             pf_buckets4(c0, c0.codes + o_next, len_next, len_next >= c0.k ? len_next - c0.k + 1 : 0, 0, lane, ahead, wrong, letter);
         }
         ck.mark(0);
         if (total64 == 0) continue;
         sum_hits += total64;
-        if (fits) { pf_process(a, (uint32_t)total64, lane, region, key, pos, tail, lng, flen, id, sum_long, ck); continue; }
+        if (fits) { pf_fetch_land(c0, (uint32_t)total64, lane, key, pos, fetch); pf_process(a, (uint32_t)total64, lane, region, key, pos, tail, lng, flen, id, sum_long, ck); continue; }
         // ---- more hits than a wave keeps: once per range of queries.  Histogram of the hits over kPfRanges slices of the query
         //      indices, consecutive slices grouped into passes of at most kPfCap hits ----
         pf_lds_fence();
@@ -738,7 +803,7 @@ __global__ __launch_bounds__(256) void pf_target_lis(PfFused a) {
             pf_buckets4(c0, c, len, n_kmers, base, lane, blk, wrong, letter);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                for (uint32_t h = 0; h < blk.n[u]; ++h) atomicAdd(&hist[(h ? (uint32_t)c0.hit_qp[blk.first[u] + h] : blk.hq[u]) / q_per_range], 1u);
+                for (uint32_t h = 0; h < blk.n[u]; ++h) atomicAdd(&hist[(uint32_t)pf_hit(c0, blk, u, h) / q_per_range], 1u);
         }
         pf_lds_fence();
         if (__ballot(hist[lane] > kPfCap)) {                            // one slice of queries alone does not fit: the general passes take the target

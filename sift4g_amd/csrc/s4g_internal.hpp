@@ -145,6 +145,10 @@ struct DeviceCtx {
     struct PinSlab { char* p = nullptr; uint64_t cap = 0, used = 0; int live = 0; };
     std::vector<PinSlab> trace_pin_slabs;
     uint64_t trace_pin_bytes = 0;
+    // what the device's last k-mer prefilter handle left behind for the next one (s4g_prefilter.hip): its pinned staging buffer and its
+    // work arena -- pinning 12 MB and allocating and releasing a few hundred MB cost a handle 2-3 ms, as much as its whole add call
+    char* pf_spare_stage = nullptr; uint64_t pf_spare_stage_cap = 0;
+    char* pf_spare_work = nullptr;  uint64_t pf_spare_work_cap = 0;
     hipStream_t coop_stream = nullptr;  // they run next to the one-wave-per-pair launches of the same submission, not behind them
     hipEvent_t coop_fork = nullptr, coop_join = nullptr;
     char* d_coop_ws = nullptr;          // their boundary rows (s4g_pairs.hip, ensure_coop_ws)

@@ -31,6 +31,7 @@ struct s4g_prefilter {
     uint32_t n_words = 0;           // radix^k / 32 index slots
     uint32_t radix = 32;            // digits of a k-mer's number: the codes the queries use + one for all others (kmer_prefilter.hip.h: pf_kmer)
     uint32_t f_q_bits = 0;          // packing of d_fhit (0: unused, every bucket through d_bounds)
+    char* d_index = nullptr;        // the block every d_ pointer of the index points into
     uint8_t* d_letter = nullptr;    // [32] code -> digit
     uint32_t* d_fhit = nullptr;     // [n_hash_hits + 1] first hit of the present k-mers, by rank
     hipStream_t stream = nullptr;
@@ -67,6 +68,15 @@ namespace {
 
 int ensure_stage(s4g_prefilter* p, uint64_t bytes) {
     if (p->stage_cap >= bytes) return S4G_OK;
+    if (!p->h_stage) {                                   // a handle's first: what the device's last handle left behind, if that is enough
+        DeviceCtx* cx = device_ctx(p->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (cx->pf_spare_stage && cx->pf_spare_stage_cap >= bytes) {
+            p->h_stage = cx->pf_spare_stage; p->stage_cap = cx->pf_spare_stage_cap;
+            cx->pf_spare_stage = nullptr; cx->pf_spare_stage_cap = 0;
+            return S4G_OK;
+        }
+    }
     if (p->h_stage) { HIP_TRY(hipStreamSynchronize(p->stream)); HIP_TRY(hipHostFree(p->h_stage)); p->h_stage = nullptr; p->stage_cap = 0; }
     const uint64_t want = bytes + bytes / 8;
     HIP_TRY(hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault));
@@ -82,6 +92,21 @@ int ensure_dev(s4g_prefilter* p, T** ptr, uint64_t* cap, uint64_t n) {
     if (hipMalloc((void**)ptr, want * sizeof(T)) != hipSuccess) return fail(S4G_ERR_NOMEM, "prefilter: cannot allocate %llu bytes of device memory", (unsigned long long)(want * sizeof(T)));
     *cap = want;
     return S4G_OK;
+}
+
+// the work arena: bytes, not elements
+int ensure_work(s4g_prefilter* p, uint64_t need) {
+    if (p->work_cap >= need) return S4G_OK;
+    if (!p->d_work) {
+        DeviceCtx* cx = device_ctx(p->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (cx->pf_spare_work && cx->pf_spare_work_cap >= need) {
+            p->d_work = cx->pf_spare_work; p->work_cap = cx->pf_spare_work_cap;
+            cx->pf_spare_work = nullptr; cx->pf_spare_work_cap = 0;
+            return S4G_OK;
+        }
+    }
+    return ensure_dev(p, &p->d_work, &p->work_cap, need);
 }
 
 // bump allocator over the arena
@@ -113,11 +138,6 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     const uint32_t invalid_key = (uint32_t)n_kmer_values;            // sorts behind every real k-mer
     const int key_bits = (int)bits_for(n_kmer_values + 1);
     p->n_words = (uint32_t)(n_kmer_values / 32 + 1);
-    HIP_TRY(hipMalloc((void**)&p->d_letter, 32));
-    HIP_TRY(hipMemcpyAsync(p->d_letter, letter, 32, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMalloc((void**)&p->d_q_kmers, (uint64_t)std::max(1u, p->nq) * 4));
-    HIP_TRY(hipMalloc((void**)&p->d_slots, (uint64_t)p->n_words * 8));
-    HIP_TRY(hipMemsetAsync(p->d_slots, 0, (uint64_t)p->n_words * 8, p->stream));
     std::vector<uint32_t> q_kmers(std::max(1u, p->nq), 0);
     std::vector<uint64_t> rel(p->nq + 1);
     uint64_t longest = 0;
@@ -131,26 +151,39 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     }
     p->f_q_bits = p->q_bits + bits_for(longest + 1) <= 31 ? p->q_bits : 0;
     if (total >= (1ull << 32)) return fail(S4G_ERR_INVALID, "prefilter: more than 2^32 query residues");
+    // the index in ONE device block (eight allocations and as many releases were a third of a millisecond each way), the temporaries of
+    // its construction in the handle's work arena (which the first chunk needs anyway)
+    const uint64_t hits1 = std::max<uint64_t>(1, p->n_hash_hits);
+    const uint64_t index_bytes = 256 + align256((uint64_t)std::max(1u, p->nq) * 4) + align256((uint64_t)p->n_words * 8) + 2 * align256(hits1 * 4) +
+                                 align256(hits1 * 8) + align256((p->n_hash_hits + 2) * 4) + align256((p->n_hash_hits + 1) * 4);
+    if (hipMalloc((void**)&p->d_index, index_bytes) != hipSuccess) return fail(S4G_ERR_NOMEM, "prefilter: cannot allocate %llu bytes of device memory", (unsigned long long)index_bytes);
+    Arena I{p->d_index};
+    p->d_letter = I.take<uint8_t>(32);
+    p->d_q_kmers = I.take<uint32_t>(std::max(1u, p->nq));
+    p->d_slots = I.take<uint2>(p->n_words);
+    p->d_hit_q = I.take<uint32_t>(hits1); p->d_hit_p = I.take<uint32_t>(hits1); p->d_hit_qp = I.take<uint64_t>(hits1);
+    p->d_bounds = I.take<uint32_t>(p->n_hash_hits + 2);
+    p->d_fhit = I.take<uint32_t>(p->n_hash_hits + 1);
+    HIP_TRY(hipMemcpyAsync(p->d_letter, letter, 32, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_slots, 0, (uint64_t)p->n_words * 8, p->stream));
     HIP_TRY(hipMemcpyAsync(p->d_q_kmers, q_kmers.data(), q_kmers.size() * 4, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMalloc((void**)&p->d_hit_q, std::max<uint64_t>(1, p->n_hash_hits) * 4));
-    HIP_TRY(hipMalloc((void**)&p->d_hit_p, std::max<uint64_t>(1, p->n_hash_hits) * 4));
-    HIP_TRY(hipMalloc((void**)&p->d_hit_qp, std::max<uint64_t>(1, p->n_hash_hits) * 8));
-    HIP_TRY(hipMalloc((void**)&p->d_bounds, (p->n_hash_hits + 2) * 4));
     HIP_TRY(hipMemsetAsync(p->d_bounds, 0, (p->n_hash_hits + 2) * 4, p->stream));
-    HIP_TRY(hipMalloc((void**)&p->d_fhit, (p->n_hash_hits + 1) * 4));
-    DevBuf<uint32_t> cnt, before;                        // per index word: present k-mers in it, and before it
-    HIP_TRY(cnt.alloc(p->n_words)); HIP_TRY(before.alloc(p->n_words));
     size_t cub_scan = 0, cub_sort = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)p->n_words, p->stream));
     if (total) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                                           (uint32_t*)nullptr, (int)total, 0, key_bits, p->stream));
-    DevBuf<char> tmp;
-    HIP_TRY(tmp.alloc(std::max(cub_scan, cub_sort)));
-    DevBuf<uint8_t> d_codes; DevBuf<uint64_t> d_off; DevBuf<uint32_t> key, val, key2, val2, pos_q, pos_j;
+    const uint64_t total1 = std::max<uint64_t>(1, total);
+    S4G_TRY(ensure_work(p, 2 * align256((uint64_t)p->n_words * 4) + align256(std::max(cub_scan, cub_sort)) + align256(total1) +
+                               align256(((uint64_t)p->nq + 1) * 8) + 6 * align256(total1 * 4) + 4096));
+    Arena T{p->d_work};
+    struct Buf32 { uint32_t* p; };                       // (the names the code below was written with)
+    const Buf32 cnt{T.take<uint32_t>(p->n_words)}, before{T.take<uint32_t>(p->n_words)};     // per index word: present k-mers in it, and before it
+    struct BufC { char* p; } const tmp{T.take<char>(std::max(cub_scan, cub_sort))};
+    struct Buf8 { uint8_t* p; } const d_codes{T.take<uint8_t>(total1)};
+    struct Buf64 { uint64_t* p; } const d_off{T.take<uint64_t>((uint64_t)p->nq + 1)};
+    const Buf32 key{T.take<uint32_t>(total1)}, val{T.take<uint32_t>(total1)}, key2{T.take<uint32_t>(total1)}, val2{T.take<uint32_t>(total1)},
+                pos_q{T.take<uint32_t>(total1)}, pos_j{T.take<uint32_t>(total1)};
     if (total) {
-        HIP_TRY(d_codes.alloc(total)); HIP_TRY(d_off.alloc(p->nq + 1));
-        HIP_TRY(key.alloc(total)); HIP_TRY(val.alloc(total)); HIP_TRY(key2.alloc(total)); HIP_TRY(val2.alloc(total));
-        HIP_TRY(pos_q.alloc(total)); HIP_TRY(pos_j.alloc(total));
         HIP_TRY(hipMemcpyAsync(d_codes.p, codes + off[0], total, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, p->stream));
         hipLaunchKernelGGL(s4g::pf_query_kmers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, d_codes.p, d_off.p, p->nq, total, p->k,
@@ -172,7 +205,7 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
                            p->n_hash_hits, p->d_slots, p->f_q_bits, p->d_bounds, p->d_fhit);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));            // the temporaries above go out of scope here
+    HIP_TRY(hipStreamSynchronize(p->stream));            // (the host vectors above go out of scope here)
     if (getenv("S4G_PROFILE"))
         fprintf(stderr, "[s4g profile] prefilter index: radix %u, %u slots, allocations + uploads + first kernels queued %.0f us, rest + wait %.0f us\n",
                 p->radix, p->n_words, us(t_index0, t_queued), us(t_queued, Clock::now()));
@@ -209,7 +242,7 @@ int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* 
     size_t cub_scan = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(nt + 1), p->stream));
     const uint64_t b_cnt = align256((uint64_t)(nt + 1) * 8);
-    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, 2 * b_cnt + align256(cub_scan)));
+    S4G_TRY(ensure_work(p, 2 * b_cnt + align256(cub_scan)));
     S4G_TRY(ensure_stage(p, b_cnt));
     uint64_t* d_count = (uint64_t*)p->d_work;
     uint64_t* d_hit_off = (uint64_t*)(p->d_work + b_cnt);
@@ -262,7 +295,7 @@ int add_chunk_general(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* 
                             + align256((uint64_t)p->nq * 4) + b_cub;
         if (p->work_cap < need) {
             // the per-target offsets live at the front of the arena: they are on the host already, the device copy is re-uploaded
-            S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+            S4G_TRY(ensure_work(p, need));
             d_count = (uint64_t*)p->d_work; d_hit_off = (uint64_t*)(p->d_work + b_cnt);
             HIP_TRY(hipMemcpyAsync(d_hit_off, hit_off.data(), (uint64_t)(nt + 1) * 8, hipMemcpyHostToDevice, p->stream));
             HIP_TRY(hipStreamSynchronize(p->stream));
@@ -393,7 +426,7 @@ int add_chunk_fused(s4g_prefilter* p, const uint8_t* d_codes, const uint64_t* d_
         uint64_t merge_bytes = 0;
         S4G_TRY(merge_fused_bytes(p, cand_cap, &merge_bytes));
         const uint64_t need = align256(kCounterWords * 8) + align256((uint64_t)nt * 4) + align256(cand_cap * 4) + align256(cand_cap * 8) + merge_bytes;
-        S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+        S4G_TRY(ensure_work(p, need));
         Arena A{p->d_work};
         unsigned long long* d_counters = A.take<unsigned long long>(kCounterWords);
         overflow = A.take<uint32_t>(nt);
@@ -521,7 +554,8 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
         HIP_TRY(hipDeviceGetAttribute(&lds_bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
         p->lds_keys = 1024;
         while (p->lds_keys < 16384 && (uint64_t)p->lds_keys * 2 * 8 <= (uint64_t)lds_bytes) p->lds_keys *= 2;
-        p->fused = getenv("S4G_PREFILTER_GLOBAL_SORT") == nullptr && p->q_bits + s4g::kPfOrderBits <= 32 && max_candidates <= p->lds_keys / 2;
+        p->fused = getenv("S4G_PREFILTER_GLOBAL_SORT") == nullptr && p->q_bits + s4g::kPfOrderBits <= 32 && max_candidates <= p->lds_keys / 2 &&
+                   offsets[n_queries] - offsets[0] < (1ull << 31);       // (a hit's index in the index beside a flag bit: kmer_prefilter.hip.h, kPfFetch)
         p->scatter = p->fused && n_queries <= s4g::kPfScatterMaxQ && getenv("S4G_PREFILTER_RADIX_MERGE") == nullptr;
         HIP_TRY(hipMalloc((void**)&p->d_list_key, slots * 8));
         if (p->fused) {
@@ -620,7 +654,7 @@ static int rows_to_host(s4g_prefilter* p, const void* d_src, void* h_dst, uint64
 static int finish_fused(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_counts, float* h_scores) {
     const uint64_t slots = (uint64_t)p->nq * p->max_c;
     const uint64_t need = 2 * align256(slots * 4) + align256((uint64_t)p->nq * 4);
-    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+    S4G_TRY(ensure_work(p, need));
     Arena A{p->d_work};
     uint32_t* ids = A.take<uint32_t>(slots); float* scores = A.take<float>(slots);
     uint32_t* counts = A.take<uint32_t>(p->nq);
@@ -653,7 +687,7 @@ S4G_API int s4g_prefilter_finish(s4g_prefilter* p, uint32_t* h_ids, uint32_t* h_
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_sort, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
                                                (uint32_t*)nullptr, (int)slots, 0, (int)(32 + p->list_q_bits), p->stream));
     const uint64_t need = 2 * align256(slots * 8) + 4 * align256(slots * 4) + 2 * align256((uint64_t)p->nq * 4) + align256(cub_sort);
-    S4G_TRY(ensure_dev(p, &p->d_work, &p->work_cap, need));
+    S4G_TRY(ensure_work(p, need));
     Arena A{p->d_work};
     uint64_t* key = A.take<uint64_t>(slots); uint64_t* key2 = A.take<uint64_t>(slots);
     uint32_t* val = A.take<uint32_t>(slots); uint32_t* val2 = A.take<uint32_t>(slots);
@@ -688,8 +722,16 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     if (!p) return S4G_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_slots); (void)hipFree(p->d_bounds); (void)hipFree(p->d_fhit); (void)hipFree(p->d_letter); (void)hipFree(p->d_hit_q); (void)hipFree(p->d_hit_p); (void)hipFree(p->d_hit_qp); (void)hipFree(p->d_q_kmers);
+    (void)hipFree(p->d_index);
     (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
+    {
+        // the staging buffer and the arena stay with the device for its next handle (the larger of what is there and what comes back;
+        // an arena beyond 1 GB is released)
+        DeviceCtx* cx = device_ctx(p->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        if (p->h_stage && p->stage_cap > cx->pf_spare_stage_cap) { std::swap(p->h_stage, cx->pf_spare_stage); std::swap(p->stage_cap, cx->pf_spare_stage_cap); }
+        if (p->d_work && p->work_cap > cx->pf_spare_work_cap && p->work_cap <= (1ull << 30)) { std::swap(p->d_work, cx->pf_spare_work); std::swap(p->work_cap, cx->pf_spare_work_cap); }
+    }
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->h_flags) (void)hipHostFree(p->h_flags);
