@@ -856,22 +856,40 @@ __device__ __forceinline__ void pf_block_sort(uint64_t* keys, uint32_t n) {
 
 // The want-th smallest of the n distinct 64-bit keys in LDS (1 <= want <= n): a radix select, most significant byte first -- per
 // round a 256-bin histogram of the keys that still match the bytes decided so far picks the bin the want-th smallest lies in.
-// Whole block; hist: 256 words, ctl: 2 words of LDS.
+// Whole block (at least 256 threads); hist: 256 words, ctl: 8 words of LDS.
+// The keys are ~score << 32 | id with scores of one narrow range: in the leading rounds nearly every key falls into one bin, and 64 lanes
+// adding to one LDS word take 64 turns -- a wave whose lanes all hold the same bin adds its count once.  The bin is found by a prefix sum
+// over the 256 counters held by 256 threads (one thread walking them paid an LDS round trip per bin: 10 us per round, 24 rounds per add).
 __device__ __forceinline__ uint64_t pf_block_kth(const uint64_t* keys, uint32_t n, uint32_t want, uint32_t* hist, uint32_t* ctl) {
     uint64_t prefix = 0;                         // the bytes of the answer decided so far
     uint32_t remaining = want;                   // its rank among the keys that match them (1-based)
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int shift = 56; shift >= 0; shift -= 8) {
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint64_t k = keys[i];
-            if (shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+            const uint32_t i = i0 + threadIdx.x;
+            const uint64_t k = i < n ? keys[i] : 0;
+            const bool in = i < n && (shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8)));
+            const uint32_t bin = (uint32_t)(k >> shift) & 255u;
+            const unsigned long long live = __ballot(in);
+            if (!live) continue;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)__ffsll((long long)live) - 1);
+            const unsigned long long same = __ballot(in && bin == lead);
+            if (same == live) { if (lane == (uint32_t)__ffsll((long long)live) - 1) atomicAdd(&hist[lead], (uint32_t)__popcll(live)); }
+            else if (in) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0, bin = 0;
-            for (; bin < 255; ++bin) { if (acc + hist[bin] >= remaining) break; acc += hist[bin]; }
-            ctl[0] = bin; ctl[1] = remaining - acc;
+        uint32_t mine = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            mine = hist[threadIdx.x];
+            incl = pf_scan64(mine);
+            if (lane == 63) ctl[4 + wv] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            for (uint32_t w = 0; w < wv; ++w) incl += ctl[4 + w];
+            if (incl - mine < remaining && remaining <= incl) { ctl[0] = threadIdx.x; ctl[1] = remaining - (incl - mine); }
         }
         __syncthreads();
         prefix |= (uint64_t)ctl[0] << shift;
@@ -890,7 +908,7 @@ __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ lis
                                                       const uint64_t* __restrict__ sv, const uint32_t* __restrict__ first, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint64_t pf_keys[];
     __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_ctl[4];
+    __shared__ uint32_t s_ctl[8];
     const uint32_t q = blockIdx.x;
     const uint32_t b = first[q], e = first[q + 1];
     if (b == e) return;
@@ -908,9 +926,15 @@ __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ lis
             const uint64_t kth = pf_block_kth(pf_keys, n, max_c, s_hist, s_ctl);
             if (threadIdx.x == 0) s_ctl[2] = 0;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                const uint64_t k = pf_keys[i];
-                if (k <= kth) mine[atomicAdd(&s_ctl[2], 1u)] = k;          // the keys are distinct: exactly max_c of them pass
+            for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {             // the keys are distinct: exactly max_c of them pass
+                const uint32_t i = i0 + threadIdx.x;
+                const uint64_t k = i < n ? pf_keys[i] : ~0ull;
+                const bool keep = i < n && k <= kth;
+                const unsigned long long m = __ballot(keep);                // one slot reservation per wave, not per key (64 lanes on one LDS word take 64 turns)
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&s_ctl[2], (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (keep) mine[base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = k;
             }
         }
         __syncthreads();                          // (the list just written is read back by the next slice)
