@@ -905,7 +905,8 @@ __device__ __forceinline__ uint64_t pf_block_kth(const uint64_t* keys, uint32_t 
 // block's LDS holds; the new candidates go through it in slices of cap - max_c.  A selection, not a sort: the cut is found by a
 // radix select in LDS and the survivors go straight back to the list.
 __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ list, uint32_t* __restrict__ list_cnt, uint32_t max_c,
-                                                      const uint64_t* __restrict__ sv, const uint32_t* __restrict__ first, uint32_t cap) {
+                                                      const uint64_t* __restrict__ sv, const uint32_t* __restrict__ first, uint32_t cap,
+                                                      uint64_t* __restrict__ worst) {    // worst[q] = the list's largest key once it is full (NULL: not kept)
     extern __shared__ __attribute__((aligned(16))) uint64_t pf_keys[];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[8];
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(512) void pf_merge_lists(uint64_t* __restrict__ lis
             for (uint32_t i = threadIdx.x; i < take; i += blockDim.x) pf_keys[cur + i] = sv[at + i];
             __syncthreads();
             const uint64_t kth = pf_block_kth(pf_keys, n, max_c, s_hist, s_ctl);
-            if (threadIdx.x == 0) s_ctl[2] = 0;
+            if (threadIdx.x == 0) { s_ctl[2] = 0; if (worst) worst[q] = kth; }
             __syncthreads();
             for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {             // the keys are distinct: exactly max_c of them pass
                 const uint32_t i = i0 + threadIdx.x;
@@ -976,14 +977,26 @@ __device__ __forceinline__ void pf_tile_for_each(uint64_t region_cap, const unsi
     }
 }
 
-// q_count[q] += candidates of query q
-__global__ __launch_bounds__(512) void pf_cand_count(const uint32_t* __restrict__ cand_q, uint64_t region_cap, const unsigned long long* __restrict__ counters,
-                                                     uint32_t n_regions, uint64_t single_n, uint32_t nq, uint32_t* __restrict__ q_count) {
-    extern __shared__ uint32_t pf_h[];
+// A candidate that cannot enter its query's list any more is dropped here, before it is moved: worst[q] = the largest key of query q's
+// list once that list is full (pf_merge_lists; ~0 before) -- lists only ever improve, so a key beyond it is beyond the final cut too.
+// (In a stream of many chunks the lists fill up with the first and nearly every later candidate ends here.)
+struct PfQS { uint32_t q; uint64_t sv; };
+
+// q_count[q] += candidates of query q (LDS: a counter and the list's worst key per query = 12 bytes per query)
+__global__ __launch_bounds__(512) void pf_cand_count(const uint32_t* __restrict__ cand_q, const uint64_t* __restrict__ cand_sv, uint64_t region_cap,
+                                                     const unsigned long long* __restrict__ counters, uint32_t n_regions, uint64_t single_n, uint32_t nq,
+                                                     const uint64_t* __restrict__ worst, uint32_t* __restrict__ q_count) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char pf_lds[];
+    uint64_t* lw = reinterpret_cast<uint64_t*>(pf_lds);
+    uint32_t* pf_h = reinterpret_cast<uint32_t*>(pf_lds + (size_t)nq * 8);
     __shared__ uint64_t prefix[kPfRegions + 1];
-    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
-    pf_tile_for_each<uint32_t>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return cand_q[i]; },
-                               [&](uint32_t q) { atomicAdd(&pf_h[q], 1u); });
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { pf_h[q] = 0; lw[q] = worst ? worst[q] : ~0ull; }
+    if (worst)
+        pf_tile_for_each<PfQS>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return PfQS{cand_q[i], cand_sv[i]}; },
+                               [&](const PfQS& c) { if (c.sv <= lw[c.q]) atomicAdd(&pf_h[c.q], 1u); });
+    else                                         // (no list is full yet -- a handle's first chunk: the scores need not be read)
+        pf_tile_for_each<uint32_t>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return cand_q[i]; },
+                                   [&](uint32_t q) { atomicAdd(&pf_h[q], 1u); });
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) atomicAdd(&q_count[q], c); }
 }
@@ -1008,21 +1021,97 @@ __global__ __launch_bounds__(512) void pf_cand_first(const uint32_t* __restrict_
     if (threadIdx.x == 511) first[nq] = part[511];
 }
 
-// out[first[q] ..] = the (score, id) words of query q's candidates, in no particular order
+// out[first[q] ..] = the (score, id) words of query q's candidates (those pf_cand_count counted), in no particular order
 __global__ __launch_bounds__(512) void pf_cand_scatter(const uint32_t* __restrict__ cand_q, const uint64_t* __restrict__ cand_sv, uint64_t region_cap,
                                                        const unsigned long long* __restrict__ counters, uint32_t n_regions, uint64_t single_n,
-                                                       uint32_t nq, uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
-    extern __shared__ uint32_t pf_h[];
+                                                       uint32_t nq, const uint64_t* __restrict__ worst, uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char pf_lds[];
+    uint64_t* lw = reinterpret_cast<uint64_t*>(pf_lds);
+    uint32_t* pf_h = reinterpret_cast<uint32_t*>(pf_lds + (size_t)nq * 8);
     __shared__ uint64_t prefix[kPfRegions + 1];
-    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) pf_h[q] = 0;
-    pf_tile_for_each<uint32_t>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return cand_q[i]; },
-                               [&](uint32_t q) { atomicAdd(&pf_h[q], 1u); });
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { pf_h[q] = 0; lw[q] = worst ? worst[q] : ~0ull; }
+    pf_tile_for_each<PfQS>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return PfQS{cand_q[i], cand_sv[i]}; },
+                           [&](const PfQS& c) { if (c.sv <= lw[c.q]) atomicAdd(&pf_h[c.q], 1u); });
     __syncthreads();
     // the tile's share of every query's range, reserved with one atomic per query that occurs; the counter then becomes the write position
     for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { const uint32_t c = pf_h[q]; if (c) pf_h[q] = atomicAdd(&cursor[q], c); }
-    struct QS { uint32_t q; uint64_t sv; };
-    pf_tile_for_each<QS>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return QS{cand_q[i], cand_sv[i]}; },
-                         [&](const QS& c) { out[atomicAdd(&pf_h[c.q], 1u)] = c.sv; });
+    pf_tile_for_each<PfQS>(region_cap, counters, n_regions, single_n, prefix, [&](uint64_t i) { return PfQS{cand_q[i], cand_sv[i]}; },
+                           [&](const PfQS& c) { if (c.sv <= lw[c.q]) out[atomicAdd(&pf_h[c.q], 1u)] = c.sv; });
+}
+
+// The same for up to kPfStageMaxQ queries, with the tile brought into query order in LDS first: a block's candidates of one query then
+// leave it as ONE run written by neighbouring lanes.  (Scattered 8-byte stores from 226 blocks x 1000 open runs overflow the L2s: lines
+// were evicted half written, 3.3 bytes went to memory per byte of payload.)  A tile is kPfStageTile candidates, 16 per thread, read once
+// and held in registers between the counting and the placing.
+constexpr uint32_t kPfStageMaxQ = 2048;
+constexpr uint32_t kPfStageTile = 8192;
+__host__ __device__ constexpr size_t pf_stage_lds(uint32_t nq) { return (size_t)kPfStageTile * 10 + (size_t)nq * 16; }
+__global__ __launch_bounds__(512) void pf_cand_scatter_staged(const uint32_t* __restrict__ cand_q, const uint64_t* __restrict__ cand_sv, uint64_t region_cap,
+                                                              const unsigned long long* __restrict__ counters, uint32_t n_regions, uint64_t single_n,
+                                                              uint32_t nq, const uint64_t* __restrict__ worst, uint32_t* __restrict__ cursor, uint64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char pf_lds[];
+    uint64_t* stage_sv = reinterpret_cast<uint64_t*>(pf_lds);                       // [kPfStageTile]
+    uint64_t* lw = stage_sv + kPfStageTile;                                          // [nq] worst key of the query's list
+    uint32_t* fill = reinterpret_cast<uint32_t*>(lw + nq);                           // [nq] count, then the next free slot of the query's run in the stage
+    uint32_t* dl = fill + nq;                                                        // [nq] (start of the run in `out`) - (start of the run in the stage)
+    uint16_t* stage_q = reinterpret_cast<uint16_t*>(dl + nq);                        // [kPfStageTile]
+    __shared__ uint64_t prefix[kPfRegions + 1];
+    __shared__ uint32_t wave_tot[8];
+    constexpr int EPT = kPfStageTile / 512;
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t r = 0; r < n_regions; ++r) { prefix[r] = acc; acc += counters ? min((uint64_t)counters[8 * r], region_cap) : single_n; }
+        prefix[n_regions] = acc;
+    }
+    for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) { fill[q] = 0; lw[q] = worst ? worst[q] : ~0ull; }
+    __syncthreads();
+    const uint64_t lo_tile = (uint64_t)blockIdx.x * kPfStageTile, hi_tile = min(prefix[n_regions], lo_tile + kPfStageTile);
+    uint32_t r0 = 0;
+    while (r0 + 1 < n_regions && prefix[r0 + 1] <= lo_tile) ++r0;                    // (uniform)
+    uint32_t q[EPT];
+    uint64_t sv[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint64_t k = lo_tile + (uint64_t)j * 512 + threadIdx.x;
+        q[j] = 0xFFFFFFFFu; sv[j] = 0;
+        if (k < hi_tile) {
+            uint32_t r = r0;
+            while (k >= prefix[r + 1]) ++r;
+            const uint64_t at = (uint64_t)r * region_cap + (k - prefix[r]);
+            q[j] = cand_q[at]; sv[j] = cand_sv[at];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        if (q[j] != 0xFFFFFFFFu && sv[j] > lw[q[j]]) q[j] = 0xFFFFFFFFu;             // cannot enter its list any more
+        if (q[j] != 0xFFFFFFFFu) atomicAdd(&fill[q[j]], 1u);
+    }
+    __syncthreads();
+    // runs in query order: exclusive prefix over the queries' counts (each thread a stretch of queries), their places in `out` reserved
+    const uint32_t per = (nq + 511) / 512;
+    const uint32_t qa = min(nq, threadIdx.x * per), qb = min(nq, qa + per);
+    uint32_t sum = 0;
+    for (uint32_t x = qa; x < qb; ++x) sum += fill[x];
+    const uint32_t incl = pf_scan64(sum);
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += wave_tot[w];
+    uint32_t kept = 0;
+    for (uint32_t w = 0; w < 8; ++w) kept += wave_tot[w];
+    __syncthreads();                                                                 // (every count has been read before any becomes a position)
+    for (uint32_t x = qa; x < qb; ++x) {
+        const uint32_t c = fill[x];
+        dl[x] = (c ? atomicAdd(&cursor[x], c) : 0u) - run;
+        fill[x] = run;
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (q[j] != 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&fill[q[j]], 1u); stage_sv[at] = sv[j]; stage_q[at] = (uint16_t)q[j]; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kept; i += blockDim.x) out[dl[stage_q[i]] + i] = stage_sv[i];
 }
 
 // first[q] = index of the first candidate of query q in the query-sorted array (first[nq] = n): one thread per candidate boundary

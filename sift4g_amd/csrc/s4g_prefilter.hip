@@ -57,9 +57,11 @@ struct s4g_prefilter {
     uint64_t stat_hits = 0, stat_pairs = 0, stat_long = 0, stat_chunks = 0;
     // the fused path (kmer_prefilter.hip.h): lists = nq rows of max_c keys ~score << 32 | id, ascending, d_list_cnt entries used
     bool fused = false;
+    bool lists_filling = true;      // no candidate has been merged yet
     bool scatter = false;           // candidates into query order by the counting pass (pf_cand_*) rather than a radix sort
     uint32_t lds_keys = 0;          // 64-bit keys a block of pf_merge_lists sorts in LDS
     uint32_t* d_list_cnt = nullptr;
+    uint64_t* d_list_worst = nullptr;   // [nq] largest key of a full list (~0 until then): pf_cand_count / pf_cand_scatter drop what lies beyond
     uint64_t cand_guess = 0;        // candidates the last chunk produced (sizes the next chunk's arrays)
     uint64_t stat_overflow = 0, stat_repeats = 0;
 };
@@ -385,11 +387,19 @@ int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* c
         uint32_t* q_count = A.take<uint32_t>((uint64_t)p->nq + 1);
         uint32_t* cursor = A.take<uint32_t>((uint64_t)p->nq + 1);
         const dim3 grid((unsigned)((n_used + s4g::kPfTile - 1) / s4g::kPfTile)), block(512);
-        const size_t lds = (size_t)p->nq * 4;
+        const size_t lds = (size_t)p->nq * 12;
         HIP_TRY(hipMemsetAsync(q_count, 0, ((uint64_t)p->nq + 1) * 4, p->stream));
-        hipLaunchKernelGGL(s4g::pf_cand_count, grid, block, lds, p->stream, cand_q, region_cap, d_counters, n_regions, region_cap, p->nq, q_count);
+        const uint64_t* worst = p->lists_filling ? nullptr : p->d_list_worst;       // (before the first merge every list is empty: nothing to compare with)
+        hipLaunchKernelGGL(s4g::pf_cand_count, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, n_regions, region_cap, p->nq,
+                           worst, q_count);
         hipLaunchKernelGGL(s4g::pf_cand_first, dim3(1), dim3(512), 0, p->stream, q_count, p->nq, first, cursor);
-        hipLaunchKernelGGL(s4g::pf_cand_scatter, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, n_regions, region_cap, p->nq, cursor, sv2);
+        if (p->nq <= s4g::kPfStageMaxQ && !getenv("S4G_PREFILTER_DIRECT_SCATTER"))
+            hipLaunchKernelGGL(s4g::pf_cand_scatter_staged, dim3((unsigned)((n_used + s4g::kPfStageTile - 1) / s4g::kPfStageTile)), block,
+                               s4g::pf_stage_lds(p->nq), p->stream, cand_q, cand_sv, region_cap, d_counters, n_regions, region_cap, p->nq, worst, cursor, sv2);
+        else
+            hipLaunchKernelGGL(s4g::pf_cand_scatter, grid, block, lds, p->stream, cand_q, cand_sv, region_cap, d_counters, n_regions, region_cap, p->nq,
+                               worst, cursor, sv2);
+        p->lists_filling = false;
     } else {
         uint32_t* q2 = A.take<uint32_t>(n);
         size_t cub = arena_bytes - A.at;
@@ -401,7 +411,7 @@ int merge_fused(s4g_prefilter* p, char* arena, uint64_t arena_bytes, uint32_t* c
     // two blocks per CU)
     uint32_t keys = 1024;
     while (keys < p->lds_keys && (uint64_t)p->max_c * 4 > (uint64_t)keys * 3) keys *= 2;
-    hipLaunchKernelGGL(s4g::pf_merge_lists, dim3(p->nq), dim3(512), (size_t)keys * 8, p->stream, p->d_list_key, p->d_list_cnt, p->max_c, sv2, first, keys);
+    hipLaunchKernelGGL(s4g::pf_merge_lists, dim3(p->nq), dim3(512), (size_t)keys * 8, p->stream, p->d_list_key, p->d_list_cnt, p->max_c, sv2, first, keys, p->scatter ? p->d_list_worst : nullptr);
     HIP_TRY(hipGetLastError());
     return S4G_OK;
 }
@@ -561,6 +571,11 @@ S4G_API int s4g_prefilter_create(s4g_prefilter** out, int device, const uint8_t*
         if (p->fused) {
             HIP_TRY(hipMalloc((void**)&p->d_list_cnt, (uint64_t)std::max(1u, n_queries) * 4));
             HIP_TRY(hipMemsetAsync(p->d_list_cnt, 0, (uint64_t)std::max(1u, n_queries) * 4, p->stream));
+            HIP_TRY(hipMalloc((void**)&p->d_list_worst, (uint64_t)std::max(1u, n_queries) * 8));
+            HIP_TRY(hipMemsetAsync(p->d_list_worst, 0xFF, (uint64_t)std::max(1u, n_queries) * 8, p->stream));
+            HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_cand_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s4g::kPfScatterMaxQ * 12)));
+            HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_cand_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(s4g::kPfScatterMaxQ * 12)));
+            HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_cand_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s4g::pf_stage_lds(s4g::kPfStageMaxQ)));
             HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_merge_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->lds_keys * 8)));
             HIP_TRY(hipFuncSetAttribute((const void*)s4g::pf_finish_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->lds_keys * 8)));
         } else {
@@ -723,7 +738,7 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     (void)hipFree(p->d_index);
-    (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
+    (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_list_worst); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     {
         // the staging buffer and the arena stay with the device for its next handle (the larger of what is there and what comes back;
         // an arena beyond 1 GB is released)

@@ -195,10 +195,11 @@ def test_arguments_are_checked():
     p.close()
 
 
-@pytest.mark.parametrize("mode", ["S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_GLOBAL_SORT"])
+@pytest.mark.parametrize("mode", ["S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_DIRECT_SCATTER", "S4G_PREFILTER_GLOBAL_SORT"])
 def test_the_other_merge_paths_agree(monkeypatch, mode):
-    """the candidates reach query order by a counting pass (pf_cand_count / pf_cand_scatter) by default; the radix sort it replaced
-    (still the path beyond 8192 queries) and the all-global general passes give the same lists"""
+    """the candidates reach query order by a counting pass (pf_cand_count, pf_cand_scatter_staged) by default; the scatter without the LDS
+    stage (the path from 2049 to 8192 queries), the radix sort they replaced (still the path beyond 8192 queries) and the all-global
+    general passes give the same lists.  Three chunks and lists of 60: the later chunks meet full lists (candidates dropped early)."""
     queries, targets = _workload(21, 40, 6000)
     chunks = [targets[:2500], targets[2500:2501], targets[2501:]]
     base, ref, stats = _both(queries, chunks, 5, 60)
@@ -207,7 +208,7 @@ def test_the_other_merge_paths_agree(monkeypatch, mode):
     monkeypatch.setenv(mode, "1")
     other, ref2, stats2 = _both(queries, chunks, 5, 60)
     _assert_equal(other, ref2)
-    assert stats2["fused"] == (mode == "S4G_PREFILTER_RADIX_MERGE")
+    assert stats2["fused"] == (mode != "S4G_PREFILTER_GLOBAL_SORT")
 
 
 def test_more_queries_than_the_counting_pass_holds():
