@@ -113,7 +113,7 @@ constexpr uint32_t kPfMore = 0x80000000u;
 constexpr uint32_t kPfNoBucket = 0xFFFFFFFFu;   // PfBlock::first of a position whose one hit is in hq / hp
 __global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ pos_q,
                                  const uint32_t* __restrict__ pos_j, uint64_t n_hits, const uint2* __restrict__ slots, uint32_t f_q_bits,
-                                 uint32_t* __restrict__ bounds, uint32_t* __restrict__ fhit) {
+                                 uint32_t pack_limit, uint32_t* __restrict__ bounds, uint32_t* __restrict__ fhit) {      // pack_limit: 2^23 (0: nothing is packed)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint32_t v = sorted_key[i];
@@ -124,7 +124,7 @@ __global__ void pf_bucket_bounds(const uint32_t* __restrict__ sorted_key, const 
         uint32_t cnt = 1;
         while (cnt < 256 && i + cnt < n_hits && sorted_key[i + cnt] == v) ++cnt;
         if (f_q_bits != 0 && cnt == 1) fhit[r] = (pos_j[g] << f_q_bits) | pos_q[g];
-        else fhit[r] = kPfMore | (cnt < 256 && i < (1u << 23) ? ((uint32_t)i << 8) | cnt : 0u);
+        else fhit[r] = kPfMore | (cnt < 256 && i < pack_limit ? ((uint32_t)i << 8) | cnt : 0u);
     }
     if (i + 1 == n_hits) bounds[r + 1] = (uint32_t)n_hits;
 }

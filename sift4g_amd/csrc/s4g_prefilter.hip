@@ -151,7 +151,10 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
         p->n_hash_hits += q_kmers[q];
         longest = std::max(longest, len);
     }
-    p->f_q_bits = p->q_bits + bits_for(longest + 1) <= 31 ? p->q_bits : 0;
+    // (S4G_PREFILTER_UNPACKED=1: the tests' switch for the two fallbacks no ordinary query set reaches -- hits that do not fit a bucket
+    // word beside their query, buckets beyond 2^23 -- every lookup then goes through bounds[] and hit_qp)
+    const bool unpacked = getenv("S4G_PREFILTER_UNPACKED") != nullptr;
+    p->f_q_bits = !unpacked && p->q_bits + bits_for(longest + 1) <= 31 ? p->q_bits : 0;
     if (total >= (1ull << 32)) return fail(S4G_ERR_INVALID, "prefilter: more than 2^32 query residues");
     // the index in ONE device block (eight allocations and as many releases were a third of a millisecond each way), the temporaries of
     // its construction in the handle's work arena (which the first chunk needs anyway)
@@ -204,7 +207,7 @@ int build_index(s4g_prefilter* p, const uint8_t* codes, const uint64_t* off) {
     hipLaunchKernelGGL(s4g::pf_slot_rank, dim3((p->n_words + 255) / 256), dim3(256), 0, p->stream, p->d_slots, p->n_words, before.p);
     if (p->n_hash_hits)
         hipLaunchKernelGGL(s4g::pf_bucket_bounds, dim3((unsigned)((p->n_hash_hits + 255) / 256)), dim3(256), 0, p->stream, key2.p, val2.p, pos_q.p, pos_j.p,
-                           p->n_hash_hits, p->d_slots, p->f_q_bits, p->d_bounds, p->d_fhit);
+                           p->n_hash_hits, p->d_slots, p->f_q_bits, unpacked ? 0u : 1u << 23, p->d_bounds, p->d_fhit);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_flags, p->d_flags, 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));            // (the host vectors above go out of scope here)

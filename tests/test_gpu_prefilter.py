@@ -195,11 +195,13 @@ def test_arguments_are_checked():
     p.close()
 
 
-@pytest.mark.parametrize("mode", ["S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_DIRECT_SCATTER", "S4G_PREFILTER_GLOBAL_SORT"])
+@pytest.mark.parametrize("mode", ["S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_DIRECT_SCATTER", "S4G_PREFILTER_UNPACKED", "S4G_PREFILTER_GLOBAL_SORT"])
 def test_the_other_merge_paths_agree(monkeypatch, mode):
     """the candidates reach query order by a counting pass (pf_cand_count, pf_cand_scatter_staged) by default; the scatter without the LDS
     stage (the path from 2049 to 8192 queries), the radix sort they replaced (still the path beyond 8192 queries) and the all-global
-    general passes give the same lists.  Three chunks and lists of 60: the later chunks meet full lists (candidates dropped early)."""
+    general passes give the same lists; so does the index without packed bucket words (what a query set of more than 2^23 residues, or
+    of positions and query numbers beyond 31 bits together, falls back to).  Three chunks and lists of 60: the later chunks meet full
+    lists (candidates dropped early)."""
     queries, targets = _workload(21, 40, 6000)
     chunks = [targets[:2500], targets[2500:2501], targets[2501:]]
     base, ref, stats = _both(queries, chunks, 5, 60)
@@ -267,10 +269,15 @@ def test_randomised_soak():
         cuts = sorted(set(int(x) for x in rng.integers(0, len(targets) + 1, size=int(rng.integers(0, 4)))))
         chunks = [targets[a:b] for a, b in zip([0] + cuts, cuts + [len(targets)])]
         os.environ["S4G_PREFILTER_PASS_HITS"] = str(int(rng.choice([1000, 50000, 1 << 26])))
+        switch = str(rng.choice(["", "", "S4G_PREFILTER_RADIX_MERGE", "S4G_PREFILTER_DIRECT_SCATTER", "S4G_PREFILTER_UNPACKED", "S4G_PREFILTER_GLOBAL_SORT"]))
+        if switch:
+            os.environ[switch] = "1"
         try:
             dev, ref, _ = _both(queries, chunks, k, max_candidates)
         finally:
             del os.environ["S4G_PREFILTER_PASS_HITS"]
+            if switch:
+                del os.environ[switch]
         _assert_equal(dev, ref)
         rounds += 1
     assert rounds >= 6
