@@ -3,8 +3,9 @@
 // What the reference does on its thread pool (/root/reference/sift4g/src/database_search.cpp:185-253, hash.cpp:21-90), per
 // database chunk, as data-parallel passes over HBM-resident arrays:
 //
-//   pf_query_kmers     one thread per query residue: the k-mer that starts there (hash.cpp:21-44) -> sort key, bucket count
-//   (radix sort, scan)  -> the CSR index of hash.cpp:56-85: starts[kmer], hits in (query, position) order inside a bucket
+//   pf_query_kmers     one thread per query residue: the k-mer that starts there (hash.cpp:21-44) -> sort key, presence bit
+//   (radix sort, scan, pf_bucket_bounds)  -> the CSR index of hash.cpp:56-85 by RANK of the present k-mers; hits in (query, position)
+//                      order inside a bucket
 //   pf_target_count    one wave per target: bucket sizes of its k-mers, a k-mer equal to its predecessor skipped (:212-214)
 //   pf_target_emit     one wave per target: the hits themselves, in the order the reference appends them (:216-220): by target
 //                      position, then bucket order -> key (target, query), value = query position
@@ -16,26 +17,29 @@
 //   (radix sort by (query, score descending), stable over ascending target id) + pf_keep -> best max_candidates per query
 //
 // Round 3 -- the fused path (the default; the passes above remain as the general path for targets with more hits than a wave
-// keeps in LDS, for max_candidates beyond what a block sorts in LDS, and behind S4G_PREFILTER_GLOBAL_SORT=1):
+// keeps in LDS, for max_candidates beyond what a block sorts in LDS, and behind S4G_PREFILTER_GLOBAL_SORT=1), as it stands after round 5:
 //
-//   pf_target_lis      one wave per target does ALL of the above for it: bucket sizes, the hits into LDS in the reference's order,
-//                      a wave-wide bitonic sort of (query, order) keys -- the hits of a target are a few dozen to a few hundred --
-//                      segment starts by ballot, the LIS of every segment (a lane per short one, the whole wave per long one, tails
-//                      in LDS) and one (query, ~score | id) candidate per segment appended to a global array.  Hits never touch HBM.
-//   (radix sort of the candidates by query: 10 bits of key)
+//   pf_target_lis      one wave per target (dealt out by 64 counters) does ALL of the above for it: the index lookups of its k-mers
+//                      (three dependent loads, issued for the wave's NEXT target before this one is processed), the hits into LDS in the
+//                      reference's order (DPP prefix sums; hits of shared buckets by reference, fetched by all lanes at once), the
+//                      (query, order) keys sorted IN REGISTERS (bitonic; DPP / swizzle partners), segment starts by ballot, the LIS of
+//                      every segment (a lane per short one; the whole wave per long one, tails in registers) and one
+//                      (query, ~score | id) candidate per segment appended to one of 64 regions of a global array.  Hits never touch HBM.
+//   pf_cand_count, pf_cand_first, pf_cand_scatter_staged
+//                      the candidates into query order by counting (a tile sorted in LDS, one run per query written out); candidates
+//                      beyond the worst key of a list that is full are dropped here.  (pf_cand_scatter: without the LDS stage, 2049 ..
+//                      8192 queries; rocPRIM's radix sort beyond.)
 //   pf_merge_lists     one block per query: its running list and its new candidates in LDS, the cut found by a radix select, the
 //                      best max_candidates kept (unordered)
 //   pf_finish_rows     one block per query: its list by ascending id -> the rows the caller gets
 //
-// Round 5 -- the index is COMPACT (hash.cpp:56-85 keeps a vector per possible k-mer: 32^5 slots): one 8-byte slot per 32 possible
-// k-mers = (presence bits, number of present k-mers before this word), and the bucket bounds of the PRESENT k-mers only, indexed by
-// that rank.  A thousand queries hold ~350 000 distinct k-mers: 8 MB of slots (of which the 20-letter alphabet touches a quarter) and
-// 1.4 MB of bounds instead of a 134 MB table whose every lookup was a 128-byte line from the fabric (round 4: 3/5 of the kernel's
-// counter traffic).  And the candidates are brought into query order by ONE counting pass (pf_cand_count / pf_cand_scatter) instead
-// of a two-pass radix sort over the whole capacity of the candidate regions.
+// The index is COMPACT (hash.cpp:56-85 keeps a vector per possible k-mer: 32^5 slots): a k-mer is a number in the radix of the letters
+// the queries use (pf_kmer), slots[kmer >> 5] = (32 presence bits, number of present k-mers before the word), fhit[rank] = the bucket in
+// one word (pf_bucket_bounds), bounds[rank] for what does not fit one.  A thousand queries: 1 MB + 1.3 MB, L2-resident, instead of a
+// 134 MB table whose every lookup was a 128-byte line from the fabric (round 4: 3/5 of the kernel's counter traffic).
 //
-// HBM-bound integer work: no MFMA anywhere; what matters is coalesced target reads (a wave walks one target), index lookups that stay
-// in L2, and writes that leave a block as whole lines.
+// Integer gather work, bound by vector issue: no MFMA anywhere; what matters is instructions per hit, index lookups that stay in L2,
+// no dependent memory round trip inside a per-lane loop, and writes that leave a block as whole runs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(64) void pf_lis_long(PfLisArgs a) {
 
 // =====================================================================================================================
 // The fused path.
-constexpr uint32_t kPfCap = 512;                // hits a wave groups in LDS at a time (6 KB per wave: 6 waves per SIMD)
+constexpr uint32_t kPfCap = 512;                // hits a wave groups in LDS at a time (6 KB per wave)
 constexpr uint32_t kPfOrderBits = 9;            // log2(kPfCap): a sort key is query << kPfOrderBits | position in the reference's order
 constexpr uint32_t kPfMaxLong = 16;             // long segments (more than kPfSmallMax hits) kPfCap hits can hold
 constexpr uint32_t kPfRanges = 64;              // a target with more hits is walked once per RANGE OF QUERIES: histogram of its hits over
@@ -714,7 +718,9 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
     ck.mark(5);
 }
 
-// One wave per target (grid-stride).  See the header of this file.
+// One wave per target.  See the header of this file.
+// (Four waves per SIMD at ~112 VGPRs, no spills.  At five and six -- 36 and 84 bytes of scratch -- the kernel takes the same time:
+// it is bound by vector issue, not by latency.  -DPF_WPE=n rebuilds it for n.)
 #ifndef PF_WPE
 #define PF_WPE 4
 #endif
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WPE, PF_
     const uint32_t q_per_range = (a.nq + kPfRanges - 1) / kPfRanges;
     unsigned long long sum_hits = 0, sum_long = 0;
     unsigned wrong = 0;
-    // The four dependent rounds of loads of a target's first 256 positions are issued BEFORE the previous target's hits are sorted and
+    // The three dependent rounds of loads of a target's first 256 positions are issued BEFORE the previous target's hits are sorted and
     // walked, so they are there when its turn comes (three targets in four are no longer than that).
     PfBlock ahead;
     uint64_t o_next = 0;
