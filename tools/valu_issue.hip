@@ -22,7 +22,7 @@ enum Op { ADD_VV, ADD_SV, ADD_K, ADD_SDWA, MAX_VV, MAX3_VVV, MAX3_VVS, SUBREV_SV
           PK_ADD, PK_SUB_S, PK_MAX, PK_MAX3, PK_MAX3_S, FMA_F32, ADD_F32, MAX_F32, MAX3_F32, PK_FMA_F32, PK_ADD_F32,
           MIX_I32D, MIX_PKD, LSHL_ADD, AND_OR, CNDMASK,
           SUB_VV, AND_VV, OR_VV, XOR_VV, LSHLREV_K, ASHRREV_K, MINU_VV, MAXU_VV, MUL_F32, SUB_F32, MIN_F32, ADD_U16, MAX_U16, ADDCO, MOV_DPP, ADD_DPP,
-          ADD_LIT, BFE_I32, MUL_U24, MAD_U24, ADD3, FMAC_F32, ADD_F16, PK_ADD_F16, PK_MUL_F16, CVT_F32_I32, MIX_NEW, MIX_RUN8, MIX_RUN32, MIX_RUN128, MIX_SAMEOP, N_OPS };
+          ADD_LIT, BFE_I32, MUL_U24, MAD_U24, ADD3, FMAC_F32, ADD_F16, PK_ADD_F16, PK_MUL_F16, CVT_F32_I32, MIX_NEW, MIX_RUN8, MIX_RUN32, MIX_RUN128, MIX_SAMEOP, MIX_PKC, N_OPS };
 static const char* kNames[N_OPS] = {
     "v_add_u32 v,v,v", "v_add_u32 v,s,v", "v_add_u32 v,64,v", "v_add_u32_sdwa sext(BYTE_1)", "v_max_i32 v,v,v", "v_max3_i32 v,v,v,v",
     "v_max3_i32 v,v,v,s", "v_subrev_u32 v,s,v", "v_sub_u32 clamp", "v_mov_b32", "v_perm_b32",
@@ -34,7 +34,8 @@ static const char* kNames[N_OPS] = {
     "v_mul_f32", "v_sub_f32", "v_min_f32", "v_add_u16", "v_max_u16", "v_add_co_u32 (vcc)", "v_mov_b32_dpp row_shr:1", "v_add_u32_dpp row_shr:1",
     "v_add_u32 v,0x12345,v (literal)", "v_bfe_i32 v,v,8,8", "v_mul_u32_u24", "v_mad_u32_u24", "v_add3_u32", "v_fmac_f32", "v_add_f16", "v_pk_add_f16", "v_pk_mul_f16",
     "v_cvt_f32_i32", "mix 4 fast (v_add/v_sub v,v,v) + 3.5 slow (v_pk_maximum3_f16): the 5.5-op packed recurrence",
-    "the same mix in runs: 8 fast, then 7 slow", "runs: 32 fast, then 28 slow", "runs: 128 fast, then 112 slow", "isolated mix, every fast op the same v_add_u32"};
+    "the same mix in runs: 8 fast, then 7 slow", "runs: 32 fast, then 28 slow", "runs: 128 fast, then 112 slow", "isolated mix, every fast op the same v_add_u32",
+    "mix of sw_scan_pkc (add v,v; max3; add v,v; max3 s; pk max; sub v,v; 1 max3 per 2 rows): 6 fast + 7 slow"};
 
 // instruction mixes in the proportions of the recurrences, fully unrolled at compile time
 template <int OP, int I>
@@ -59,6 +60,13 @@ __device__ __forceinline__ void mix_one(unsigned& x, unsigned vb, unsigned vc, u
         constexpr int F = OP == MIX_RUN8 ? 8 : OP == MIX_RUN32 ? 32 : 128, S = F / 8 * 7;
         if constexpr (I % (F + S) < F) { if constexpr ((I & 1) == 0) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "v"(vb)); else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(vb)); }
         else asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(vb), "v"(vc));
+    } else if constexpr (OP == MIX_PKC) {  // one sw_scan_pkc row pair (round 5, column frame): 13 instructions, 6 of them two-VGPR 32-bit add / sub
+        constexpr int m = I % 13;
+        if constexpr (m == 0 || m == 6 || m == 2 || m == 8) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "v"(vb));
+        else if constexpr (m == 1 || m == 7 || m == 12) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(vb), "v"(vc));
+        else if constexpr (m == 3 || m == 9) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(vb), "s"(sb));
+        else if constexpr (m == 4 || m == 10) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(x) : "v"(vb));
+        else asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(vb));
     } else if constexpr (OP == MIX_SAMEOP) {
         constexpr int kind[15] = {0, 1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 1};
         if constexpr (kind[I % 15] == 0) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "v"(vb));
@@ -201,10 +209,10 @@ int run(int cus, int waves_per_simd, double* out_cyc, double* out_tops) {
 
 template <int OP>
 int row(int cus) {
-    double c[4], t[4];
-    const int ws[4] = {1, 2, 3, 8};
-    for (int i = 0; i < 4; ++i) if (run<OP>(cus, ws[i], &c[i], &t[i])) return 1;
-    printf("%-86s %6.2f %6.2f %6.2f %6.2f   %6.1f %6.1f\n", kNames[OP], c[0], c[1], c[2], c[3], t[2], t[3]);
+    double c[5], t[5];
+    const int ws[5] = {1, 2, 3, 4, 8};
+    for (int i = 0; i < 5; ++i) if (run<OP>(cus, ws[i], &c[i], &t[i])) return 1;
+    printf("%-86s %6.2f %6.2f %6.2f %6.2f %6.2f   %6.1f %6.1f %6.1f\n", kNames[OP], c[0], c[1], c[2], c[3], c[4], t[2], t[3], t[4]);
     return 0;
 }
 
@@ -217,8 +225,8 @@ int all(int cus, int first) {
 int main(int argc, char** argv) {
     hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
     printf("%s, %d CUs; shader clocks (s_memtime) per wave64 instruction and SIMD, from the slowest wave; %d chains x %d x %d instructions;\n"
-           "last two columns: T lane-ops/s by HIP events (launch included) at 3 and 8 waves per SIMD\n",
+           "last three columns: T lane-ops/s by HIP events (launch included) at 3, 4 and 8 waves per SIMD\n",
            p.gcnArchName, p.multiProcessorCount, CH, REP, LOOPS);
-    printf("%-86s %6s %6s %6s %6s   %6s %6s   (waves per SIMD)\n", "instruction", "1", "2", "3", "8", "3", "8");
+    printf("%-86s %6s %6s %6s %6s %6s   %6s %6s %6s   (waves per SIMD)\n", "instruction", "1", "2", "3", "4", "8", "3", "4", "8");
     return all<0>(p.multiProcessorCount, argc > 1 ? atoi(argv[1]) : 0);
 }
