@@ -649,46 +649,57 @@ __device__ __forceinline__ void pf_process(const PfFused& a, uint32_t total, uin
         const unsigned long long bal = __ballot(start);
         const uint32_t rank = rank0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         rank0 += (uint32_t)__popcll(bal);
+        uint32_t n_mine = 0;                                     // hits of the segment that starts in this lane (0: none does)
         if (start) {
             // length: up to the next segment start -- in this chunk of 64 by the ballot, beyond it by looking
             const unsigned long long later = lane < 63 ? bal >> (lane + 1) : 0ull;
             uint32_t n;
             if (later) n = (uint32_t)__ffsll((long long)later);
             else { n = min(64u - lane, total - i); while (i + n < total && (key[i + n] >> kPfOrderBits) == q) ++n; }
-            if (n == 1) emit(q, 1, slot0 + rank);
-            else if (n <= 8) {
-                // the hits in registers (independent LDS reads), then the quadratic recurrence without touching LDS again:
-                // L[i] = 1 + max{L[j]: j < i, x[j] < x[i]} -- the same longest strictly increasing run as the tails method finds
-                int32_t x[8];
-                uint32_t L[8];
+            n_mine = n;
+        }
+        // (one copy of each path and of the candidate's division and stores for the whole chunk, each behind a uniform test)
+        const uint32_t n_short = n_mine <= 8 ? n_mine : 0;                     // 2 .. 8 hits: in registers
+        uint32_t lis = 1;
+        const unsigned long long any_short = __ballot(n_short >= 2);
+        if (any_short) {
+            // the hits in registers (independent LDS reads), then the quadratic recurrence without touching LDS again:
+            // L[i] = 1 + max{L[j]: j < i, x[j] < x[i]} -- the same longest strictly increasing run as the tails method finds.
+            // Unrolled to eight, cut off (uniformly) at the longest such segment of the chunk.
+            uint32_t reach = n_short;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = (uint32_t)k < n ? (int32_t)pos[key[i + k] & (kPfCap - 1)] : 0x7FFFFFFF;
-                uint32_t best = 1;
+            for (int d = 32; d >= 1; d >>= 1) reach = max(reach, (uint32_t)__shfl_xor((int)reach, d, 64));
+            reach = (uint32_t)__builtin_amdgcn_readfirstlane((int)reach);
+            int32_t x[8];
+            uint32_t L[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    uint32_t l = 1;
+            for (int k = 0; k < 8; ++k) x[k] = (uint32_t)k < n_short ? (int32_t)pos[key[i + k] & (kPfCap - 1)] : 0x7FFFFFFF;
 #pragma unroll
-                    for (int j = 0; j < k; ++j) if (x[j] < x[k] && L[j] + 1 > l) l = L[j] + 1;
-                    L[k] = l;
-                    if ((uint32_t)k < n && l > best) best = l;
-                }
-                emit(q, best, slot0 + rank);
-            } else if (n > kPfSmallMax) {
-                const uint32_t w = atomicAdd(&lng[0], 1u);          // (at most kPfCap / (kPfSmallMax + 1) < kPfMaxLong of them)
-                lng[1 + 3 * w] = i; lng[2 + 3 * w] = n; lng[3 + 3 * w] = rank;
-            } else {
-                int32_t* T = tail + i;                               // T[l] = smallest last element of an increasing run of length l + 1
-                uint32_t best = 0;
-                for (uint32_t k = 0; k < n; ++k) {
-                    const int32_t x = (int32_t)pos[key[i + k] & (kPfCap - 1)];
-                    uint32_t l = 0, u = best;                        // first l in [0, best] with T[l] >= x  (T[best] = +inf)
-                    while (u > l) { const uint32_t mid = (l + u) / 2; if (T[mid] < x) l = mid + 1; else u = mid; }
-                    T[l] = x;
-                    best = l + 1 > best ? l + 1 : best;
-                }
-                emit(q, best, slot0 + rank);
+            for (int k = 0; k < 8; ++k) {
+                if ((uint32_t)k >= reach) break;
+                uint32_t l = 1;
+#pragma unroll
+                for (int j = 0; j < k; ++j) if (x[j] < x[k] && L[j] + 1 > l) l = L[j] + 1;
+                L[k] = l;
+                if ((uint32_t)k < n_short && l > lis) lis = l;
             }
         }
+        if (n_mine > kPfSmallMax) {
+            const uint32_t w = atomicAdd(&lng[0], 1u);          // (at most kPfCap / (kPfSmallMax + 1) < kPfMaxLong of them)
+            lng[1 + 3 * w] = i; lng[2 + 3 * w] = n_mine; lng[3 + 3 * w] = rank;
+        } else if (n_mine > 8) {
+            int32_t* T = tail + i;                               // T[l] = smallest last element of an increasing run of length l + 1
+            uint32_t best = 0;
+            for (uint32_t k = 0; k < n_mine; ++k) {
+                const int32_t xk = (int32_t)pos[key[i + k] & (kPfCap - 1)];
+                uint32_t l = 0, u = best;                        // first l in [0, best] with T[l] >= x  (T[best] = +inf)
+                while (u > l) { const uint32_t mid = (l + u) / 2; if (T[mid] < xk) l = mid + 1; else u = mid; }
+                T[l] = xk;
+                best = l + 1 > best ? l + 1 : best;
+            }
+            lis = best;
+        }
+        if (n_mine >= 1 && n_mine <= kPfSmallMax) emit(q, lis, slot0 + rank);
     }
     pf_lds_fence();
     ck.mark(4);
