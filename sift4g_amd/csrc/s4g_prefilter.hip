@@ -744,10 +744,10 @@ S4G_API int s4g_prefilter_destroy(s4g_prefilter* p) {
     (void)hipFree(p->d_list_key); (void)hipFree(p->d_list_val); (void)hipFree(p->d_list_cnt); (void)hipFree(p->d_list_worst); (void)hipFree(p->d_codes); (void)hipFree(p->d_off);
     {
         // the staging buffer and the arena stay with the device for its next handle (the larger of what is there and what comes back;
-        // an arena beyond 1 GB is released)
+        // a staging buffer beyond 64 MB of pinned memory and an arena beyond 1 GB are released)
         DeviceCtx* cx = device_ctx(p->device);
         std::lock_guard<std::mutex> lk(cx->mu);
-        if (p->h_stage && p->stage_cap > cx->pf_spare_stage_cap) { std::swap(p->h_stage, cx->pf_spare_stage); std::swap(p->stage_cap, cx->pf_spare_stage_cap); }
+        if (p->h_stage && p->stage_cap > cx->pf_spare_stage_cap && p->stage_cap <= (64ull << 20)) { std::swap(p->h_stage, cx->pf_spare_stage); std::swap(p->stage_cap, cx->pf_spare_stage_cap); }
         if (p->d_work && p->work_cap > cx->pf_spare_work_cap && p->work_cap <= (1ull << 30)) { std::swap(p->d_work, cx->pf_spare_work); std::swap(p->work_cap, cx->pf_spare_work_cap); }
     }
     (void)hipFree(p->d_work); (void)hipFree(p->d_flags);
