@@ -661,7 +661,11 @@ def main():
                 "clock_in_kernel": {"shader_mhz": round(clock_mhz, 1), "min_block": round(clk["shader_mhz_min"], 1),
                                     "max_block": round(clk["shader_mhz_max"], 1), "blocks": clk["blocks"],
                                     "kernel_ms_by_100MHz_counter": round(clk["kernel_ms"], 3), "tier": clk["tier"],
-                                    "launches_sampled": clk["launches"]},
+                                    "launches_sampled": clk["launches"],
+                                    # how long the persistent blocks were busy, mean over blocks / the longest: what is missing to 1 is the
+                                    # drain of the work queue (few long items: configs[4] 0.94; configs[1] 0.999)
+                                    "block_busy_ms": {"mean": round(clk["block_ms_mean"], 3), "min": round(clk["block_ms_min"], 3)},
+                                    "blocks_busy_frac": round(clk["block_ms_mean"] / clk["kernel_ms"], 4) if clk["kernel_ms"] > 0 else None},
                 "peak_at_measured_clock": round(valu_peak_meas, 3) if valu_peak_meas else None,
                 "frac_algorithmic_at_measured_clock": round(valu_achieved / valu_peak_meas, 4) if valu_peak_meas else None,
                 "frac_executed_at_measured_clock": round(valu_executed / valu_peak_meas, 4) if valu_executed and valu_peak_meas else None,

@@ -299,8 +299,10 @@ int s4g_scan_stats(int device, uint64_t* out, uint32_t cap);
  * drained.  out[0] = launches sampled in the call (at most 16); for the LONGEST of them: out[1] = shader clock in MHz, mean over
  * blocks of d(s_memtime) / d(s_memrealtime) x 100, out[2] / out[3] = smallest / largest block value, out[4] = blocks that
  * contributed, out[5] = duration in ms by the 100 MHz counter (longest block), out[6] = tier of that launch (0 drifting frame,
- * 1 maximum3, 2 plain int16, 3 int32), out[7] = shader clocks of the longest block.  All zero if the call launched no scan
- * kernel.  cap >= 8.  This is the clock bench.py prices the vector-issue roofline with. */
+ * 1 maximum3, 2 plain int16, 3 int32), out[7] = shader clocks of the longest block; with cap >= 10 also out[8] / out[9] = mean / shortest
+ * block duration in ms (mean / out[5] = the share of the launch the persistent blocks were busy: the rest is the drain of the work
+ * queue, which matters when items are few and long -- 64 queries of 5000 residues: 0.94; 1000 of 350: 0.999).  All zero if the call
+ * launched no scan kernel.  cap >= 8.  This is the clock bench.py prices the vector-issue roofline with. */
 int s4g_scan_clock(int device, double* out, uint32_t cap);
 
 /* Starts, once per device and on a thread of its own, everything a process pays before its first scan: HIP context, code

@@ -190,6 +190,8 @@ struct DeviceCtx {
     // clock samples of the scan launches of the last call (s4g_scan_clock; sw_kernels.hip.h clk_enter / clk_leave): a region of
     // 4 counters per block for each of the call's first kClkLaunches launches
     int max3_state = 0;                  // ensure_max3: 0 not yet checked, 1 the integer-max3-on-f16-patterns argument holds here, -1 it does not
+    char* d_order[2] = {nullptr, nullptr};   // item orders of launches of few, long items (s4g_scan.hip, item_order): main / side stream
+    uint64_t order_cap[2] = {0, 0};
     unsigned long long* d_clk = nullptr;
     uint64_t clk_cap = 0;                // counters allocated
     struct ClkLaunch { uint64_t off; uint32_t blocks; int tier; };

@@ -2,6 +2,7 @@
 // /root/reference/sift4g/src/database_alignment.cpp:83-86) and the device top-k (steps 2-3): per-tile plan, tier routing,
 // persistent-grid launches, streaming scan + running top-k.
 #include "s4g_internal.hpp"
+#include <hipcub/hipcub.hpp>
 
 // ---------------------------------------------------------------------------
 
@@ -215,8 +216,9 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             }
         }
         TileWork w;
-        // critical-path items: larger than a quarter of the per-wave share of their launch (only then can unfair issue
-        // arbitration between co-resident waves stretch the launch)
+        // critical-path items: measured against a quarter of the per-wave share of their launch (sw_kernels.hip.h, item_priority: three
+        // priority levels a factor of four apart; only items of that order can let unfair issue arbitration between co-resident waves
+        // stretch the launch)
         for (int tier = 0; tier < 3; ++tier) {
             if (ids[tier].empty()) continue;
             double rows_sum = 0;
@@ -261,6 +263,57 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
     return S4G_OK;
 }
 
+// ---- launches of few, long items ----
+// The work queue hands out items group-major (longest database groups first, every query pair of a group in turn): with hundreds of
+// items per wave that is as good as any order.  64 queries of 2000-5000 residues against 100 000 targets are 12 items per wave of up to
+// half a second each, and the order matters: in the anti-diagonal of (group, pair) costs the queue reaches items of 100+ ms when most
+// waves have 100 ms left -- the blocks were busy 0.94 of such a launch (s4g_scan_clock: mean / longest block).  Below kOrderItemsPerWave
+// items per wave the items are dealt out by cost instead, rows x columns, largest first (one small sort on the device per launch).
+constexpr uint64_t kOrderItemsPerWave = 48;
+__global__ void scan_item_cost(uint32_t n_groups, uint32_t n_pairs, const uint32_t* __restrict__ grp_len4, const uint32_t* __restrict__ pairs,
+                               const uint32_t* __restrict__ q_len, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * n_pairs) return;
+    const uint32_t g = i / n_pairs, pi = i - g * n_pairs;
+    const uint32_t qA = pairs[2 * pi], qB = pairs[2 * pi + 1];
+    const uint32_t rows = std::max(q_len[qA], qB != 0xFFFFFFFFu ? q_len[qB] : 0u);
+    key[i] = (uint64_t)grp_len4[g] * rows;
+    val[i] = i;
+}
+static bool item_order_enabled() {
+    static const bool on = []() { const char* e = getenv("S4G_SCAN_ITEM_ORDER"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// -> *out = device array of the launch's items by descending cost, or NULL (many items per wave, or switched off)
+static int item_order(DeviceCtx* cx, int which, hipStream_t stream, uint32_t n_groups, uint32_t n_pairs, uint32_t blocks, const uint32_t* grp_len4,
+                      const uint32_t* pairs, const uint32_t* q_len, const uint32_t** out) {
+    *out = nullptr;
+    const uint64_t n = (uint64_t)n_groups * n_pairs;
+    if (!item_order_enabled() || n < 2 || n >= kOrderItemsPerWave * blocks * kWavesPerBlock) return S4G_OK;
+    size_t cub = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                                         (uint32_t*)nullptr, (int)n, 0, 48, stream));
+    const auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
+    const uint64_t need = 2 * al(n * 8) + 2 * al(n * 4) + al(cub);
+    if (cx->order_cap[which] < need) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (cx->d_order[which]) (void)hipFree(cx->d_order[which]);
+        cx->d_order[which] = nullptr; cx->order_cap[which] = 0;
+        if (hipMalloc((void**)&cx->d_order[which], need + need / 4) != hipSuccess) return fail(S4G_ERR_NOMEM, "cannot allocate %llu bytes for the item order", (unsigned long long)need);
+        cx->order_cap[which] = need + need / 4;
+    }
+    char* b = cx->d_order[which];
+    uint64_t* key = (uint64_t*)b;                   b += al(n * 8);
+    uint64_t* key2 = (uint64_t*)b;                  b += al(n * 8);
+    uint32_t* val = (uint32_t*)b;                   b += al(n * 4);
+    uint32_t* val2 = (uint32_t*)b;                  b += al(n * 4);
+    hipLaunchKernelGGL(scan_item_cost, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n_groups, n_pairs, grp_len4, pairs, q_len, key, val);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(b, cub, key, key2, val, val2, (int)n, 0, 48, stream));
+    HIP_TRY(hipGetLastError());
+    *out = val2;
+    return S4G_OK;
+}
+
 // One tile: one launch per non-empty tier.  perm/stride select the output layout: original ids into the caller's
 // [q][n_seqs] matrix, or tile columns.
 int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_queries* q, const s4g_scorer* scorer, const Plan& p,
@@ -298,11 +351,13 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     a.n_groups = n_groups; a.q_begin = q_begin;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext;
     a.spec_base = 0;
+    a.order = nullptr;
     if (w.n_drift) {
         a.pairs = cx->d_qlist + w.off_drift; a.n_pairs = w.n_drift; a.counter = counters + 3; a.prio_cost = w.prio_cost[0];
         a.floor_bits = p.bias | (p.bias << 16);
         a.spec_base = p.speculative ? p.spec_base : 0;
         const uint32_t gd = grid_of(p.grid_drift, (uint64_t)n_groups * w.n_drift);
+        { const uint32_t* ord = nullptr; const int rco = item_order(cx, side ? 1 : 0, stream, n_groups, a.n_pairs, gd, a.grp_len4, a.pairs, a.q_len, &ord); if (rco) return rco; a.order = ord; }
         a.clk = clk_region(gd, 0);
         if (p.col_frame) hipLaunchKernelGGL((sw_scan_pkc<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((sw_scan_pkd<kStripRows16>), dim3(gd), dim3(kBlock), 0, stream, a);
@@ -311,6 +366,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     if (w.n_m3) {
         a.pairs = cx->d_qlist + w.off_m3; a.n_pairs = w.n_m3; a.counter = counters + 2; a.prio_cost = w.prio_cost[1];
         const uint32_t g3 = grid_of(p.grid_m3, (uint64_t)n_groups * w.n_m3);
+        { const uint32_t* ord = nullptr; const int rco = item_order(cx, side ? 1 : 0, stream, n_groups, a.n_pairs, g3, a.grp_len4, a.pairs, a.q_len, &ord); if (rco) return rco; a.order = ord; }
         a.clk = clk_region(g3, 1);
         if (p.f16_arith) {
             a.floor_bits = 0xE800E800u;      // (-2048.0h, -2048.0h)
@@ -327,6 +383,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         a.pairs = cx->d_qlist + w.off_pk; a.n_pairs = w.n_pk; a.counter = counters; a.prio_cost = w.prio_cost[2];
         a.floor_bits = 0;
         const uint32_t g2 = grid_of(p.grid_i16, (uint64_t)n_groups * w.n_pk);
+        { const uint32_t* ord = nullptr; const int rco = item_order(cx, side ? 1 : 0, stream, n_groups, a.n_pairs, g2, a.grp_len4, a.pairs, a.q_len, &ord); if (rco) return rco; a.order = ord; }
         a.clk = clk_region(g2, 2);
         hipLaunchKernelGGL((sw_scan_pk<ArithI16, kStripRows16>), dim3(g2), dim3(kBlock), 0, stream, a);
         HIP_TRY(hipGetLastError());
@@ -463,7 +520,7 @@ S4G_API int s4g_scan_clock(int device, double* out, uint32_t cap) {
     DeviceGuard guard(device);
     DeviceCtx* cx = device_ctx(device);
     std::lock_guard<std::mutex> lk(cx->mu);
-    for (uint32_t i = 0; i < 8; ++i) out[i] = 0.0;
+    for (uint32_t i = 0; i < std::min(cap, 10u); ++i) out[i] = 0.0;
     if (!cx->d_clk || cx->clk_launches.empty()) return S4G_OK;
     HIP_TRY(hipDeviceSynchronize());
     out[0] = (double)cx->clk_launches.size();
@@ -472,19 +529,20 @@ S4G_API int s4g_scan_clock(int device, double* out, uint32_t cap) {
     for (const auto& L : cx->clk_launches) {
         h.resize(4ull * L.blocks);
         HIP_TRY(hipMemcpy(h.data(), cx->d_clk + L.off, h.size() * 8, hipMemcpyDeviceToHost));
-        double sum = 0, lo = 1e30, hi = 0, ms = 0, shader_ticks = 0;
+        double sum = 0, lo = 1e30, hi = 0, ms = 0, shader_ticks = 0, ms_sum = 0, ms_min = 1e30;
         uint32_t used = 0;
         for (uint32_t b = 0; b < L.blocks; ++b) {
             const unsigned long long t0 = h[4 * b], r0 = h[4 * b + 1], t1 = h[4 * b + 2], r1 = h[4 * b + 3];
             if (r1 <= r0 || t1 <= t0 || r1 - r0 < 1000) continue;          // a block that found the queue empty: < 10 us
             const double mhz = (double)(t1 - t0) / (double)(r1 - r0) * 100.0;       // s_memrealtime counts at 100 MHz
             sum += mhz; lo = std::min(lo, mhz); hi = std::max(hi, mhz); ++used;
-            ms = std::max(ms, (double)(r1 - r0) * 1e-5);
+            ms = std::max(ms, (double)(r1 - r0) * 1e-5); ms_sum += (double)(r1 - r0) * 1e-5; ms_min = std::min(ms_min, (double)(r1 - r0) * 1e-5);
             shader_ticks = std::max(shader_ticks, (double)(t1 - t0));
         }
         if (!used || ms <= best_ms) continue;
         best_ms = ms;                                                   // report the longest launch of the call
         out[1] = sum / used; out[2] = lo; out[3] = hi; out[4] = used; out[5] = ms; out[6] = L.tier; out[7] = shader_ticks;
+        if (cap >= 10) { out[8] = ms_sum / used; out[9] = ms_min; }      // how long the blocks were busy: mean / longest = what the drain of the queue cost
     }
     return S4G_OK;
 }

@@ -77,6 +77,17 @@ __device__ __forceinline__ void clk_leave(unsigned long long* clk, int lane) {
     }
 }
 
+// Wave priority of a work item by its size (rows x columns / 4) against prio_cost = a quarter of the per-wave share of the launch: the SIMD
+// arbitrates vector issue by priority, then age, so of four co-resident waves the "young" ones get the leftovers, and a launch of few,
+// long items ends when the slowest of them does.  Three levels, a factor of four apart (measured on 64 queries of 2000-5000 residues,
+// EXPERIMENTS.md A.7: one level at share / 4: blocks busy 0.94 of the launch; one level at share / 16: 0.986; at share / 64: 0.85).
+__device__ __forceinline__ void item_priority(uint32_t prio_cost, uint64_t cost) {
+    if (!prio_cost || cost * 16 < prio_cost) __builtin_amdgcn_s_setprio(0);
+    else if (cost * 4 < prio_cost) __builtin_amdgcn_s_setprio(1);
+    else if (cost < prio_cost) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 __device__ __forceinline__ unsigned usub_sat(unsigned a, unsigned b) {
     return __builtin_elementwise_sub_sat(a, b);
 }
@@ -477,9 +488,12 @@ struct ScanArgs16 {
     uint32_t n_groups, n_pairs, q_begin;
     uint32_t open, ext;                      // each < 2^15
     uint32_t floor_bits;                     // packed floor of the arithmetic policy (see Arith*)
-    uint32_t prio_cost;                      // items with rows * len4 >= prio_cost run at raised wave priority (0 = never)
+    uint32_t prio_cost;                      // a quarter of the per-wave share of the launch in rows * len4: item_priority raises a wave's
+                                             // priority by its item's size against it (0 = never)
     uint32_t spec_base;                      // sw_scan_pkd, speculative launch: 0x7BFF - B - (max score + 2 ext); 0 = exact launch
     unsigned long long* clk;                 // optional clock samples, 4 per block (clk_enter / clk_leave)
+    const uint32_t* __restrict__ order;      // optional: the k-th item drawn from the queue is order[k] -- items by rows x columns, largest first
+                                             // (s4g_scan.hip, item_order: launches of few, long items); NULL: group-major, pairs as listed
 };
 
 // Written by a speculative sw_scan_pkd launch instead of a score that may not be exact; sw_pair_recheck replaces it.
@@ -664,6 +678,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
         if (lane == 0) item = atomicAdd(a.counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (a.order) item = a.order[item];
         const unsigned g = item / a.n_pairs;
         const unsigned pi = item - g * a.n_pairs;
         const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
@@ -678,9 +693,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pk(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
-        // An item that is large against the per-wave share of the launch sits on the critical path: the SIMD arbitrates
-        // vector issue by priority, then age, so without this a big item on a "young" wave gets the leftovers.
-        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        // (an item that is large against the per-wave share of the launch sits on the critical path)
+        item_priority(a.prio_cost, (uint64_t)lq * len4);
         int best = fl;
 
         for (unsigned s = 0; s < nstrips; ++s) {
@@ -848,6 +862,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
         if (lane == 0) item = atomicAdd(a.counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (a.order) item = a.order[item];
         const unsigned g = item / a.n_pairs;
         const unsigned pi = item - g * a.n_pairs;
         const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
@@ -862,7 +877,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_pkd(const ScanArgs16 a) {
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
-        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);   // see sw_scan_pk
+        item_priority(a.prio_cost, (uint64_t)lq * len4);   // see sw_scan_pk
         int best = 0;
 
         for (unsigned s = 0; s < nstrips; ++s) {
@@ -1116,6 +1131,7 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
         if (lane == 0) item = atomicAdd(a.counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (a.order) item = a.order[item];
         const unsigned g = item / a.n_pairs;
         const unsigned pi = item - g * a.n_pairs;
         const unsigned qA = a.pairs[2 * pi], qB = a.pairs[2 * pi + 1];
@@ -1132,7 +1148,7 @@ __global__ __launch_bounds__(kBlock, WPS) void sw_scan_pkc(const ScanArgs16 a) {
         const unsigned capB = hasB ? (lB + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign : 0u;
         const unsigned lq = lA > lB ? lA : lB;
         const unsigned nstrips = (lq + R - 1) / R;
-        if (a.prio_cost && (uint64_t)lq * len4 >= a.prio_cost) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);   // see sw_scan_pk
+        item_priority(a.prio_cost, (uint64_t)lq * len4);   // see sw_scan_pk
         const int zend = B2 + (int)(len4 * 4u) * e2;                   // z of the column after the last: where best~ stands when a strip ends
         int best = 0;                                                   // true running maximum (both halves), between strips
         int ovf = 0;

@@ -241,10 +241,11 @@ def chain_cache_info(device=0):
 def scan_clock(device=0):
     """shader clock and duration of the longest scan launch of the last scan call on `device`, sampled inside the kernel
     (s4g_scan_clock)"""
-    out = (ctypes.c_double * 8)()
-    check(lib.s4g_scan_clock(device, out, 8), "s4g_scan_clock")
+    out = (ctypes.c_double * 10)()
+    check(lib.s4g_scan_clock(device, out, 10), "s4g_scan_clock")
     return dict(launches=int(out[0]), shader_mhz=out[1], shader_mhz_min=out[2], shader_mhz_max=out[3], blocks=int(out[4]),
-                kernel_ms=out[5], tier=("drift", "m3", "i16", "i32")[int(out[6])] if out[0] else None, shader_clocks=out[7])
+                kernel_ms=out[5], tier=("drift", "m3", "i16", "i32")[int(out[6])] if out[0] else None, shader_clocks=out[7],
+                block_ms_mean=out[8], block_ms_min=out[9])
 
 
 def clock_probe(device=0):

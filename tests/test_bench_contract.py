@@ -89,6 +89,8 @@ def _check_common(d, n_gpus, steps, warmup):
     if ck["launches_sampled"]:           # a call that went to the pair waves as a whole launches no scan kernel
         assert 800.0 < ck["min_block"] <= ck["shader_mhz"] <= ck["max_block"] < 2600.0 and ck["blocks"] >= 1
         assert abs(rf["peak_at_measured_clock"] / rf["peak"] - ck["shader_mhz"] / 2400.0) < 1e-3
+        # how long the persistent blocks were busy, mean over blocks / the longest: the drain of the work queue is what is missing to 1
+        assert 0.5 < ck["blocks_busy_frac"] <= 1.0001 and ck["block_busy_ms"]["min"] <= ck["block_busy_ms"]["mean"] <= ck["kernel_ms_by_100MHz_counter"] * 1.0001
         if rf["kernel_ms"] > 50.0 and ck["launches_sampled"] == 1:       # one long launch: the two clocks must tell the same time
             assert abs(ck["kernel_ms_by_100MHz_counter"] / rf["kernel_ms"] - 1.0) < 0.05
     for ph in ("scan_ms", "topk_ms", "gather_ms"):
