@@ -27,7 +27,7 @@ struct TileWork {
     uint32_t off_m3 = 0, n_m3 = 0;
     uint32_t off_pk = 0, n_pk = 0;
     uint32_t off_wide = 0, n_wide = 0;     // single ids
-    uint32_t prio_cost[3] = {0, 0, 0};     // per packed tier: rows * len4 at or above which an item runs at raised wave priority
+    uint32_t prio_cost[4] = {0, 0, 0, 0};  // per tier (3: int32): a quarter of the per-wave share of its launch in rows * len4 (item_priority)
 };
 
 struct Plan {
@@ -219,12 +219,12 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         // critical-path items: measured against a quarter of the per-wave share of their launch (sw_kernels.hip.h, item_priority: three
         // priority levels a factor of four apart; only items of that order can let unfair issue arbitration between co-resident waves
         // stretch the launch)
-        for (int tier = 0; tier < 3; ++tier) {
+        for (int tier = 0; tier < 4; ++tier) {
             if (ids[tier].empty()) continue;
             double rows_sum = 0;
             for (uint32_t id : ids[tier]) rows_sum += q->len[id];
             const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
-            const double share = 0.5 * rows_sum * ((double)t.padded_residues / 256.0) / waves;       // (rows * len4) per wave
+            const double share = (tier < 3 ? 0.5 : 1.0) * rows_sum * ((double)t.padded_residues / 256.0) / waves;       // (rows * len4) per wave; a packed item is two queries
             w.prio_cost[tier] = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, share / 4.0));
         }
         add_pairs(ids[0], &w.off_drift, &w.n_drift);
@@ -270,13 +270,15 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
 // waves have 100 ms left -- the blocks were busy 0.94 of such a launch (s4g_scan_clock: mean / longest block).  Below kOrderItemsPerWave
 // items per wave the items are dealt out by cost instead, rows x columns, largest first (one small sort on the device per launch).
 constexpr uint64_t kOrderItemsPerWave = 48;
+// (pairs: [2 n_pairs] query ids of the packed tiers, or -- singles -- [n_pairs] query ids of the int32 tier, NULL there = q_begin + index)
 __global__ void scan_item_cost(uint32_t n_groups, uint32_t n_pairs, const uint32_t* __restrict__ grp_len4, const uint32_t* __restrict__ pairs,
-                               const uint32_t* __restrict__ q_len, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                               bool singles, uint32_t q_begin, const uint32_t* __restrict__ q_len, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_groups * n_pairs) return;
     const uint32_t g = i / n_pairs, pi = i - g * n_pairs;
-    const uint32_t qA = pairs[2 * pi], qB = pairs[2 * pi + 1];
-    const uint32_t rows = std::max(q_len[qA], qB != 0xFFFFFFFFu ? q_len[qB] : 0u);
+    uint32_t rows;
+    if (singles) rows = q_len[pairs ? pairs[pi] : q_begin + pi];
+    else { const uint32_t qA = pairs[2 * pi], qB = pairs[2 * pi + 1]; rows = std::max(q_len[qA], qB != 0xFFFFFFFFu ? q_len[qB] : 0u); }
     key[i] = (uint64_t)grp_len4[g] * rows;
     val[i] = i;
 }
@@ -286,7 +288,7 @@ static bool item_order_enabled() {
 }
 // -> *out = device array of the launch's items by descending cost, or NULL (many items per wave, or switched off)
 static int item_order(DeviceCtx* cx, int which, hipStream_t stream, uint32_t n_groups, uint32_t n_pairs, uint32_t blocks, const uint32_t* grp_len4,
-                      const uint32_t* pairs, const uint32_t* q_len, const uint32_t** out) {
+                      const uint32_t* pairs, const uint32_t* q_len, const uint32_t** out, bool singles = false, uint32_t q_begin = 0) {
     *out = nullptr;
     const uint64_t n = (uint64_t)n_groups * n_pairs;
     if (!item_order_enabled() || n < 2 || n >= kOrderItemsPerWave * blocks * kWavesPerBlock) return S4G_OK;
@@ -307,7 +309,7 @@ static int item_order(DeviceCtx* cx, int which, hipStream_t stream, uint32_t n_g
     uint64_t* key2 = (uint64_t*)b;                  b += al(n * 8);
     uint32_t* val = (uint32_t*)b;                   b += al(n * 4);
     uint32_t* val2 = (uint32_t*)b;                  b += al(n * 4);
-    hipLaunchKernelGGL(scan_item_cost, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n_groups, n_pairs, grp_len4, pairs, q_len, key, val);
+    hipLaunchKernelGGL(scan_item_cost, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n_groups, n_pairs, grp_len4, pairs, singles, q_begin, q_len, key, val);
     HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(b, cub, key, key2, val, val2, (int)n, 0, 48, stream));
     HIP_TRY(hipGetLastError());
     *out = val2;
@@ -400,6 +402,9 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
         b.q_list = cx->d_qlist + w.off_wide;
         b.open = (uint32_t)scorer->open; b.ext = (uint32_t)scorer->ext;
         const uint32_t gw = grid_of(p.grid_i32, (uint64_t)n_groups * w.n_wide);
+        b.prio_cost = w.prio_cost[3];
+        b.order = nullptr;
+        { const uint32_t* ord = nullptr; const int rco = item_order(cx, side ? 1 : 0, stream, n_groups, b.q_count, gw, b.grp_len4, b.q_list, b.q_len, &ord, true, q_begin); if (rco) return rco; b.order = ord; }
         b.clk = clk_region(gw, 3);
         // the drifting-frame form (6.5 ops per cell instead of 7.5) wherever its shifted scores fit the int8 strip profile
         if (p.wide_drift) hipLaunchKernelGGL(sw_scan_i32d<kStripRows>, dim3(gw), dim3(kBlock), 0, stream, b);

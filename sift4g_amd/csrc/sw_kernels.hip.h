@@ -57,6 +57,8 @@ struct ScanArgs {
     const uint32_t* __restrict__ q_list;     // optional: the q_count query ids to score (NULL = q_begin .. q_begin+q_count)
     uint32_t open, ext;
     unsigned long long* clk;                 // optional clock samples, 4 per block (clk_enter / clk_leave)
+    uint32_t prio_cost;                      // as ScanArgs16::prio_cost (item_priority); 0 = never
+    const uint32_t* __restrict__ order;      // as ScanArgs16::order; NULL: group-major
 };
 
 // Clock samples of a launch (s4g_scan_clock): thread 0 of every block stores the shader-clock counter (s_memtime) and the
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
         if (lane == 0) item = atomicAdd(a.counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (a.order) item = a.order[item];
         const unsigned g = item / a.q_count;
         const unsigned qi = item - g * a.q_count;
         const unsigned q = a.q_list ? a.q_list[qi] : a.q_begin + qi;
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32(const ScanArgs a) {
         const uint32_t* res = a.db_res + a.grp_off[g] + lane;
         const uint8_t* qc = a.q_codes + a.q_off[q];
         const unsigned lq = a.q_len[q];
+        item_priority(a.prio_cost, (uint64_t)lq * len4);
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
         int best = 0;
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
         if (lane == 0) item = atomicAdd(a.counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (a.order) item = a.order[item];
         const unsigned g = item / a.q_count;
         const unsigned qi = item - g * a.q_count;
         const unsigned q = a.q_list ? a.q_list[qi] : a.q_begin + qi;
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_i32d(const ScanArgs a) {
         const uint32_t* res = a.db_res + a.grp_off[g] + lane;
         const uint8_t* qc = a.q_codes + a.q_off[q];
         const unsigned lq = a.q_len[q];
+        item_priority(a.prio_cost, (uint64_t)lq * len4);
         const unsigned nstrips = (lq + R - 1) / R;
         v4i* wsF = wsH + (uint64_t)len4 * 64;
         int best = 0;
