@@ -15,11 +15,18 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Iinclude
 SWSRC   := $(CSRC)/swsharp/core.cpp $(CSRC)/swsharp/evalue.cpp $(CSRC)/swsharp/align.cpp $(CSRC)/swsharp/output.cpp
 REF     ?= /root/reference
 
-all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so build/shotgun_demo build/gather_demo oracle
+all: $(LIBDIR)/libs4g_hip.so $(LIBDIR)/libswsharp.so build/shotgun_demo build/gather_demo build/pin_dump_ours oracle
 
 build/shotgun_demo: tools/shotgun_demo.cpp $(LIBDIR)/libswsharp.so
 	@mkdir -p build
 	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/shotgun_demo.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+# this repo's half of the pinning recipe (oracle/Makefile target _ref, oracle/pin_against_swsharp.py): oracle/pin_dump.cpp -- a program
+# written against the swsharp API the reference uses -- on OUR headers and libraries; the other half is the same source on upstream swsharp
+pin-dump: build/pin_dump_ours
+build/pin_dump_ours: oracle/pin_dump.cpp $(LIBDIR)/libswsharp.so
+	@mkdir -p build
+	$(CXX) -O2 -std=c++11 -Wno-write-strings -Iinclude -o $@ oracle/pin_dump.cpp -L$(LIBDIR) -lswsharp -ls4g_hip -lpthread -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 # the one-process-per-GPU layout in plain C++ over the C ABI: N ranks (child processes), scan + s4g_gather_topk (RCCL), self-checking
 build/gather_demo: tools/gather_demo.cpp include/s4g_hip.h $(LIBDIR)/libs4g_hip.so
@@ -105,7 +112,7 @@ clean:
 	rm -rf build $(LIBDIR)/*.so
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle isa clean pf-timing dropin dropin-batched dropin-fullscan dropin-devsearch dropin-prefilter-dump
+.PHONY: all oracle isa clean pf-timing pin-dump dropin dropin-batched dropin-fullscan dropin-devsearch dropin-prefilter-dump
 
 # A measuring build of the library: pf_target_lis with shader-clock counters per section (kmer_prefilter.hip.h: PF_TIMING), printed per
 # chunk on stderr.  S4G_LIB=build/pf_timing/libs4g_hip.so python tools/prefilter_call_probe.py

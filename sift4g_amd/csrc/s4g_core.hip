@@ -771,19 +771,23 @@ S4G_API int s4g_queries_create(s4g_queries** out, int device, const uint8_t* cod
             e = hipMalloc((void**)&q->d_block, q->block_bytes);
         }
         if (e == hipSuccess && cx->query_pin_bytes < blk_need) {
-            if (cx->h_query_pin) { (void)hipEventSynchronize(cx->query_pin_done); (void)hipHostFree(cx->h_query_pin); cx->h_query_pin = nullptr; cx->query_pin_bytes = 0; }
+            if (cx->h_query_pin) { (void)hipHostFree(cx->h_query_pin); cx->h_query_pin = nullptr; cx->query_pin_bytes = 0; }
             e = hipHostMalloc((void**)&cx->h_query_pin, 1u << 20, hipHostMallocDefault);
             if (e == hipSuccess) cx->query_pin_bytes = 1u << 20;
         }
-        if (e == hipSuccess && !cx->query_pin_done) e = hipEventCreateWithFlags(&cx->query_pin_done, hipEventDisableTiming);
-        else if (e == hipSuccess) e = hipEventSynchronize(cx->query_pin_done);                  // the previous set's upload out of the staging buffer
+        if (e == hipSuccess && !cx->query_copy_stream) e = hipStreamCreateWithFlags(&cx->query_copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess) {
             memcpy(cx->h_query_pin, padded.data(), padded.size());
             memcpy(cx->h_query_pin + o_off, off.data(), off.size() * 8);
             if (n) memcpy(cx->h_query_pin + o_len, q->len.data(), (size_t)n * 4);
-            e = hipMemcpyAsync(q->d_block, cx->h_query_pin, blk_need, hipMemcpyHostToDevice, nullptr);
+            // On a stream of its own and waited for HERE: when the call returns the set is in device memory, whichever stream the
+            // caller queues its scan on (a torch.cuda.Stream() is hipStreamNonBlocking: the null stream would order nothing against
+            // it), and the staging buffer is free for the next set.  The wait is for these few hundred KB, not for the device: a
+            // traceback still running on trace_stream, or a caller's scan on its own stream, goes on underneath.  (The block itself
+            // has no reader left: s4g_queries_destroy waits for the device before a block goes back into the cache.)
+            e = hipMemcpyAsync(q->d_block, cx->h_query_pin, blk_need, hipMemcpyHostToDevice, cx->query_copy_stream);
         }
-        if (e == hipSuccess) e = hipEventRecord(cx->query_pin_done, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(cx->query_copy_stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             if (q->d_block) (void)hipFree(q->d_block);

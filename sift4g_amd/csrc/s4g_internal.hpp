@@ -133,8 +133,10 @@ struct DeviceCtx {
     uint64_t stat_pair_pk = 0;              // pairs of the last pair submission that ran there
     char* h_trace_pin = nullptr;        // pinned staging of traceback_pairs: items up, results back
     std::vector<std::pair<char*, uint64_t>> query_blocks;        // device blocks of destroyed small query sets (stream-ordered reuse on the null stream)
-    char* h_query_pin = nullptr; uint64_t query_pin_bytes = 0;   // pinned staging of s4g_queries_create, guarded by query_pin_done
-    hipEvent_t query_pin_done = nullptr;
+    char* h_query_pin = nullptr; uint64_t query_pin_bytes = 0;   // pinned staging of s4g_queries_create (free again when the call returns)
+    hipStream_t query_copy_stream = nullptr; // a small query set is uploaded here and WAITED for before s4g_queries_create returns: the set is
+                                             // then valid on every stream of the caller's (the null stream orders nothing against
+                                             // a hipStreamNonBlocking stream), and the wait is for this copy alone, not for the device
     hipStream_t trace_stream = nullptr;      // tracebacks in flight (s4g_traceback_submit) run here, beside the next call's scoring on the null stream
     hipEvent_t trace_inputs = nullptr;       // recorded on the null stream at submit: the uploads the job's kernels read
     hipEvent_t trace_last = nullptr;         // behind the last job queued on trace_stream: what shares its buffers (the traceback arena, its

@@ -15,10 +15,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the suite (the driver runs `pytest -x`: whatever fails first hides everything behind it).  Row evidence first
+# -- tests/test_gpu_rows.py holds one small HIP-vs-oracle test per row of SURVEY.md 8 and per BASELINE config -- then the parity files
+# from the kernels outwards, and only then the tests that spawn bench.py ranks or run time-boxed soaks.  Files not listed keep their
+# alphabetical place in front of the bench / soak group.
+_ORDER = ["test_gpu_rows", "test_gpu_parity", "test_gpu_swsharp", "test_gpu_prefilter", "test_gpu_fullsize", "test_gpu_shard", "test_gpu_multi"]
+_LAST = ["test_bench_contract", "test_gpu_soak"]
+
+
+def _file_rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name in _ORDER:
+        return _ORDER.index(name)
+    if name in _LAST:
+        return len(_ORDER) + 1 + _LAST.index(name)
+    return len(_ORDER)
+
+
 def pytest_collection_modifyitems(config, items):
-    """A test that hangs (a kernel that never ends, a deadlocked rendezvous) must fail on its own instead of holding the GPU box
-    until the driver's limit: with pytest-timeout installed every test gets 15 minutes unless it asked for something else (the
-    longest, the full-size configs, take about one)."""
+    """(1) the order above (a stable sort: the order inside a file is the file's own);  (2) a test that hangs (a kernel that never
+    ends, a deadlocked rendezvous) must fail on its own instead of holding the GPU box until the driver's limit: with pytest-timeout
+    installed every test gets 15 minutes unless it asked for something else (the longest, the full-size configs, take about one)."""
+    items.sort(key=_file_rank)
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:
