@@ -7,6 +7,12 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
+# gfx950 (MI355X) ONLY: the kernels use what that target has and others lack -- 160 KB of LDS per workgroup (topk_rows declares 65 KB
+# of static LDS, over the 64 KB limit of gfx90a / gfx942), v_pk_maximum3_f16, the packed kernels' denormal mode.  Another ARCH would
+# stop somewhere inside the build with an unhelpful message; say it here instead.
+ifneq ($(ARCH),gfx950)
+$(error this library is written for gfx950 (MI355X) only: ARCH=$(ARCH) is not supported -- see DESIGN.md "No compatibility layers")
+endif
 LIBDIR  := sift4g_amd/lib
 CSRC    := sift4g_amd/csrc
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -Wall -Wno-unused-function

@@ -171,8 +171,9 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
              const s4g_scorer* scorer, int32_t* d_scores, void* stream);
 
 /* s4g_scan with options.  By default every query runs in the fastest kernel that is EXACT for it, decided from
- * its score bound sum_i max(0, max_b table[q_i][b]): packed int16 in a drifting frame (bound + bias + (rows +
- * columns) * extend <= 31743), packed int16 with v_pk_maximum3_f16 as integer max3 (bound + bias <= 31743), plain
+ * its score bound sum_i max(0, max_b table[q_i][b]): packed int16 in a drifting frame (the column frame of sw_scan_pkc, the
+ * default: bound + bias + columns * extend <= 31743, no row term; with S4G_SCAN_DIAG_FRAME the anti-diagonal frame of
+ * sw_scan_pkd: bound + bias + (rows + columns) * extend <= 31743), packed int16 with v_pk_maximum3_f16 as integer max3 (bound + bias <= 31743), plain
  * packed int16 (bound <= 32767), else int32.  A query whose BOUND exceeds the drifting-frame window but whose frame fits it
  * with room to spare (long queries: the bound grows by ~5.6 per residue, real scores rarely do) still runs in that kernel,
  * speculatively: the kernel marks every result that came within one score step of the window's end, and an exact int32
@@ -187,7 +188,8 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
                                    (sw_scan_lists in scan mode: the four waves of a block on one (group, query pair) item) whatever the
                                    query count; by default calls of 3 to 16 queries (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it */
 #define S4G_SCAN_DIAG_FRAME 128u /* the drifting-frame tier runs sw_scan_pkd (frame grows per anti-diagonal, rounds 1-4) instead of sw_scan_pkc
-                                   (frame grows per column, round 5): the same results, kept as an independent second form */
+                                   (frame grows per column, round 5): the same results, kept as an independent second form.  The flag wins
+                                   over the process-wide S4G_SCAN_FRAME variable, which only moves the default of calls that do not set it */
 #define S4G_SCAN_F16_ARITH 4u   /* run the maximum3 tier in true f16 arithmetic (exact on bounds <= 4096) instead of the
                                    biased-int16 bit-pattern form (exact on bounds <= 0x7BFF - bias) */
 int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t q_count,

@@ -170,6 +170,7 @@ struct DeviceCtx {
     hipEvent_t merge_done[2] = {nullptr, nullptr};          // s4g_scan_topk with alternating tiles: the running lists are merged in tile order
     int32_t* d_ws_side = nullptr;
     uint64_t ws_side_bytes = 0;
+    uint64_t ws_budget = 40ull << 30;   // strip-boundary workspace budget of the call in progress (make_plan sets it: s4g_scan.hip call_workspace_budget)
     std::vector<std::pair<char*, uint64_t>> block_cache;    // freed small-tile blocks, reused by the next s4g_db_create
     char* arena = nullptr;              // traceback temporaries
     uint64_t arena_bytes = 0;

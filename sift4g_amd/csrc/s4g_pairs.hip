@@ -1069,7 +1069,13 @@ S4G_API int s4g_traceback_submit(const s4g_db* db, const s4g_queries* q, const s
         std::iota(all.begin(), all.end(), 0u);
         const int rc = traceback_pairs(db, q, scorer, all, pair_q, pair_t, pair_score, job->out5.data(), job->path_off.data(), job->paths.data(), job);
         if (rc) {
-            if (job->pin_slab >= 0) { DeviceCtx* cx = device_ctx(job->device); std::lock_guard<std::mutex> lk(cx->mu); --cx->trace_pin_slabs[(size_t)job->pin_slab].live; }
+            // the job's piece of a pinned slab goes back only once nothing queued can touch it any more: a copy or a kernel that was
+            // queued before the failure still reads or writes it, and a slab whose live count reaches 0 is handed to the next job
+            if (job->pin_slab >= 0) {
+                DeviceCtx* cx = device_ctx(job->device);
+                { DeviceGuard guard(job->device); if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError(); }
+                std::lock_guard<std::mutex> lk(cx->mu); --cx->trace_pin_slabs[(size_t)job->pin_slab].live;
+            }
             if (job->done) (void)hipEventDestroy(job->done);
             delete job;
             return rc;
@@ -1086,7 +1092,11 @@ S4G_API int s4g_traceback_finish(s4g_trace_job* job, int32_t* h_out, uint8_t* h_
     if (job->n_pairs && (!h_out || !h_paths)) rc = fail(S4G_ERR_INVALID, "NULL argument");
     DeviceGuard guard(job->device);
     if (job->in_flight) {
-        if (hipEventSynchronize(job->done) != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = fail(S4G_ERR_HIP, "waiting for the traceback failed"); }
+        if (hipEventSynchronize(job->done) != hipSuccess) {
+            (void)hipGetLastError();
+            if (!rc) rc = fail(S4G_ERR_HIP, "waiting for the traceback failed");
+            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();     // nothing may still write the slab piece released below
+        }
         if (!rc) {
             const int32_t* out5 = reinterpret_cast<const int32_t*>(job->pin + job->back_off);
             const int32_t* best = reinterpret_cast<const int32_t*>(job->pin + job->best_off);

@@ -9,6 +9,7 @@
 constexpr int kStripRows = 32;      // sw_scan_i32
 constexpr int kStripRows16 = 32;    // sw_scan_i16x2
 constexpr uint64_t kWorkspaceBudget = 40ull << 30;   // strip-boundary workspace cap (round 5: 40 GB, so that a tile of sequences up to 12 288 residues keeps the full grid of 4096 waves); longer-sequence tiles run on a smaller grid
+constexpr uint64_t kWorkspaceAlwaysFits = 8ull << 30; // below this nobody asks the runtime how much memory is free (every tile of sequences up to 3000 residues: 6.3 GB)
 constexpr uint64_t kTileScoreBudget = 4ull << 30;    // s4g_scan_topk: bytes of the [query batch][tile columns] buffer
 
 // Work of one tile launch: which queries run in which kernel.  Tiers, fastest first; a query goes to the first one that
@@ -44,7 +45,7 @@ struct Plan {
     uint32_t spec_base = 0;         // sw_scan_pkd: 0x7BFF - bias - (max score + 2 ext); sw_scan_pkc: 0x7BFF - (max score + ext), in the frame
     bool col_frame = true;          // drift tier = sw_scan_pkc (column frame) rather than sw_scan_pkd (anti-diagonal frame)
 };
-// S4G_SCAN_FRAME=diag|col overrides the flag for a whole process (A/B runs of bench.py and the tests)
+// S4G_SCAN_FRAME=diag|col: the frame of calls that do NOT set S4G_SCAN_DIAG_FRAME, for a whole process (A/B runs of bench.py)
 static int frame_env() {
     static const int v = []() { const char* e = getenv("S4G_SCAN_FRAME"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
     return v;
@@ -87,10 +88,25 @@ inline uint64_t ws_slot_elems(const Tile& t) { return 2ull * (t.max_len4 ? t.max
 
 // grid of a tile launch: the full persistent grid unless the tile's sequences are so long that the per-wave
 // strip-boundary workspace would exceed the budget
-inline uint32_t tile_grid(const Tile& t, uint32_t full_grid) {
+inline uint32_t tile_grid(const Tile& t, uint32_t full_grid, uint64_t budget) {
     const uint64_t per_block = ws_slot_elems(t) * 4 * kWavesPerBlock;
-    const uint64_t fit = kWorkspaceBudget / per_block;
+    const uint64_t fit = budget / per_block;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(full_grid, fit));
+}
+
+// The workspace budget of ONE call: kWorkspaceBudget, unless a tile of this database is long enough to want more than
+// kWorkspaceAlwaysFits at the full grid -- then at most 40 % of what the device has free right now (counting the two workspaces the
+// context already holds: they would be freed and re-made), for EACH of the main and the side workspace, so that a scan of a
+// long-sequence tile beside a large resident database runs on a smaller grid instead of failing in hipMalloc.  Fixed for the call
+// (make_plan stores it in the context under the context's lock): the plan's sizes and the launches' grids agree.
+static uint64_t call_workspace_budget(DeviceCtx* cx, const s4g_db* db, uint32_t full_grid) {
+    uint64_t want = 0;
+    for (const Tile& t : db->tiles) want = std::max<uint64_t>(want, ws_slot_elems(t) * 4 * kWavesPerBlock * full_grid);
+    if (want <= kWorkspaceAlwaysFits) return kWorkspaceBudget;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return kWorkspaceBudget; }
+    const uint64_t avail = (uint64_t)free_b + cx->ws_bytes + cx->ws_side_bytes;
+    return std::max<uint64_t>(1ull << 30, std::min<uint64_t>(kWorkspaceBudget, avail / 5 * 2));
 }
 
 // per-query upper bound of any reachable score under this scorer (host, O(residues), cached per scorer)
@@ -119,7 +135,10 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
     if (rc) return rc;
     rc = grid_for(db, (const void*)sw_scan_pkc<kStripRows16>, &cx->grid_col);
     if (rc) return rc;
-    p->col_frame = frame_env() ? frame_env() == 2 : !(flags & S4G_SCAN_DIAG_FRAME);
+    cx->ws_budget = call_workspace_budget(cx, db, std::max(std::max(cx->grid_i32, cx->grid_i16), std::max(std::max(cx->grid_f16, cx->grid_drift), cx->grid_col)));
+    // the per-call flag wins; S4G_SCAN_FRAME only moves the default of calls that do not set it (with the variable winning,
+    // every diag_frame=True comparison of the tests would have run the same kernel twice)
+    p->col_frame = (flags & S4G_SCAN_DIAG_FRAME) ? false : frame_env() != 1;
     p->grid_i32 = cx->grid_i32; p->grid_i16 = cx->grid_i16; p->grid_m3 = cx->grid_f16; p->grid_drift = p->col_frame ? cx->grid_col : cx->grid_drift;
     const bool gaps16 = sc->open < 32768 && sc->ext < 32768;
     p->f16_arith = (flags & S4G_SCAN_F16_ARITH) != 0;
@@ -193,7 +212,7 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         // fold a tier into the next slower one whenever the estimate says one launch beats two.  Units: VALU ops.
         {
             static const double ops[4] = {6.5, 7.5, 9.0, 15.0};     // per pair of cells (int32: two single-query items)
-            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double waves = (double)tile_grid(t, full, cx->ws_budget) * kWavesPerBlock;
             const double cols_sum = (double)t.padded_residues / 64.0;           // sum over groups of padded length
             const double cols_max = (double)t.max_len4 * 4.0;
             auto launch_time = [&](const std::vector<uint32_t>& v, int tier) -> double {
@@ -223,7 +242,7 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
             if (ids[tier].empty()) continue;
             double rows_sum = 0;
             for (uint32_t id : ids[tier]) rows_sum += q->len[id];
-            const double waves = (double)tile_grid(t, full) * kWavesPerBlock;
+            const double waves = (double)tile_grid(t, full, cx->ws_budget) * kWavesPerBlock;
             const double share = (tier < 3 ? 0.5 : 1.0) * rows_sum * ((double)t.padded_residues / 256.0) / waves;       // (rows * len4) per wave; a packed item is two queries
             w.prio_cost[tier] = (uint32_t)std::min<double>(4e9, std::max<double>(1.0, share / 4.0));
         }
@@ -235,7 +254,7 @@ int make_plan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t
         p->tiles.push_back(w);
         // workspace: one slot per wave of the largest launch of this tile (grids are capped by the item count)
         const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
-        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full, cx->ws_budget), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
         p->ws_bytes = std::max<uint64_t>(p->ws_bytes, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
     }
     return S4G_OK;
@@ -246,7 +265,10 @@ int ensure_scratch(const s4g_db* db, const s4g_scorer* sc, const Plan& p, hipStr
     if (cx->ws_bytes < p.ws_bytes) {
         if (cx->d_ws) HIP_TRY(hipFree(cx->d_ws));
         cx->d_ws = nullptr; cx->ws_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&cx->d_ws, p.ws_bytes));
+        if (hipMalloc((void**)&cx->d_ws, p.ws_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(S4G_ERR_NOMEM, "cannot allocate %llu bytes of strip-boundary workspace (budget of this call %llu)", (unsigned long long)p.ws_bytes, (unsigned long long)cx->ws_budget);
+        }
         cx->ws_bytes = p.ws_bytes;
     }
     if (!cx->d_counter) HIP_TRY(hipMalloc((void**)&cx->d_counter, 256));
@@ -328,7 +350,7 @@ int launch_tile(const s4g_db* db, const Tile& t, const TileWork& w, const s4g_qu
     unsigned* const counters = cx->d_counter + (side ? 8 : 0);
     // a persistent grid larger than the number of items only launches blocks that exit at once
     auto grid_of = [&](uint32_t full, uint64_t items) {
-        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), (items + kWavesPerBlock - 1) / kWavesPerBlock));
+        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full, cx->ws_budget), (items + kWavesPerBlock - 1) / kWavesPerBlock));
     };
     const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
     if ((uint64_t)n_groups * most >= 0xFFFFFFFFull)
@@ -702,7 +724,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
             on_side[ti] = 1;
             const TileWork& w = p.tiles[ti];
             const uint64_t most = std::max(std::max<uint64_t>(w.n_drift, w.n_m3), std::max<uint64_t>(w.n_pk, w.n_wide));
-            const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
+            const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(tile_grid(t, full, cx->ws_budget), ((uint64_t)t.n_groups * most + kWavesPerBlock - 1) / kWavesPerBlock));
             need = std::max<uint64_t>(need, ws_slot_elems(t) * 4 * kWavesPerBlock * blocks);
         }
     const bool forked = need != 0 || any_pairs;
@@ -824,6 +846,9 @@ __device__ void find_bin(const unsigned* hist, unsigned want, int* bin, unsigned
 // bitonic sort on (score desc, id asc) yields the exact top-k: two reads of the row instead of four, no ordered tie scan.  A row
 // whose cut lies beyond 251, or with more than 8192 scores at or above its cut bin, takes the general path below, unchanged.
 constexpr int kFastBins = 64, kFastShift = 2, kFastCap = 8192;
+// topk_rows holds kFastCap 8-byte keys (64 KB) PLUS ~1.1 KB of small arrays in static LDS: more than the 64 KB a workgroup gets on
+// gfx90a / gfx942.  gfx950 has 160 KB per CU and the Makefile refuses any other target; two blocks per CU is all the top-k needs.
+static_assert(kFastCap * 8 + 2048 <= 160 * 1024 / 2, "topk_rows: two blocks per CU must fit gfx950's 160 KB of LDS");
 
 __global__ __launch_bounds__(kTopkBlock) void topk_rows(const int32_t* __restrict__ scores, uint32_t n_cols, uint32_t seg_len,
                                                         uint32_t k, uint32_t kpad,
