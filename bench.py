@@ -712,6 +712,23 @@ def main():
         gather_ms = float(np.mean(gather_host_s)) * 1e3
     stats = s4gd.scan_stats(dev_index)
     clk = s4gd.scan_clock(dev_index)                # sampled inside the scan kernel of the last timed step
+    # The gather below Python (s4g_gather_topk: its own RCCL communicator, pack / all-gather / unpack or merge kernels) against the
+    # torch.distributed form of the same exchange on the last step's lists, once, outside the timed region: every rank must hold the
+    # same merged lists either way.  (The multi-rank RCCL path has only ever run with one rank on the boxes this was built on.)
+    gather_check = None
+    if gather_comm is not None and last is not None:
+        (l_ids_, l_sc_, l_cnt_), g_c = last
+        if db_shard:
+            g_t = shard.gather_db_shards(l_ids_, l_sc_, l_cnt_, rank * n_per, TOPK, gather_group, comm=None)
+        else:
+            g_t = shard.gather_query_shards(l_ids_, l_sc_, l_cnt_, allq.n, gather_group, comm=None)
+        torch.cuda.synchronize()
+        same = all(torch.equal(a.to(torch.int32), b.to(torch.int32)) for a, b in zip(g_c, g_t))
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = {"c_abi_equals_torch_distributed_on_every_rank": bool(int(flag.item())), "lists": int(g_c[0].shape[0])}
+        if not gather_check["c_abi_equals_torch_distributed_on_every_rank"]:
+            log(f"rank {rank}: GATHER CROSS-CHECK FAILED: s4g_gather_topk and the torch.distributed gather disagree")
 
     red_dev = dev if backend != "gloo" else torch.device("cpu")
     t = torch.tensor([dt, kern_ms, topk_ms, gather_ms], dtype=torch.float64, device=red_dev)
@@ -832,6 +849,7 @@ def main():
             "phases": phases,
             "gather_payload_bytes": (allq.n * 2 * TOPK * 4 * world if db_shard else (max(shard.shard_bounds(allq.n, world)[r + 1] - shard.shard_bounds(allq.n, world)[r] for r in range(world)) * (2 * TOPK + 1) * 4 * world)) if use_dist else 0,
             "host_affinity": affinity,
+            "gather_crosscheck": gather_check,
             "speculative": {"queries": stats["speculative"], "rechecked": stats["rechecked"]},
             "routing": {k: stats[k] for k in ("tier_drift", "tier_m3", "tier_i16", "tier_i32", "pair_items")},
         }
@@ -981,7 +999,8 @@ def main():
             pass
         result_out.write(line + "\n")
         result_out.flush()
-        if json.loads(line).get("selfcheck", {}).get("mismatches") or json.loads(line).get("prefilter", {}).get("check", {}).get("mismatches"):
+        if json.loads(line).get("selfcheck", {}).get("mismatches") or json.loads(line).get("prefilter", {}).get("check", {}).get("mismatches") \
+                or (gather_check and not gather_check["c_abi_equals_torch_distributed_on_every_rank"]):
             sys.exit(3)
         # Figures that look wrong on THIS box are said on stderr, never turned into an exit code: the line stands as measured, and a
         # time-sliced or down-clocked GPU must not fail the run (GPUTEST_r05 died on a busy-fraction threshold, not on a mismatch).

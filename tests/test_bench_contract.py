@@ -184,11 +184,14 @@ def test_bench_rccl_path_with_one_rank():
                    "--no-cpu-baseline", "--no-tiers", "--no-prefilter", "--no-scale-ref", env=env)
     _check_common(d, 1, 2, 1)
     assert d["backend"] == "RCCL (nccl)" and d["rccl_ranks"] == 1 and not d["emulated"]
+    # the gather below Python against the torch.distributed form of the same exchange, on the lists of the last step
+    assert d["gather_crosscheck"] == {"c_abi_equals_torch_distributed_on_every_rank": True, "lists": 20}
     assert d["selfcheck"]["mismatches"] == 0 and d["selfcheck"]["top_list_entries"] > 0
     d = _run_bench("--gpus", "1", "--mode", "db-shard", "--steps", "1", "--warmup", "1", "--queries", "6", "--targets", "30000",
                    "--no-cpu-baseline", env=env)
     _check_common(d, 1, 1, 1)
     assert d["backend"] == "RCCL (nccl)" and d["selfcheck"]["planted_not_first"] == 0 and d["selfcheck"]["mismatches"] == 0
+    assert d["gather_crosscheck"]["c_abi_equals_torch_distributed_on_every_rank"] is True
 
 
 @pytest.mark.gpu
