@@ -31,7 +31,9 @@ for d, tag in ((f"{prefix}_fetch", "fetch"), (f"{prefix}_write", "write"), (f"{p
         if key + "<" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
             meta = dict(kernel_symbol=r["Kernel_Name"], vgpr=r["VGPR_Count"], lds_bytes=r["LDS_Block_Size"], scratch=r["Scratch_Size"])
-    out[tag] = {k: {"sum": v, "dispatches": n[k]} for k, v in agg.items()}
+    # PER LAUNCH: a pass may dispatch the kernel more than once on the same workload (round 6: bench.py's end_to_end leg adds four scans
+    # unless --no-end-to-end is given); every figure below is the mean over the pass's dispatches, "all_dispatches" keeps the raw sum
+    out[tag] = {k: {"sum": v / n[k], "dispatches": n[k], "all_dispatches": v} for k, v in agg.items()}
 fetch_kb, write_kb = out["fetch"]["FETCH_SIZE"]["sum"], out["write"]["WRITE_SIZE"]["sum"]
 avg_ns = [float(r["AverageNs"]) for r in csv.DictReader(open(f"{dst}/kernel_stats.csv")) if key + "<" in r["Name"]][0]
 t = avg_ns / 1e9
