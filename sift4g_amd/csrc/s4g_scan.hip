@@ -100,6 +100,8 @@ inline uint32_t tile_grid(const Tile& t, uint32_t full_grid, uint64_t budget) {
 // long-sequence tile beside a large resident database runs on a smaller grid instead of failing in hipMalloc.  Fixed for the call
 // (make_plan stores it in the context under the context's lock): the plan's sizes and the launches' grids agree.
 static uint64_t call_workspace_budget(DeviceCtx* cx, const s4g_db* db, uint32_t full_grid) {
+    // S4G_WORKSPACE_BUDGET=<bytes>: the tests' way to the smaller grids (read per call: a test sets it for one scan)
+    if (const char* e = getenv("S4G_WORKSPACE_BUDGET")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) return std::max<uint64_t>(v, 1ull << 20); }
     uint64_t want = 0;
     for (const Tile& t : db->tiles) want = std::max<uint64_t>(want, ws_slot_elems(t) * 4 * kWavesPerBlock * full_grid);
     if (want <= kWorkspaceAlwaysFits) return kWorkspaceBudget;

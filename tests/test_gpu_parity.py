@@ -770,6 +770,54 @@ def test_concurrent_host_threads_and_streams(s4g, oracle_mod, blosum62, scorer):
     assert not errors, errors
 
 
+def test_fresh_query_set_scanned_at_once_on_a_non_blocking_stream(s4g, oracle_mod, blosum62, scorer):
+    """s4g_queries_create uploads a small set asynchronously; a scan queued right behind it on a stream of the caller's (every
+    torch.cuda.Stream() is hipStreamNonBlocking: the null stream orders nothing against it) must see the NEW set -- the create call now
+    waits for its own copy on its own stream.  Many short sets in a row through the recycled query blocks, each scanned at once."""
+    import torch
+    rng = np.random.default_rng(361)
+    ts = rand_seqs(rng, 300, 5, 200)
+    db = s4g.Database(ts)
+    st = torch.cuda.Stream()
+    busy = torch.empty((64 << 20,), dtype=torch.int32, device="cuda:0")
+    for it in range(60):
+        qs = rand_seqs(rng, 1 + it % 3, 20, 180)
+        exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+        busy.add_(1)                                     # keeps the null stream occupied while the set is made and scanned
+        q = s4g.QuerySet(qs)
+        with torch.cuda.stream(st):
+            out = torch.empty((len(qs), db.n), dtype=torch.int32, device="cuda:0")
+            s4g.scan(db, q, scorer, out, no_pairs=bool(it & 1))
+        st.synchronize()
+        assert np.array_equal(out.cpu().numpy(), exp), it
+        del q
+
+
+def test_reduced_workspace_budget_runs_on_a_smaller_grid(s4g, oracle_mod, blosum62, scorer, monkeypatch):
+    """ADVICE r5: the strip-boundary workspace budget of a call is cut to what the device has free when a tile wants more than 8 GB;
+    S4G_WORKSPACE_BUDGET forces the cut: the same scores on a grid of a few blocks (long targets: 12 000 residues = 6 MB per wave slot),
+    full matrix and streaming top-k, and the launch's block count (s4g_scan_clock) shrinks with the budget."""
+    from sift4g_amd import device as s4gd
+    rng = np.random.default_rng(362)
+    qs = rand_seqs(rng, 24, 300, 400)
+    ts = rand_seqs(rng, 3000, 30, 400) + rand_seqs(rng, 70, 9000, 12000)
+    ts[3] = qs[2].copy()
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=os.cpu_count() or 8)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), exp)
+    blocks_full = s4gd.scan_clock(0)["blocks"]                             # blocks of the longest launch that found work (s4g_scan_clock)
+    monkeypatch.setenv("S4G_WORKSPACE_BUDGET", str(200 << 20))             # 24.6 MB per block of four waves at 12 000 residues: 8 blocks
+    assert np.array_equal(s4g.scan_host(db, q, scorer, no_pairs=True), exp)
+    blocks_small = s4gd.scan_clock(0)["blocks"]
+    assert 1 <= blocks_small <= 8 < blocks_full, (blocks_small, blocks_full)
+    for mode in (dict(no_pairs=True), dict(no_pairs=True, force_i32=True), dict(no_pairs=True, diag_frame=True)):
+        assert np.array_equal(s4g.scan_host(db, q, scorer, **mode), exp), mode
+    ids, sc, cnt = [x.cpu().numpy() for x in s4g.scan_topk(db, q, scorer, 9, 1)]
+    for i in range(len(qs)):
+        order = sorted(range(len(ts)), key=lambda j: (-exp[i, j], j))[:9]
+        assert ids[i].tolist() == order and sc[i].tolist() == [int(exp[i, j]) for j in order]
+
+
 def test_argument_errors_are_reported(s4g, scorer):
     """bad arguments come back as error codes with text (never a crash, never a silent fallback)."""
     import torch
