@@ -219,6 +219,30 @@ def test_bench_eight_rank_rehearsal_on_one_gpu():
     assert chk["planted_copies"] == 11 and chk["planted_not_first"] == 0 and chk["mismatches"] == 0
 
 
+def test_cpu_baseline_says_what_bounds_it(tmp_path, monkeypatch):
+    """bench.py's cpu_baseline helpers on this host: the core map and the spread masks (one hardware thread per physical core, evenly
+    over the core list, siblings only beyond the cores), the cgroup quota reader on a synthetic cpu.max, and the baseline itself on a toy
+    workload -- `limits.bound_by`, `quota_cpus`, `pinned` are in the result and the affinity mask is back to what it was."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cores = bench._core_map()
+    assert cores and all(c == sorted(c) for c in cores)
+    for n in (1, 2, len(cores)):
+        m = bench._spread_mask(cores, n)
+        assert len(m) == n and all(sum(1 for x in c if x in m) <= 1 for c in cores)       # never two siblings of one core while n fits the cores
+    fake = [[0, 8], [1, 9], [2, 10], [3, 11]]
+    assert bench._spread_mask(fake, 2) == {0, 2} and bench._spread_mask(fake, 4) == {0, 1, 2, 3} and bench._spread_mask(fake, 6) == {0, 1, 2, 3, 8, 9}
+    lim = bench._cpu_limits()
+    assert lim["affinity_cpus"] == len(os.sched_getaffinity(0)) and "quota_cpus" in lim
+    before = os.sched_getaffinity(0)
+    from sift4g_amd import synth
+    cfg = synth.make_config(2, n_queries=8, n_targets=600, homologs_per_query=4)
+    cb = bench.cpu_baseline(cfg, len(before), target_seconds=0.5)
+    assert os.sched_getaffinity(0) == before
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["limits"]["bound_by"] and "quota_cpus" in cb and isinstance(cb["pinned"], bool)
+    assert cb["limits"]["bound_by"] in cb["sample"]
+
+
 def test_bench_refuses_more_ranks_than_devices_in_seconds():
     """`python bench.py --gpus 8` where fewer than 8 GPUs are visible (this container: none; the 1-GPU test box: one): exit code 2 and the
     reason on stderr before a single rank is spawned -- not a hang, not a JSON line.  (Runs on CPU and on the GPU box alike.)"""
