@@ -114,6 +114,32 @@ def test_long_sequences(s4g, oracle_mod, blosum62, scorer):
     _check(s4g, oracle_mod, blosum62, qs, ts, scorer)
 
 
+def test_giant_queries_and_targets(s4g, oracle_mod, blosum62, scorer):
+    """titin-sized QUERIES (36 000 and 20 000 residues: score bounds of 200 000 and 110 000, beyond every int16 window) against a small
+    database that holds a copy of the first (self-score 209 182), a 14 500-residue piece of the second and an unrelated 35 000-residue
+    target: the library's own routing for the call, the streaming top-k, both pair-list routes, and the device traceback of the
+    36 000 x 36 000 self-alignment -- scores, lists, coordinates and path lengths == the oracle."""
+    rng = np.random.default_rng(77)
+    qs = [rand_seqs(rng, 1, 36000, 36000)[0], rand_seqs(rng, 1, 20000, 20000)[0], rand_seqs(rng, 1, 350, 350)[0]]
+    ts = rand_seqs(rng, 100, 30, 900) + [qs[0].copy(), rand_seqs(rng, 1, 35000, 35000)[0], qs[1][500:15000].copy()]
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=os.cpu_count() or 8)
+    assert exp[0, 100] > 200000 and exp[1, 102] > 80000
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    assert np.array_equal(s4g.scan_host(db, q, scorer), exp)
+    ids, sc, cnt = [x.cpu().numpy() for x in s4g.scan_topk(db, q, scorer, 5, 1)]
+    for i in range(len(qs)):
+        order = sorted(range(len(ts)), key=lambda j: (-exp[i, j], j))[:5]
+        assert ids[i].tolist() == order and sc[i].tolist() == [int(exp[i, j]) for j in order]
+    pq, pt = np.array([0, 1, 2, 0, 1], dtype=np.uint32), np.array([100, 102, 5, 101, 101], dtype=np.uint32)
+    for route in ("lists", "wave"):
+        assert s4g.score_pairs(db, q, scorer, pq, pt, route=route).tolist() == exp[pq, pt].tolist(), route
+    res = s4g.traceback(db, q, scorer, pq[:3], pt[:3], exp[pq[:3], pt[:3]])
+    for r, a, b in zip(res, pq[:3], pt[:3]):
+        o = oracle_mod.sw_align(qs[a], ts[b], blosum62, 10, 1)
+        assert (r["q_start"], r["q_end"], r["t_start"], r["t_end"]) == (o["q_start"], o["q_end"], o["t_start"], o["t_end"])
+        assert r["path"].tolist() == [{0: 1, 1: 2, 2: 3}[m] for m in o["path"]]
+
+
 def test_more_items_than_resident_waves(s4g, oracle_mod, blosum62, scorer):
     """enough (group, query) items that the persistent grid loops, with very unequal work."""
     rng = np.random.default_rng(17)
