@@ -464,6 +464,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
     a.scores = B.scores; a.ws = cx->d_ws; a.ws_slot = ws_slot; a.counter = cx->d_counter + kListCounter; a.n_items = n_items;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.floor_bits = (uint32_t)(bias | (bias << 16));
+    a.grp_perm = nullptr; a.scan_scores = nullptr; a.score_stride = 0; a.q_begin = 0; a.spec_base = 0;       // (scan-mode fields)
     {   // Critical-path items run at raised wave priority (the SIMD arbitrates issue by priority, then age).  A launch of
         // lists has only about two items per resident wave, so "large against the wave's share" would mean nearly all of
         // them; instead: the longest items, as many as there are SIMDs to own (their count is estimated from the length
@@ -523,8 +524,9 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
 // query of its own: residues straight out of the tile (no gather), scores straight into the caller's matrix.
 // *used = false: not applicable (a query outside the drifting-frame window, a tile of very long sequences); nothing was launched.
 int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
-                        int32_t* d_scores, uint64_t stride, const uint32_t* d_perm, hipStream_t stream, bool* used) {
+                        int32_t* d_scores, uint64_t stride, const uint32_t* d_perm, hipStream_t stream, bool* used, bool allow_spec, bool* speculative) {
     *used = false;
+    if (speculative) *speculative = false;
     if (!q_count || !t.n_groups || t.h_grp_off.size() < t.n_groups) return S4G_OK;
     if (!(scorer->open < 32768 && scorer->ext < 32768) || (uint64_t)t.max_len4 * 4 > kListMaxTarget) return S4G_OK;
     ensure_bounds(q, scorer);
@@ -535,11 +537,16 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     for (uint32_t i = 0; i < q_count; ++i) order[i] = q_begin + i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return q->len[a] > q->len[b]; });
     const uint64_t cols = (uint64_t)t.max_len4 * 4 + 8;
+    // A query whose score BOUND leaves the window still runs here when its FRAME fits with room to spare (long queries: the bound grows
+    // by ~5.6 per residue, real scores rarely do) -- speculatively, as in sw_scan_pkc's tier (s4g_scan.hip make_plan, the same
+    // criterion): the kernel marks what it cannot vouch for and the caller's recheck_marked recomputes those entries in int32.
+    const uint64_t step_c = (uint64_t)std::max(0, scorer->max_score) + (uint64_t)scorer->ext;
+    bool spec = false;
     for (uint32_t i = 0; i < q_count; ++i) {
-        const uint32_t longer = order[i & ~1u];
         if (q->len[order[i]] == 0) return S4G_OK;
-        (void)longer;
-        if (q->score_bound[order[i]] + bias + cols * (uint64_t)scorer->ext > cap) return S4G_OK;
+        if (q->score_bound[order[i]] + bias + cols * (uint64_t)scorer->ext <= cap) continue;
+        if (!allow_spec || !speculative || bias + step_c + cols * (uint64_t)scorer->ext + 6144 /* kSpecSpan, s4g_scan.hip */ > cap) return S4G_OK;
+        spec = true;
     }
     const uint32_t n_pairs = (q_count + 1) / 2;
     const uint64_t n_items64 = (uint64_t)t.n_groups * n_pairs;
@@ -604,8 +611,10 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.floor_bits = (uint32_t)(bias | (bias << 16));
     a.prio_cost = 0;        // (raised wave priority for the longest items was measured: no change -- their latency is their own strips', not their neighbours')
     a.grp_perm = d_perm; a.scan_scores = d_scores; a.score_stride = stride; a.q_begin = q_begin;
+    a.spec_base = spec ? (uint32_t)(cap - step_c) : 0u;
     hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
     HIP_TRY(hipGetLastError());
     *used = true;
+    if (speculative) *speculative = spec;
     return S4G_OK;
 }

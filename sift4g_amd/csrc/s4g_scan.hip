@@ -657,11 +657,21 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     // the bench distribution, ms per call, pipeline | split model (profiles/r03_scan_latency.txt):
     //   1 query 5.5 | 2.6-3.7    2: 5.6 | 3.6    3: 5.7 | 6.3    4: 5.7 | 6.5    6: 6.8 | 8.6    8: 8.8 | 10.4    12: 13.1 | 13.5    16: 17.1 | 17.2    32: 34.5 | 33.9
     // (one or two queries: the longest group is 5 ms of four waves whatever else happens, and only the pair waves spread it over CUs)
+    // Round 6: ONE or TWO queries take it too when they are long and the database is large -- the launch of the split model waits for the
+    // wave that walks the longest group under the longest query, rows * columns of one dependent chain; the pipeline spreads that item's
+    // strips over the four waves of a block.  Measured (tools/scan_latency.py shapes, 100 000 targets, ms per call, pipeline | split):
+    //   1 query of 700: 10.4 | 11.0   1000: 13.8 | 13.8   1500: 20.7 | 31.5   3000: 40.7 | 61.0   8000: 104 | 162   20 000: 264 | 415
+    //   2 queries: the same within 2 ms.  Against 20 000 targets the split (all pairs for one query) wins at every length: 0.8-60 | 3.8-195.
+    uint32_t max_rows = 0;
+    for (uint32_t i = 0; i < q_count; ++i) max_rows = std::max(max_rows, q->len[q_begin + i]);
     const bool want_pipe = (flags & S4G_SCAN_BLOCK_PIPE) != 0 ||
-                           (flags == 0 && q_count >= 3 && q_count <= pipe_max_queries() && !(all_pairs && any_pairs) && db->n_seqs >= 256u * 64u);
+                           (flags == 0 && !(all_pairs && any_pairs) && pipe_max_queries() != 0 &&
+                            ((q_count >= 3 && q_count <= pipe_max_queries() && db->n_seqs >= 256u * 64u) ||
+                             (q_count <= 2 && max_rows >= 1200 && db->n_seqs >= 1024u * 64u)));
     flags &= ~S4G_SCAN_BLOCK_PIPE;
     std::vector<char> piped(db->tiles.size(), 0);
     uint64_t pipe_pairs = 0;
+    bool pipe_spec = false;         // a pipelined tile ran speculatively (round 6): its marks need the recheck pass below
     if (want_pipe) {
         rc = scope.acquire();
         if (rc) return rc;
@@ -673,13 +683,23 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         for (size_t ti = 0; ti < db->tiles.size(); ++ti) {
             const Tile& t = db->tiles[ti];
             if (!t.n_seqs) { piped[ti] = 1; continue; }
-            bool used = false;
-            rc = scan_tile_pipelined(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, t.d_perm_global, stream, &used);
+            bool used = false, spec = false;
+            rc = scan_tile_pipelined(db, t, q, q_begin, q_count, scorer, d_scores, db->n_seqs, t.d_perm_global, stream, &used,
+                                     /*allow_spec=*/!(flags & S4G_SCAN_NO_SPEC), &spec);
             if (rc) return rc;
-            if (used) { piped[ti] = 1; g0s[ti] = 0; pipe_pairs += (uint64_t)q_count * t.n_seqs; } else ++refused;
+            if (used) { piped[ti] = 1; g0s[ti] = 0; pipe_pairs += (uint64_t)q_count * t.n_seqs; pipe_spec = pipe_spec || spec; } else ++refused;
         }
         cx->stat_list_pairs = pipe_pairs;
-        if (!refused) return scope.release();
+        if (pipe_spec) cx->stat_spec_queries += q_count;
+        if (!refused) {
+            if (pipe_spec) {        // exact int32 pass over the entries the speculative pipeline launches marked
+                uint32_t max_lt = 0;
+                for (const Tile& t : db->tiles) max_lt = std::max(max_lt, t.max_len4 * 4);
+                rc = recheck_marked(db, q, scorer, q_begin, q_count, d_scores, db->n_seqs, db->n_seqs, nullptr, max_lt, stream);
+                if (rc) return rc;
+            }
+            return scope.release();
+        }
         // Tiles the pipeline does not take (a query beyond the drifting-frame window there, a tile of titin-sized sequences) go
         // through the general route below, behind what was launched above on the same stream; the tiles that are done are skipped.
         rc = scope.release();
@@ -768,7 +788,7 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
         if (rc) return rc;
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(stream, cx->side_join, 0));
-    if (p.speculative) {        // exact int32 pass over the entries the speculative launches marked
+    if (p.speculative || pipe_spec) {        // exact int32 pass over the entries the speculative launches marked
         uint32_t max_lt = 0;
         for (const Tile& t : db->tiles) max_lt = std::max(max_lt, t.max_len4 * 4);
         rc = recheck_marked(db, q, scorer, q_begin, q_count, d_scores, db->n_seqs, db->n_seqs, nullptr, max_lt, stream);

@@ -63,6 +63,10 @@ struct ListArgs {
     int32_t* __restrict__ scan_scores;          // [query - q_begin][score_stride]
     uint64_t score_stride;
     uint32_t q_begin;
+    // SCAN mode, speculative launch (round 6; 0 = every query of the launch is exact by its score bound): the host guarantees only that
+    // the FRAME fits the int16 window; a result whose strip's in-frame running maximum passed spec_base = 0x7BFF - (max score + e) is
+    // written as kScoreUnsure and recomputed by sw_pair_recheck -- sw_scan_pkc's scheme (sw_kernels.hip.h), strip by strip
+    uint32_t spec_base;
 };
 
 // The entries of a call out of its raw pairs: key = (query << pos_bits | rank of the target in the database's length order), value = (target,
@@ -163,6 +167,7 @@ __device__ __forceinline__ v4i lst_load(const char* prof, unsigned taddr, int bl
 constexpr int kListRing = 16;            // fetched items a block keeps in LDS
 constexpr unsigned kListPublishEvery = 1;     // chunks between two publications of a strip's progress (power of 2; 2 and 4 measured
                                               // the same: the release's wait for the boundary stores is hidden by the other waves)
+constexpr int kMarked = 0x7FFFFFFF;      // an item's running maximum once a strip of a speculative launch could not vouch for it (above every score)
 constexpr int kListBufs = 4;             // workspace buffers (and best-score rows) per block: item k uses buffer k % 4; a wave may
                                          // run at most 3 items ahead of the slowest wave of its block
 
@@ -246,7 +251,10 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
             zj = zn;
             ho[cc] = H[RR - 1];
             fo[cc] = F;
-            best = (int)((unsigned)best + (unsigned)e2v);               // best~ moves to column j+1's frame (no speculative launches here: plain add)
+            // best~ moves to column j+1's frame.  A SIGNED SATURATING packed add (one single-rate instruction per column of RR rows), as in
+            // sw_scan_pkc: as a 16-bit pattern best~ never decreases inside a strip and never passes 0x7FFF, which is what makes it the
+            // witness of a speculative launch (ListArgs::spec_base); inside the window it is the plain add
+            best = as_i(__builtin_elementwise_add_sat(as_s(best), as_s(e2)));
             asm volatile("" : "+v"(best));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -412,18 +420,30 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
             if (first) lst_strip<R, R, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
             else lst_strip<R, R, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
         }
+        const int bframe = best;                         // the strip's maximum still IN the frame: the witness of a speculative launch
         best = (int)((unsigned)best - (unsigned)zend);   // the true maximum of the strip (no borrow: best~ >= z in both halves)
+        int lo = (int)as_s(best)[0], hi = (int)as_s(best)[1];
+        if constexpr (SCAN) {
+            if (a.spec_base) {
+                // sw_scan_pkc's claim holds strip by strip: a strip whose in-frame maximum ends at or below spec_base held every value of
+                // its own inside the window (the first value to leave it is a diag + s' above a value the maximum took in the column
+                // before, or the maximum itself); the boundary row it read came from a strip that makes the same statement about itself.
+                // A strip that cannot make it marks the item's result (kMarked wins every atomicMax below); a lower half beyond the
+                // window may have carried into the upper one: it marks both.
+                if (((unsigned)bframe & 0xFFFFu) > a.spec_base) lo = hi = kMarked;
+                else if (((unsigned)bframe >> 16) > a.spec_base) hi = kMarked;
+            }
+        }
         // merge this strip's maximum into the item's, THEN publish the strip as finished: the wave that ends the item's last strip
         // has seen every strip above finished (each waited for its predecessor's last chunk), so the row is complete for it
         if (!(first && last)) {
-            atomicMax(&sy.best[buf][2 * lane], (int)as_s(best)[0]);
-            atomicMax(&sy.best[buf][2 * lane + 1], (int)as_s(best)[1]);
+            atomicMax(&sy.best[buf][2 * lane], lo);
+            atomicMax(&sy.best[buf][2 * lane + 1], hi);
         }
         if (!last) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(mine, (my_tag << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            int lo = (int)as_s(best)[0], hi = (int)as_s(best)[1];
             if (!first) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 lo = __hip_atomic_load(&sy.best[buf][2 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -432,6 +452,8 @@ __global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
                 sy.best[buf][2 * lane + 1] = 0;
             }
             if constexpr (SCAN) {
+                if (lo == kMarked) lo = kScoreUnsure;
+                if (hi == kMarked) hi = kScoreUnsure;
                 const unsigned p = a.grp_perm[(uint64_t)it.first_a * 64 + lane];
                 if (p != 0xFFFFFFFFu) {
                     a.scan_scores[(uint64_t)(it.qa - a.q_begin) * a.score_stride + p] = lo;

@@ -1280,7 +1280,10 @@ def test_speculative_drift_tier_for_long_queries(s4g, oracle_mod, blosum62):
         assert exp.max() > 32767 and np.sort(exp[3])[-3] > 12000
         for tile_seqs in (0, 64):
             db = s4g.Database(ts, tile_seqs=tile_seqs)
-            for mode in (dict(no_pairs=True), dict(diag_frame=True), dict(no_spec=True), dict(no_spec=True, diag_frame=True), dict()):
+            # block_pipe (round 6): the block-cooperative strip pipeline takes the queries beyond its window speculatively too (its strips
+            # mark what they cannot vouch for, sw_pair_recheck recomputes); with no_spec it leaves them to the tiers by bound
+            for mode in (dict(no_pairs=True), dict(diag_frame=True), dict(no_spec=True), dict(no_spec=True, diag_frame=True), dict(),
+                         dict(block_pipe=True), dict(block_pipe=True, no_spec=True)):
                 got = s4g.scan_host(db, q, sc, **mode)
                 bad = np.argwhere(got != exp)
                 assert bad.size == 0, (go, ge, tile_seqs, mode, bad[:5].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
@@ -1320,6 +1323,9 @@ def test_speculative_launch_really_marks_results(s4g, oracle_mod, blosum62):
     got = s4g.scan_host(db, q, sc, no_pairs=True, no_spec=True)
     st = s4gd.scan_stats(0)
     assert np.array_equal(got, exp) and st["speculative"] == 0 and st["rechecked"] == 0, st
+    # the block pipeline (round 6) takes tiles of targets up to 4096 residues: here the 5000-residue copy keeps the tile on the general
+    # route -- the same matrix; test_speculative_block_pipeline_marks_and_rechecks looks at a tile it does take
+    assert np.array_equal(s4g.scan_host(db, q, sc, block_pipe=True), exp)
     # extend = 5: no drift frame fits at these lengths -> the fixed-frame maximum3 tier, speculative for the long queries;
     # its window is on the score itself: only the 6000-residue self hit (~35 000) passes 0x7BFF - bias
     qs2 = qs[:2] + [rand_seqs(rng, 1, 6000, 6000)[0]]
@@ -1330,6 +1336,42 @@ def test_speculative_launch_really_marks_results(s4g, oracle_mod, blosum62):
     assert np.array_equal(got2, exp2) and exp2[2, 20] > 32767
     # (the upper half of a register pair is marked together with a marked lower half: the partner query's result at that target too)
     assert st["speculative"] >= 1 and 1 <= st["rechecked"] <= 2 and st["tier_m3"] >= 1, st
+
+
+def test_speculative_block_pipeline_marks_and_rechecks(s4g, oracle_mod, blosum62):
+    """Round 6: the block-cooperative strip pipeline (sw_scan_lists in scan mode) runs queries whose score BOUND is beyond its window
+    speculatively, like sw_scan_pkc: each strip's in-frame running maximum is its witness, a strip that cannot vouch for its values marks
+    the item's result, sw_pair_recheck recomputes the marked entries in int32.  Queries of 5000 / 4200 / 2500 random residues and 4500
+    tryptophans (11 per match: bound 49 500) against short targets, a 4000-residue piece of the first query (23 k: inside the window) and
+    3500 tryptophans (38 500: beyond int16 altogether).  The whole call runs on the pipeline, speculatively; exactly the entries at the
+    tryptophan target that share a register pair with the tryptophan query are marked and recomputed; with no_spec the pipeline leaves the
+    tile to the tiers by bound; a call of ONE such query takes the same route."""
+    from sift4g_amd import device as s4gd
+    rng = np.random.default_rng(63)
+    qs = [rand_seqs(rng, 1, l, l)[0] for l in (5000, 4200)] + [np.full(4500, 22, dtype=np.uint8), rand_seqs(rng, 1, 2500, 2500)[0]]
+    ts = rand_seqs(rng, 70, 30, 600)
+    ts[5] = qs[0][500:4500].copy(); ts[6] = np.full(3500, 22, dtype=np.uint8); ts[7] = qs[3][:2400].copy()
+    ts[8] = np.concatenate([qs[1][:2000], np.full(600, 22, dtype=np.uint8), qs[1][2000:3000]])
+    sc = s4g.Scorer("BLOSUM_62", 10, 1)
+    db, q = s4g.Database(ts), s4g.QuerySet(qs)
+    exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=8)
+    assert exp[2, 6] == 38500 and exp[0, 5] > 20000
+    got = s4g.scan_host(db, q, sc, block_pipe=True)
+    st = s4gd.scan_stats(0)
+    assert np.array_equal(got, exp)
+    assert st["list_pairs"] == len(qs) * len(ts) and st["speculative"] >= 1 and 1 <= st["rechecked"] <= 4 and st["tier_drift"] == 0 and st["pair_items"] == 0, st
+    got = s4g.scan_host(db, q, sc, block_pipe=True, no_spec=True)
+    st = s4gd.scan_stats(0)
+    assert np.array_equal(got, exp) and st["list_pairs"] == 0 and st["speculative"] == 0 and st["rechecked"] == 0, st
+    one = s4g.QuerySet([qs[2]])
+    got = s4g.scan_host(db, one, sc, block_pipe=True)
+    st = s4gd.scan_stats(0)
+    assert np.array_equal(got[0], exp[2]) and st["list_pairs"] == len(ts) and st["rechecked"] >= 1, st
+    # other gap penalties: a frame that drifts twice as fast (lower mark), and one that no longer fits (the pipeline refuses: tiers by bound)
+    for go, ge in ((11, 2), (12, 5)):
+        sc2 = s4g.Scorer("BLOSUM_62", go, ge)
+        exp2 = oracle_mod.scan(qs, ts, blosum62, go, ge, threads=8)
+        assert np.array_equal(s4g.scan_host(db, q, sc2, block_pipe=True), exp2), (go, ge)
 
 
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
@@ -1448,13 +1490,17 @@ def test_partial_group_split_mid_size_scan(s4g, oracle_mod, blosum62, scorer):
     assert np.array_equal(s4g.scan_host(dbm, q4, scorer), exp_m)
     st = device.scan_stats(0)
     assert st["list_pairs"] == 4 * 17000 and st["pair_items"] + st["tier_drift"] + st["tier_m3"] + st["tier_i16"] + st["tier_i32"] > 0, st
-    # a query beyond the drifting-frame window: the pipeline refuses the tile and the general route scores the call
+    # a query whose score bound is beyond the drifting-frame window: since round 6 the pipeline takes the tile speculatively (its strips mark
+    # what they cannot vouch for, sw_pair_recheck recomputes); told not to speculate it refuses the tile and the general route scores the call
     long_q = rand_seqs(rng, 1, 6000, 6000, 20) + qs[:2]
     ql = s4g.QuerySet(long_q)
     sub = ts[:4000]
     dbs = s4g.Database(sub)
     exp_l = oracle_mod.scan(long_q, sub, blosum62, 10, 1, threads=8)
     assert np.array_equal(s4g.scan_host(dbs, ql, scorer, block_pipe=True), exp_l)
+    st = device.scan_stats(0)
+    assert st["list_pairs"] == 3 * 4000 and st["speculative"] >= 1, st
+    assert np.array_equal(s4g.scan_host(dbs, ql, scorer, block_pipe=True, no_spec=True), exp_l)
     assert device.scan_stats(0)["list_pairs"] == 0
     ids, sc, cnt = s4g.scan_topk(db, q, scorer, 30, 1)
     ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
