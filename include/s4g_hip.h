@@ -184,9 +184,12 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
 #define S4G_SCAN_NO_DRIFT  8u   /* skip the drifting-frame kernel (sw_scan_pkd); those queries run in the maximum3 tier */
 #define S4G_SCAN_NO_PAIRS  16u  /* scan kernels only: no group goes to the one-wave-per-pair kernels; any other flag implies this */
 #define S4G_SCAN_NO_SPEC   32u  /* no speculative use of the drifting-frame kernel: tiers by score bound only */
-#define S4G_SCAN_BLOCK_PIPE 64u /* every tile whose queries fit the drifting-frame window runs on the block-cooperative strip pipeline
-                                   (sw_scan_lists in scan mode: the four waves of a block on one (group, query pair) item) whatever the
-                                   query count; by default calls of 3 to 16 queries (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it */
+#define S4G_SCAN_BLOCK_PIPE 64u /* every tile of sequences up to 4096 residues runs on the block-cooperative strip pipeline (sw_scan_lists in
+                                   scan mode: the four waves of a block on one (group, query pair) item) whatever the query count -- queries
+                                   whose bound is beyond the drifting-frame window speculatively, with the exact recheck behind them (not with
+                                   S4G_SCAN_NO_SPEC: the tile then takes the general route); by default calls of 3 to 16 queries
+                                   (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it, and calls of one or two queries of
+                                   1200 residues or more against 65 536 sequences or more */
 #define S4G_SCAN_DIAG_FRAME 128u /* the drifting-frame tier runs sw_scan_pkd (frame grows per anti-diagonal, rounds 1-4) instead of sw_scan_pkc
                                    (frame grows per column, round 5): the same results, kept as an independent second form.  The flag wins
                                    over the process-wide S4G_SCAN_FRAME variable, which only moves the default of calls that do not set it */
