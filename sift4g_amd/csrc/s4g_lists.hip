@@ -592,7 +592,28 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, true>, kBlock, 0));
         cx->grid_pipe = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
     }
-    const uint32_t grid = std::max(1u, std::min(cx->grid_pipe, n_items));
+    // Twelve waves to a block (round 6) where the call is bound by the LATENCY of its longest item, not by throughput: long queries
+    // (>= 1200 rows: tens to hundreds of strips per item) whose longest item, walked by four waves, outlasts by 1.5 x what a block's
+    // share of ALL items amounts to.  One block to a CU then, three waves per SIMD: an item's strips go through the issue slots of a
+    // whole CU instead of one wave per SIMD next to two other blocks' waves.  (Short queries keep four waves: twelve were measured in
+    // round 3 on 350-row queries -- 3.8 against 5.2 ms for the longest item alone, but 8.9 against 10.9 TCUPS once the chip is full.)
+    // S4G_SCAN_PIPE_WAVES=4|12 forces one form (tests, A/B).
+    bool wide = false;
+    {
+        uint32_t rows_max = 0;
+        uint64_t rows_sum = 0;                                    // over the query pairs: the longer member
+        for (uint32_t p = 0; p < n_pairs; ++p) { rows_max = std::max(rows_max, q->len[order[2 * p]]); rows_sum += q->len[order[2 * p]]; }
+        const double longest = (double)rows_max * t.max_len4;
+        const double share = (double)rows_sum * ((double)t.padded_residues / 256.0) / (double)std::max(1u, std::min(cx->grid_pipe, n_items));
+        wide = rows_max >= 1200 && longest > 1.5 * share;
+        if (const char* e = getenv("S4G_SCAN_PIPE_WAVES")) wide = atoi(e) == 12 ? true : (atoi(e) == 4 ? false : wide);
+    }
+    if (wide && cx->grid_pipe_wide == 0) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, true, 12>, 12 * 64, 0));
+        cx->grid_pipe_wide = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+    }
+    const uint32_t grid = std::max(1u, std::min(wide ? cx->grid_pipe_wide : cx->grid_pipe, n_items));
     const uint64_t ws_slot = 2ull * std::max(1u, t.max_len4) * 64 * 4;
     const uint64_t ws_bytes = ws_slot * 4 * kListBufs * grid;
     if (cx->ws_bytes < ws_bytes) {
@@ -612,8 +633,10 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     a.prio_cost = 0;        // (raised wave priority for the longest items was measured: no change -- their latency is their own strips', not their neighbours')
     a.grp_perm = d_perm; a.scan_scores = d_scores; a.score_stride = stride; a.q_begin = q_begin;
     a.spec_base = spec ? (uint32_t)(cap - step_c) : 0u;
-    hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    if (wide) hipLaunchKernelGGL((sw_scan_lists<kListRows, true, 12>), dim3(grid), dim3(12 * 64), 0, stream, a);
+    else hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
     HIP_TRY(hipGetLastError());
+    cx->stat_pipe_wide = wide ? 1 : 0;
     *used = true;
     if (speculative) *speculative = spec;
     return S4G_OK;

@@ -278,10 +278,14 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 // block of profile scores ahead: 837 instead of 845 vector instructions per chunk, no scratch, 159 VGPRs -- and measured it neutral
 // (729k pairs 10.2-10.8 against 10.5-10.9 ms, 8 queries x 100k 8.60 against 8.70 ms, 4 queries 5.70 against 5.56 ms); four waves
 // per SIMD would need 128 VGPRs, 31 fewer than the two score vectors and two residue streams of this kernel leave.  Not kept.)
-template <int R, bool SCAN = false>
-__global__ __launch_bounds__(kBlock, 3) void sw_scan_lists(const ListArgs a) {
+// W: waves per block.  Four everywhere but in scan-mode calls that are bound by the LATENCY of their longest item (few long queries
+// against a large database, s4g_lists.hip scan_tile_pipelined): there twelve -- one block to a CU, three waves per SIMD, the register
+// budget of the four-wave form -- walk an item's strips, so its latency drops towards what one CU can issue (round 6).
+template <int R, bool SCAN = false, int W = kWavesPerBlock>
+__global__ __launch_bounds__(W * 64, 3) void sw_scan_lists(const ListArgs a) {
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
-    constexpr int W = kWavesPerBlock, kThreads = kBlock;
+    static_assert(1024 + W * R * 256 + 4096 <= 160 * 1024, "profile tables of the block's waves must fit gfx950's LDS");
+    constexpr int kThreads = W * 64;
     __shared__ __attribute__((aligned(16))) char lds[1024 + W * R * 256];
     __shared__ ListSync<W> sy;
     const int lane = threadIdx.x & 63;

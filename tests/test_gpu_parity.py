@@ -1374,6 +1374,42 @@ def test_speculative_block_pipeline_marks_and_rechecks(s4g, oracle_mod, blosum62
         assert np.array_equal(s4g.scan_host(db, q, sc2, block_pipe=True), exp2), (go, ge)
 
 
+@pytest.mark.parametrize("waves", ["4", "12"])
+def test_block_pipeline_with_four_and_twelve_waves_per_block(s4g, oracle_mod, blosum62, scorer, monkeypatch, waves):
+    """Round 6: the pipeline's block is four waves, or twelve where a call is bound by the latency of its longest item (few long queries
+    against a large database: one block to a CU, an item's strips on three waves per SIMD).  S4G_SCAN_PIPE_WAVES forces one form: every
+    letter code, ragged groups, query counts from 1 to 9 (items that end inside a block's round of strips, items shorter than the
+    block has waves), strips around the strip height, a long query beyond the window (speculative) -- the same matrix as the oracle's;
+    and the library's own choice on a call of one long query against 70 000 targets equals the forced forms."""
+    import torch
+    monkeypatch.setenv("S4G_SCAN_PIPE_WAVES", waves)
+    rng = np.random.default_rng(640 + int(waves))
+    ts = rand_seqs(rng, 700, 1, 500, 26) + [rand_seqs(rng, 1, 3900, 3900)[0]]
+    for qlens in ([1], [33, 31], [350, 97, 5], [64, 65, 63, 32, 1, 128, 129, 700, 12], [5200, 2100, 40]):
+        qs = [rand_seqs(rng, 1, l, l, 26 if l < 1000 else 20)[0] for l in qlens]
+        ts[7] = qs[0].copy()
+        exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=os.cpu_count() or 8)
+        got = s4g.scan_host(s4g.Database(ts), s4g.QuerySet(qs), scorer, block_pipe=True)
+        bad = np.argwhere(got != exp)
+        assert bad.size == 0, (waves, qlens, bad[:5].tolist())
+    if waves == "12":                       # the library's own choice against the forced forms, at a size where it takes the pipeline by itself
+        from sift4g_amd import synth
+        cfg = synth.make_config(2, n_queries=2, n_targets=70000, homologs_per_query=2)
+        db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+        q = s4g.QuerySet([rand_seqs(rng, 1, 2600, 2600)[0]])
+        outs = []
+        for w in ("12", "4", None):
+            if w: monkeypatch.setenv("S4G_SCAN_PIPE_WAVES", w)
+            else: monkeypatch.delenv("S4G_SCAN_PIPE_WAVES")
+            out = torch.empty((1, db.n), dtype=torch.int32, device="cuda:0")
+            s4g.scan(db, q, scorer, out)
+            torch.cuda.synchronize()
+            from sift4g_amd import device as s4gd
+            assert s4gd.scan_stats(0)["list_pairs"] == db.n
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
     """sw_pair_scan_band: queries of 1025 .. 5000 residues (2 to 5 bands of 1024 rows, partial last bands of 1 row and of
     1023 rows), alignments that cross band boundaries, targets across window boundaries, three scorers, and the scan
