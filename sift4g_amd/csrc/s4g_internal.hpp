@@ -188,7 +188,6 @@ struct DeviceCtx {
     uint32_t grid_lists = 0;
     uint32_t grid_pipe = 0;                 // blocks of sw_scan_lists<R, true> the device holds (scan_tile_pipelined)
     uint32_t grid_pipe_wide = 0;            // ... of its twelve-wave form (latency-bound calls of few long queries)
-    uint32_t stat_pipe_wide = 0;            // the last pipelined tile launch used the twelve-wave form (reported through S4G_PROFILE only)
     uint64_t stat_tier[4] = {0, 0, 0, 0};
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
     uint64_t stat_coop_scan = 0, stat_coop_trace = 0;      // pairs of the last pair submission / traceback call on the cooperative kernels

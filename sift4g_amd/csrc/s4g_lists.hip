@@ -636,7 +636,6 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     if (wide) hipLaunchKernelGGL((sw_scan_lists<kListRows, true, 12>), dim3(grid), dim3(12 * 64), 0, stream, a);
     else hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
     HIP_TRY(hipGetLastError());
-    cx->stat_pipe_wide = wide ? 1 : 0;
     *used = true;
     if (speculative) *speculative = spec;
     return S4G_OK;
