@@ -188,6 +188,7 @@ struct DeviceCtx {
     uint32_t grid_lists = 0;
     uint32_t grid_pipe = 0;                 // blocks of sw_scan_lists<R, true> the device holds (scan_tile_pipelined)
     uint32_t grid_pipe_wide = 0;            // ... of its twelve-wave form (latency-bound calls of few long queries)
+    uint32_t grid_pipe2 = 0, grid_pipe2_wide = 0;   // ... of the forms whose items may pair two GROUPS under a lone query (odd query counts)
     uint64_t stat_tier[4] = {0, 0, 0, 0};
     uint64_t stat_spec_queries = 0, stat_pair_items = 0, stat_list_pairs = 0;
     uint64_t stat_coop_scan = 0, stat_coop_trace = 0;      // pairs of the last pair submission / traceback call on the cooperative kernels

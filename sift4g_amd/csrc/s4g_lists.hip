@@ -464,7 +464,7 @@ int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer*
     a.q_codes = q->d_codes; a.q_off = q->d_off; a.q_len = q->d_len; a.mat = cx->d_mat;
     a.scores = B.scores; a.ws = cx->d_ws; a.ws_slot = ws_slot; a.counter = cx->d_counter + kListCounter; a.n_items = n_items;
     a.open = (uint32_t)scorer->open; a.ext = (uint32_t)scorer->ext; a.floor_bits = (uint32_t)(bias | (bias << 16));
-    a.grp_perm = nullptr; a.scan_scores = nullptr; a.score_stride = 0; a.q_begin = 0; a.spec_base = 0;       // (scan-mode fields)
+    a.grp_perm = nullptr; a.grp_off = nullptr; a.grp_len4 = nullptr; a.scan_scores = nullptr; a.score_stride = 0; a.q_begin = 0; a.spec_base = 0;       // (scan-mode fields)
     {   // Critical-path items run at raised wave priority (the SIMD arbitrates issue by priority, then age).  A launch of
         // lists has only about two items per resident wave, so "large against the wave's share" would mean nearly all of
         // them; instead: the longest items, as many as there are SIMDs to own (their count is estimated from the length
@@ -548,8 +548,14 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         if (!allow_spec || !speculative || bias + step_c + cols * (uint64_t)scorer->ext + 6144 /* kSpecSpan, s4g_scan.hip */ > cap) return S4G_OK;
         spec = true;
     }
-    const uint32_t n_pairs = (q_count + 1) / 2;
-    const uint64_t n_items64 = (uint64_t)t.n_groups * n_pairs;
+    // Items: every group of the tile under every PAIR of queries (neighbours in length order).  An odd query count leaves the shortest
+    // query without a partner; it takes two neighbouring GROUPS per item instead (sw_scan_lists<R, 2>: the halves of a register read
+    // different targets), so a lone query fills both halves of its registers instead of computing every cell twice.  That pays where the
+    // call is bound by throughput (one query against 570 000 targets: 12.3 -> 6.x ms); a call bound by its longest item's latency (one
+    // query against 100 000) takes the same time either way.
+    const bool odd = (q_count & 1u) != 0 && t.d_grp_off != nullptr && t.d_grp_len4 != nullptr && getenv("S4G_SCAN_PIPE_NO_GROUP_PAIRS") == nullptr;
+    const uint32_t n_pairs = odd ? q_count / 2 : (q_count + 1) / 2;             // pairs of two queries (without the lone one when it pairs groups)
+    const uint64_t n_items64 = (uint64_t)t.n_groups * n_pairs + (odd ? ((uint64_t)t.n_groups + 1) / 2 : 0);
     if (n_items64 > (1u << 22)) return S4G_OK;
     const uint32_t n_items = (uint32_t)n_items64;
 
@@ -583,13 +589,19 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         for (uint32_t p = 0; p < n_pairs; ++p) {
             ListItem it;
             it.qa = order[2 * p]; it.qb = 2 * p + 1 < q_count ? order[2 * p + 1] : order[2 * p];
-            it.first_a = g; it.first_b = 0; it.na = 64; it.nb = 64; it.len4 = len4; it.res_off = t.h_grp_off[g];
+            it.first_a = g; it.first_b = odd ? g : 0; it.na = 64; it.nb = 64; it.len4 = len4; it.res_off = t.h_grp_off[g];
+            h_items[at++] = it;
+        }
+        if (odd && (g & 1u) == 0) {                               // the query without a partner on groups g and g + 1 (g alone at the end)
+            ListItem it;
+            it.qa = it.qb = order[q_count - 1];
+            it.first_a = g; it.first_b = g + 1 < t.n_groups ? g + 1 : g; it.na = 64; it.nb = 64; it.len4 = len4; it.res_off = t.h_grp_off[g];
             h_items[at++] = it;
         }
     }
     if (cx->grid_pipe == 0) {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, true>, kBlock, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, 1>, kBlock, 0));
         cx->grid_pipe = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
     }
     // Twelve waves to a block (round 6) where the call is bound by the LATENCY of its longest item, not by throughput: long queries
@@ -603,6 +615,7 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         uint32_t rows_max = 0;
         uint64_t rows_sum = 0;                                    // over the query pairs: the longer member
         for (uint32_t p = 0; p < n_pairs; ++p) { rows_max = std::max(rows_max, q->len[order[2 * p]]); rows_sum += q->len[order[2 * p]]; }
+        if (odd) { rows_max = std::max(rows_max, q->len[order[q_count - 1]]); rows_sum += (q->len[order[q_count - 1]] + 1) / 2; }   // half as many items
         const double longest = (double)rows_max * t.max_len4;
         const double share = (double)rows_sum * ((double)t.padded_residues / 256.0) / (double)std::max(1u, std::min(cx->grid_pipe, n_items));
         wide = rows_max >= 1200 && longest > 1.5 * share;
@@ -610,10 +623,17 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     }
     if (wide && cx->grid_pipe_wide == 0) {
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, true, 12>, 12 * 64, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, 1, 12>, 12 * 64, 0));
         cx->grid_pipe_wide = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
     }
-    const uint32_t grid = std::max(1u, std::min(wide ? cx->grid_pipe_wide : cx->grid_pipe, n_items));
+    if (odd && cx->grid_pipe2 == 0) {
+        int per_cu = 0, per_cu_w = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sw_scan_lists<kListRows, 2>, kBlock, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, (const void*)sw_scan_lists<kListRows, 2, 12>, 12 * 64, 0));
+        cx->grid_pipe2 = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+        cx->grid_pipe2_wide = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu_w);
+    }
+    const uint32_t grid = std::max(1u, std::min(odd ? (wide ? cx->grid_pipe2_wide : cx->grid_pipe2) : (wide ? cx->grid_pipe_wide : cx->grid_pipe), n_items));
     const uint64_t ws_slot = 2ull * std::max(1u, t.max_len4) * 64 * 4;
     const uint64_t ws_bytes = ws_slot * 4 * kListBufs * grid;
     if (cx->ws_bytes < ws_bytes) {
@@ -633,8 +653,14 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     a.prio_cost = 0;        // (raised wave priority for the longest items was measured: no change -- their latency is their own strips', not their neighbours')
     a.grp_perm = d_perm; a.scan_scores = d_scores; a.score_stride = stride; a.q_begin = q_begin;
     a.spec_base = spec ? (uint32_t)(cap - step_c) : 0u;
-    if (wide) hipLaunchKernelGGL((sw_scan_lists<kListRows, true, 12>), dim3(grid), dim3(12 * 64), 0, stream, a);
-    else hipLaunchKernelGGL((sw_scan_lists<kListRows, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    a.grp_off = t.d_grp_off; a.grp_len4 = t.d_grp_len4;
+    if (odd) {
+        if (wide) hipLaunchKernelGGL((sw_scan_lists<kListRows, 2, 12>), dim3(grid), dim3(12 * 64), 0, stream, a);
+        else hipLaunchKernelGGL((sw_scan_lists<kListRows, 2>), dim3(grid), dim3(kBlock), 0, stream, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((sw_scan_lists<kListRows, 1, 12>), dim3(grid), dim3(12 * 64), 0, stream, a);
+        else hipLaunchKernelGGL((sw_scan_lists<kListRows, 1>), dim3(grid), dim3(kBlock), 0, stream, a);
+    }
     HIP_TRY(hipGetLastError());
     *used = true;
     if (speculative) *speculative = spec;

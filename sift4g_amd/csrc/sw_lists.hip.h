@@ -60,6 +60,12 @@ struct ListArgs {
     // (group first_a of the tile, queries qa / qb), `res` the tile's residues, res_off the group's offset; both halves of a lane
     // read the SAME target
     const uint32_t* __restrict__ grp_perm;      // [G * 64] output column of (group, lane); ~0u = empty lane
+    // MODE 2 (round 6: a call with an ODD number of queries -- one query above all): the halves of an item may read DIFFERENT groups,
+    // (qa on group first_a | qb on group first_b), so that the query without a partner fills both halves of its registers with two
+    // neighbouring groups instead of computing every cell twice; first_b == first_a is MODE 1's pair of queries on one group.  The upper
+    // half's residues come from the tile in place: dword offset and chunks of group first_b out of the tile's tables
+    const uint64_t* __restrict__ grp_off;       // [G] dword offset of a group's residues in `res`
+    const uint32_t* __restrict__ grp_len4;      // [G] 4-column chunks of a group
     int32_t* __restrict__ scan_scores;          // [query - q_begin][score_stride]
     uint64_t score_stride;
     uint32_t q_begin;
@@ -190,8 +196,8 @@ __device__ __forceinline__ unsigned lds_load32(const unsigned* p) {
 
 // One strip of RR rows over all columns of the item; res points at the item's block + lane (low half; high half 64 dwords on).
 // prod: progress word of the wave that owns the strip above (FIRST: unused), need_tag = that strip's tag; mine / my_tag: this wave's.
-template <int R, int RR, bool FIRST, bool SCAN>
-__device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
+template <int R, int RR, bool FIRST, int MODE>
+__device__ __forceinline__ void lst_strip(const uint32_t* res, const uint32_t* resb, unsigned len4b, unsigned len4, const char* prof, v4i* wsH, v4i* wsF, int lane,
                                           bool last, int& best, int eo, int e2v, int e2, int B2,
                                           const unsigned long long* prod, unsigned long long need_tag,
                                           unsigned long long* mine, unsigned long long my_tag) {
@@ -215,8 +221,15 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
             }
         }
     };
-    constexpr unsigned kStride = SCAN ? 64u : 128u;          // dwords per 4-column chunk of the item's block
-    uint32_t ra_n = res[0], rb_n = SCAN ? ra_n : res[64];
+    constexpr unsigned kStride = MODE ? 64u : 128u;          // dwords per 4-column chunk of the item's block
+    // the upper half's residues: the gathered block's second row (lists), the lower half's own (a pair of queries on one group), or
+    // another group of the tile in place, padded with code 31 beyond its own length (MODE 2; the item runs to the longer group)
+    auto load_b = [&](unsigned c, uint32_t ra) -> uint32_t {
+        if constexpr (MODE == 0) return res[(uint64_t)c * kStride + 64];
+        else if constexpr (MODE == 1) return ra;
+        else return c < len4b ? resb[(uint64_t)c * 64] : 0x1F1F1F1Fu;
+    };
+    uint32_t ra_n = res[0], rb_n = load_b(0, ra_n);
     v4i hb_n = {0, 0, 0, 0}, fb_n = {0, 0, 0, 0};
     if (!first && len4) { wait_for(1); hb_n = wsH[lane]; fb_n = wsF[lane]; }
     // the profile reads run TWO blocks of four rows ahead of the arithmetic: one block (22 instructions) does not cover an LDS round
@@ -228,7 +241,7 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
         const v4i hb = hb_n, fb = fb_n;
         const unsigned cn = (c + 1 < len4) ? c + 1 : c;
         ra_n = res[(uint64_t)cn * kStride];
-        rb_n = SCAN ? ra_n : res[(uint64_t)cn * kStride + 64];
+        rb_n = load_b(cn, ra_n);
         if (!first) { wait_for(cn + 1); hb_n = wsH[(uint64_t)cn * 64 + lane]; fb_n = wsF[(uint64_t)cn * 64 + lane]; }
         v4i ho, fo;
 #pragma unroll
@@ -281,8 +294,9 @@ __device__ __forceinline__ void lst_strip(const uint32_t* res, unsigned len4, co
 // W: waves per block.  Four everywhere but in scan-mode calls that are bound by the LATENCY of their longest item (few long queries
 // against a large database, s4g_lists.hip scan_tile_pipelined): there twelve -- one block to a CU, three waves per SIMD, the register
 // budget of the four-wave form -- walk an item's strips, so its latency drops towards what one CU can issue (round 6).
-template <int R, bool SCAN = false, int W = kWavesPerBlock>
+template <int R, int MODE = 0, int W = kWavesPerBlock>
 __global__ __launch_bounds__(W * 64, 3) void sw_scan_lists(const ListArgs a) {
+    constexpr bool SCAN = MODE != 0;
     static_assert(R % 8 == 0 && R <= kQueryAlign, "strip height");
     static_assert(1024 + W * R * 256 + 4096 <= 160 * 1024, "profile tables of the block's waves must fit gfx950's LDS");
     constexpr int kThreads = W * 64;
@@ -373,6 +387,15 @@ __global__ __launch_bounds__(W * 64, 3) void sw_scan_lists(const ListArgs a) {
         v4i* wsH = ws_block + (uint64_t)buf * (a.ws_slot / 4);
         v4i* wsF = wsH + (uint64_t)len4 * 64;
         const uint32_t* res = a.res + it.res_off + lane;
+        const uint32_t* resb = res;
+        unsigned len4b = len4;
+        if constexpr (MODE == 2) {
+            if (it.first_b != it.first_a) {
+                const uint64_t ob = a.grp_off[it.first_b];
+                resb = a.res + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob)) + lane;
+                len4b = (unsigned)__builtin_amdgcn_readfirstlane((int)a.grp_len4[it.first_b]);
+            }
+        }
         const uint8_t* qca = a.q_codes + a.q_off[it.qa];
         const uint8_t* qcb = a.q_codes + a.q_off[it.qb];
         const unsigned cap_a = (a.q_len[it.qa] + kQueryAlign - 1) / kQueryAlign * kQueryAlign + kQueryAlign;      // readable bytes of the queries
@@ -413,16 +436,16 @@ __global__ __launch_bounds__(W * 64, 3) void sw_scan_lists(const ListArgs a) {
 #define S4G_LAST_STRIP(RR_)                                                                                  \
         if constexpr (R > RR_) {                                                                             \
             if (!done && rr == RR_) {                                                                        \
-                if (first) lst_strip<R, RR_, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag); \
-                else lst_strip<R, RR_, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);    \
+                if (first) lst_strip<R, RR_, true, MODE>(res, resb, len4b, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag); \
+                else lst_strip<R, RR_, false, MODE>(res, resb, len4b, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);    \
                 done = true;                                                                                 \
             }                                                                                                \
         }
         S4G_LAST_STRIP(8) S4G_LAST_STRIP(16) S4G_LAST_STRIP(24)
 #undef S4G_LAST_STRIP
         if (!done) {
-            if (first) lst_strip<R, R, true, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
-            else lst_strip<R, R, false, SCAN>(res, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
+            if (first) lst_strip<R, R, true, MODE>(res, resb, len4b, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
+            else lst_strip<R, R, false, MODE>(res, resb, len4b, len4, prof, wsH, wsF, lane, last, best, eo, e2v, e2, B2, prod, need_tag, mine, my_tag);
         }
         const int bframe = best;                         // the strip's maximum still IN the frame: the witness of a speculative launch
         best = (int)((unsigned)best - (unsigned)zend);   // the true maximum of the strip (no borrow: best~ >= z in both halves)
@@ -459,7 +482,12 @@ __global__ __launch_bounds__(W * 64, 3) void sw_scan_lists(const ListArgs a) {
                 if (lo == kMarked) lo = kScoreUnsure;
                 if (hi == kMarked) hi = kScoreUnsure;
                 const unsigned p = a.grp_perm[(uint64_t)it.first_a * 64 + lane];
-                if (p != 0xFFFFFFFFu) {
+                if constexpr (MODE == 2) {
+                    // (qa on group first_a | qb on group first_b); an upper half that repeats the lower one (the last group of an odd count) is dropped
+                    const unsigned pb = a.grp_perm[(uint64_t)it.first_b * 64 + lane];
+                    if (p != 0xFFFFFFFFu) a.scan_scores[(uint64_t)(it.qa - a.q_begin) * a.score_stride + p] = lo;
+                    if (pb != 0xFFFFFFFFu && !(it.qb == it.qa && it.first_b == it.first_a)) a.scan_scores[(uint64_t)(it.qb - a.q_begin) * a.score_stride + pb] = hi;
+                } else if (p != 0xFFFFFFFFu) {
                     a.scan_scores[(uint64_t)(it.qa - a.q_begin) * a.score_stride + p] = lo;
                     if (it.qb != it.qa) a.scan_scores[(uint64_t)(it.qb - a.q_begin) * a.score_stride + p] = hi;
                 }

@@ -1410,6 +1410,41 @@ def test_block_pipeline_with_four_and_twelve_waves_per_block(s4g, oracle_mod, bl
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_odd_query_counts_pair_groups_in_the_block_pipeline(s4g, oracle_mod, blosum62, scorer, monkeypatch):
+    """Round 6: a query without a partner takes two neighbouring GROUPS of the tile per item (sw_scan_lists<R, 2>: the halves of a register
+    read different targets) instead of computing every cell twice.  One, three and seven queries against a tile with an odd number of
+    groups, a ragged last group, targets of very different lengths in neighbouring groups (the shorter group is padded in flight), every
+    letter code: the same matrix as the oracle's and as the form that repeats the query (S4G_SCAN_PIPE_NO_GROUP_PAIRS), four and twelve
+    waves to a block; and one query against 200 000 targets takes the pipeline by itself."""
+    import torch
+    rng = np.random.default_rng(650)
+    ts = rand_seqs(rng, 64 * 5 + 17, 1, 700, 26)
+    ts[3] = rand_seqs(rng, 1, 3500, 3500)[0]
+    for qlens in ([300], [61, 350, 97], [5, 33, 64, 65, 128, 200, 410]):
+        qs = [rand_seqs(rng, 1, l, l, 26)[0] for l in qlens]
+        ts[9] = qs[-1].copy()
+        exp = oracle_mod.scan(qs, ts, blosum62, 10, 1, threads=os.cpu_count() or 8)
+        db, q = s4g.Database(ts), s4g.QuerySet(qs)
+        for waves in ("4", "12"):
+            monkeypatch.setenv("S4G_SCAN_PIPE_WAVES", waves)
+            got = s4g.scan_host(db, q, scorer, block_pipe=True)
+            assert np.array_equal(got, exp), (qlens, waves, np.argwhere(got != exp)[:5].tolist())
+            monkeypatch.setenv("S4G_SCAN_PIPE_NO_GROUP_PAIRS", "1")
+            assert np.array_equal(s4g.scan_host(db, q, scorer, block_pipe=True), exp), (qlens, waves, "repeated query")
+            monkeypatch.delenv("S4G_SCAN_PIPE_NO_GROUP_PAIRS")
+        monkeypatch.delenv("S4G_SCAN_PIPE_WAVES")
+    from sift4g_amd import synth, device as s4gd
+    cfg = synth.make_config(3, n_queries=2, n_targets=200000, homologs_per_query=2)
+    db = s4g.Database(codes=cfg["t_codes"], offsets=cfg["t_off"])
+    q = s4g.QuerySet([rand_seqs(rng, 1, 320, 320)[0]])
+    out, ref = (torch.empty((1, db.n), dtype=torch.int32, device="cuda:0") for _ in range(2))
+    s4g.scan(db, q, scorer, out)
+    torch.cuda.synchronize()
+    assert s4gd.scan_stats(0)["list_pairs"] == db.n                      # the library's own choice: the pipeline
+    s4g.scan(db, q, scorer, ref, no_pairs=True)                          # the scan kernels
+    assert torch.equal(out, ref)
+
+
 def test_pair_scan_bands_for_long_queries(s4g, oracle_mod, blosum62, scorer):
     """sw_pair_scan_band: queries of 1025 .. 5000 residues (2 to 5 bands of 1024 rows, partial last bands of 1 row and of
     1023 rows), alignments that cross band boundaries, targets across window boundaries, three scorers, and the scan
