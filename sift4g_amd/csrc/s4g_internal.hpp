@@ -311,6 +311,7 @@ int pairs_enqueue(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scor
 int score_lists_device(const s4g_db* db, const s4g_queries* q, const s4g_scorer* scorer, const uint32_t* sel_idx, uint32_t n_sel,
                        const uint32_t* pair_q, const uint32_t* pair_t, int32_t* h_scores, bool force, uint32_t forced_split, bool* used);
 // s4g_lists.hip: a tile scanned by a few queries on the block-cooperative strip pipeline (sw_scan_lists<R, true>); *used = false: not applicable
+constexpr uint64_t kSpecSpan = 6144;    // scores a speculative query can reach without a recheck, at least (s4g_scan.hip make_plan, s4g_lists.hip scan_tile_pipelined)
 int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, uint32_t q_begin, uint32_t q_count, const s4g_scorer* scorer,
                         int32_t* d_scores, uint64_t stride, const uint32_t* d_perm, hipStream_t stream, bool* used,
                         bool allow_spec = false, bool* speculative = nullptr);   // *speculative: the caller must run recheck_marked over the tile's scores

@@ -545,7 +545,7 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
     for (uint32_t i = 0; i < q_count; ++i) {
         if (q->len[order[i]] == 0) return S4G_OK;
         if (q->score_bound[order[i]] + bias + cols * (uint64_t)scorer->ext <= cap) continue;
-        if (!allow_spec || !speculative || bias + step_c + cols * (uint64_t)scorer->ext + 6144 /* kSpecSpan, s4g_scan.hip */ > cap) return S4G_OK;
+        if (!allow_spec || !speculative || bias + step_c + cols * (uint64_t)scorer->ext + kSpecSpan > cap) return S4G_OK;
         spec = true;
     }
     // Items: every group of the tile under every PAIR of queries (neighbours in length order).  An odd query count leaves the shortest

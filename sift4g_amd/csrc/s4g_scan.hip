@@ -50,7 +50,6 @@ static int frame_env() {
     static const int v = []() { const char* e = getenv("S4G_SCAN_FRAME"); return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
     return v;
 }
-constexpr uint64_t kSpecSpan = 6144;    // scores a speculative query can reach without a recheck, at least
 
 int device_props(DeviceCtx* cx) {
     if (!cx->have_prop) {
