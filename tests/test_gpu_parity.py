@@ -1418,7 +1418,7 @@ def test_odd_query_counts_pair_groups_in_the_block_pipeline(s4g, oracle_mod, blo
     waves to a block; and one query against 200 000 targets takes the pipeline by itself."""
     import torch
     rng = np.random.default_rng(650)
-    ts = rand_seqs(rng, 64 * 5 + 17, 1, 700, 26)
+    ts = rand_seqs(rng, 64 * 4 + 17, 1, 700, 26)                    # five groups: the last item of a lone query has no second group
     ts[3] = rand_seqs(rng, 1, 3500, 3500)[0]
     for qlens in ([300], [61, 350, 97], [5, 33, 64, 65, 128, 200, 410]):
         qs = [rand_seqs(rng, 1, l, l, 26)[0] for l in qlens]
