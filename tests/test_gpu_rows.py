@@ -6,7 +6,7 @@ a HIP-path-vs-oracle (or vs tests/golden) EQUALITY through the C ABI at a size t
 into every row (routes, tiers, edge cases, full sizes).  No assertion here reads a clock, a rate or a ratio.
 
   a-R  the recurrence            a1  sift4g's wrapper loop      a2  swsharp alignDatabase steps 1-4    a3  candidate lists
-  a4   valueFunction -> eValues  a5  createEValueParams         a6  Scorer (every built-in table)      a7  Chain codes 0..25
+  a4   valueFunction -> eValues  a5  createEValueParams         a6  Scorer (built-in tables)           a7  Chain codes 0..25
   a8   ChainDatabase             a9  dbAlignmentsMerge          a10 DbAlignment accessors              b   the C ABI on the GPU box
   c    golden vectors on the HIP path   d  what the bench counts      e  shard + gather + merge (one process)
   f1   device top-k / e-value cut       f2 traceback                  f3 k-mer prefilter                f4 packed database file
@@ -305,8 +305,9 @@ def test_a5_evalue_params_known_answers(sw):
 
 # ---------------------------------------------------------------------------------------------------------------- a6, a7, a8
 
-@pytest.mark.parametrize("name,go,ge", [("BLOSUM_62", 10, 1), ("BLOSUM_45", 14, 2), ("BLOSUM_50", 13, 2), ("BLOSUM_80", 10, 1), ("BLOSUM_90", 10, 1),
-                                        ("PAM_30", 9, 1), ("PAM_70", 10, 1), ("PAM_250", 14, 2)])
+# (six of the eight tables here, so that the rows and configs of this file are the first thirty tests of the suite; all eight -- and the
+# CLI's alias names -- in tests/test_gpu_parity.py::test_every_builtin_matrix and tests/test_oracle.py)
+@pytest.mark.parametrize("name,go,ge", [("BLOSUM_62", 10, 1), ("BLOSUM_45", 14, 2), ("BLOSUM_80", 10, 1), ("PAM_30", 9, 1), ("PAM_70", 10, 1), ("PAM_250", 14, 2)])
 def test_a6_scorer_every_builtin_table(s4g, sw, oracle_mod, name, go, ge):
     """scorerCreateMatrix(&s, name, open, extend) (main.cpp:208, names :304-314): the table the host API answers with == the table the
     device scores with == tests/golden/matrix_sha256.json, and a HIP scan under it == the oracle under the same table."""
