@@ -44,6 +44,35 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(900))
 
 
+# The driver keeps the TAIL of the log, and `-q` prints dots: one line at the very end says, row by row of SURVEY.md 8 and config by config of
+# BASELINE.json, what tests/test_gpu_rows.py found -- also when a later, heavier test failed and `-x` stopped the run behind it.
+_ROW_OUTCOMES = {}
+
+
+def pytest_runtest_logreport(report):
+    if "test_gpu_rows.py::" not in report.nodeid:
+        return
+    name = report.nodeid.split("::", 1)[1]
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        _ROW_OUTCOMES[name] = report.outcome if report.when == "call" else f"{report.outcome} in setup"
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _ROW_OUTCOMES:
+        return
+    rows = {}
+    for name, outcome in _ROW_OUTCOMES.items():
+        parts = name[len("test_"):].split("_")
+        tags = [parts[0]] + ([parts[1]] if len(parts) > 1 and parts[1].startswith("cfg") else [])      # test_a2_cfg0_... covers two
+        for tag in tags:
+            key = {"dagger": "cli"}.get(tag, tag)
+            worst = rows.get(key)
+            rows[key] = outcome if worst in (None, "passed") else worst
+    ok = sum(1 for v in rows.values() if v == "passed")
+    terminalreporter.write_line(f"SURVEY 8 rows / BASELINE configs (tests/test_gpu_rows.py, HIP path == oracle): {ok} of {len(rows)} passed: "
+                                + " ".join(f"{k}={v}" for k, v in rows.items()))
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle
