@@ -189,7 +189,7 @@ int s4g_scan(const s4g_db* db, const s4g_queries* q, uint32_t q_begin, uint32_t 
                                    whose bound is beyond the drifting-frame window speculatively, with the exact recheck behind them (not with
                                    S4G_SCAN_NO_SPEC: the tile then takes the general route); by default calls of 3 to 16 queries
                                    (S4G_SCAN_PIPE_MAX_QUERIES) against 16 384 sequences or more take it, and calls of one or two queries of
-                                   1200 residues or more against 65 536 sequences or more, or of any length against 196 608 or more (a
+                                   500 residues or more against 65 536 sequences or more, or of any length against 196 608 or more (a
                                    query without a partner pairs two groups of the tile per item there) */
 #define S4G_SCAN_DIAG_FRAME 128u /* the drifting-frame tier runs sw_scan_pkd (frame grows per anti-diagonal, rounds 1-4) instead of sw_scan_pkc
                                    (frame grows per column, round 5): the same results, kept as an independent second form.  The flag wins

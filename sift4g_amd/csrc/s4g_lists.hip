@@ -605,7 +605,7 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         cx->grid_pipe = (uint32_t)cx->prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
     }
     // Twelve waves to a block (round 6) where the call is bound by the LATENCY of its longest item, not by throughput: long queries
-    // (>= 1200 rows: tens to hundreds of strips per item) whose longest item, walked by four waves, outlasts by 1.5 x what a block's
+    // (>= 1200 rows, >= 500 for one or two queries: tens to hundreds of strips per item) whose longest item, walked by four waves, outlasts by 1.5 x what a block's
     // share of ALL items amounts to.  One block to a CU then, three waves per SIMD: an item's strips go through the issue slots of a
     // whole CU instead of one wave per SIMD next to two other blocks' waves.  (Short queries keep four waves: twelve were measured in
     // round 3 on 350-row queries -- 3.8 against 5.2 ms for the longest item alone, but 8.9 against 10.9 TCUPS once the chip is full.)
@@ -618,7 +618,7 @@ int scan_tile_pipelined(const s4g_db* db, const Tile& t, const s4g_queries* q, u
         if (odd) { rows_max = std::max(rows_max, q->len[order[q_count - 1]]); rows_sum += (q->len[order[q_count - 1]] + 1) / 2; }   // half as many items
         const double longest = (double)rows_max * t.max_len4;
         const double share = (double)rows_sum * ((double)t.padded_residues / 256.0) / (double)std::max(1u, std::min(cx->grid_pipe, n_items));
-        wide = rows_max >= 1200 && longest > 1.5 * share;
+        wide = rows_max >= (q_count <= 2 ? 500u : 1200u) && longest > 1.5 * share;     // (one or two queries: measured from 500 rows, s4g_scan.hip)
         if (const char* e = getenv("S4G_SCAN_PIPE_WAVES")) wide = atoi(e) == 12 ? true : (atoi(e) == 4 ? false : wide);
     }
     if (wide && cx->grid_pipe_wide == 0) {

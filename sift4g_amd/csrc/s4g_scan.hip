@@ -664,12 +664,15 @@ S4G_API int s4g_scan_flags(const s4g_db* db, const s4g_queries* q, uint32_t q_be
     // ... and whatever their length from 196 608 sequences on: there the call is bound by throughput, and the pipeline's items pair two
     // GROUPS under a query that has no partner (sw_scan_lists<R, 2>), where a scan-kernel item leaves half of every register idle.
     //   1 query of 350 residues, pipeline | split: 150 000 targets 5.1 | 5.1   200 000: 5.3 | 6.3   300 000: 5.4 | 8.1   400 000: 5.6 | 9.9   570 000: 6.8 | 13.8
+    // With twelve waves to a block (s4g_lists.hip: the form such a call gets) the length threshold is 500 rows (tools/few_query_scan.py,
+    // pipeline | split): 100 000 targets, 1 x 500: 5.3 | 5.8   1 x 600: 6.4 | 10.3   2 x 600: 6.7 | 10.7   1 x 900: 9.7 | 15.2   2 x 1100: 12.0 | 27.6;
+    // 70 000 targets, 1 x 600: 6.3 | 9.8   1 x 900: 9.5 | 10.1   1 x 1100: 12.2 | 23.5.
     uint32_t max_rows = 0;
     for (uint32_t i = 0; i < q_count; ++i) max_rows = std::max(max_rows, q->len[q_begin + i]);
     const bool want_pipe = (flags & S4G_SCAN_BLOCK_PIPE) != 0 ||
                            (flags == 0 && !(all_pairs && any_pairs) && pipe_max_queries() != 0 &&
                             ((q_count >= 3 && q_count <= pipe_max_queries() && db->n_seqs >= 256u * 64u) ||
-                             (q_count <= 2 && ((max_rows >= 1200 && db->n_seqs >= 1024u * 64u) || db->n_seqs >= 3072u * 64u))));
+                             (q_count <= 2 && ((max_rows >= 500 && db->n_seqs >= 1024u * 64u) || db->n_seqs >= 3072u * 64u))));
     flags &= ~S4G_SCAN_BLOCK_PIPE;
     std::vector<char> piped(db->tiles.size(), 0);
     uint64_t pipe_pairs = 0;
